@@ -1,0 +1,119 @@
+/* mgx.h -- C ABI of libmgx.so: the MI355X (gfx950) kernels of the Music Transformer hot path.
+ *
+ * The reference (SJTMusicTeam/MusicGeneration) has no native/FFI layer: its hot path is a
+ * sequence of ATen ops inside torch.nn.Module classes.  Each entry point below replaces one such
+ * op sequence; the reference lines it replaces are cited per function (paths relative to
+ * mg/model/MusicTransformer/).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host".
+ *  - the caller owns all buffers; the library allocates nothing and keeps no state.
+ *  - all launches are asynchronous on `stream` (a hipStream_t passed as void*); capturable.
+ *  - bf16 tensors are uint16_t storage (round-to-nearest-even), row-major, innermost dim last.
+ *  - return value: MGX_OK (0) or a negative mgx_status; mgx_last_error() gives a message.
+ *  - dh (head dim) is fixed at 64 and heads = d/64, as in the reference (layers.py:219).
+ */
+#ifndef MGX_H
+#define MGX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MGX_OK = 0,
+    MGX_ERR_SHAPE = -1,    /* unsupported shape (message says which constraint) */
+    MGX_ERR_NULL = -2,     /* required pointer is NULL */
+    MGX_ERR_LAUNCH = -3,   /* hipGetLastError() != hipSuccess after launch */
+    MGX_ERR_NO_DEVICE = -4 /* no HIP device visible */
+} mgx_status;
+
+/* thread-local, NUL-terminated description of the last failure on this thread */
+const char* mgx_last_error(void);
+/* library/ABI version (bumped on any signature change) */
+int mgx_abi_version(void);
+/* number of visible HIP devices, or a negative mgx_status */
+int mgx_device_count(void);
+
+/* ---- K1: token embedding * sqrt(d) + sinusoid PE (+dropout)      layers.py:226-229, 22-39 ----
+ * tok int32 [rows] (rows = B*L), table f32 [V,d], pe f32 [L,d] (precomputed once, device resident),
+ * out bf16 [rows,d].  dropout: keep-prob 1-p, inverted scaling; mask is a pure function of
+ * (seed, element index) so the backward regenerates it.  p == 0 disables it.                  */
+int mgx_embed_pe_fwd(const int32_t* tok, const float* table, const float* pe, uint16_t* out,
+                     int B, int L, int d, int V, float p_drop, uint64_t seed, void* stream);
+/* dtable f32 [V,d] += scatter-add of dout bf16 [rows,d] (deterministic: one block per vocab row) */
+int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dtable,
+                  int B, int L, int d, int V, float p_drop, uint64_t seed, void* stream);
+
+/* ---- A3: key-padding bitmap from tokens                          utils.py:58-83 --------------
+ * bits uint32 [B, L/32]: bit (j&31) of word j>>5 set iff tok[b,j] == pad.  L % 32 == 0.         */
+int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, int B, int L, int pad, void* stream);
+
+/* ---- K3+K4: fused relative global attention (Shaw/Huang skewing)  layers.py:86-106,111-133 ---
+ * qkv bf16 [B,L,3d]: columns [0,d)=Q, [d,2d)=K, [2d,3d)=V, head hd at columns hd*64..hd*64+63
+ *     (exactly the output of one fused [d -> 3d] projection; no permute is needed).
+ * E   bf16 [M,64] relative embedding of this layer (shared by heads and batch), M >= L.
+ * padbits uint32 [B,L/32] from mgx_pad_bitmap, or NULL for "no key padding".
+ * ctx bf16 [B,L,d] (heads merged: the input of the `fc` projection), lse f32 [B,h,L].
+ *   logit[i,j] = (q_i.k_j + q_i.E[M-1-(i-j)])/8 ; j>i masked ; padded keys get -1e9 ;
+ *   ctx_i = softmax_j(logit) v_j.  The L x L matrix is never materialised.
+ * Constraints: d % 64 == 0, L % 32 == 0, M >= L.
+ * Rows whose every key j<=i is padding (leading pads; never produced by the reference's data
+ * path, data.py:96-107) attend uniformly over j<=i (the reference's result there is a rounding
+ * artefact of -1e9+x in fp32 and is outside the parity contract).                             */
+int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
+                     uint16_t* ctx, float* lse, int B, int L, int d, int M, void* stream);
+/* backward of the above (autograd of layers.py:86-106).  dctx bf16 [B,L,d] -> dqkv bf16 [B,L,3d];
+ * dE f32 [M,64] is ACCUMULATED into (caller zeroes it once per optimiser step).
+ * delta f32 [B,h,L] is caller-provided scratch (rowsum(dctx*ctx)).                             */
+int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
+                     const uint16_t* ctx, const uint16_t* dctx, const float* lse,
+                     uint16_t* dqkv, float* dE, float* delta,
+                     int B, int L, int d, int M, void* stream);
+
+/* ---- K6: out = LayerNorm(dropout(x) + res) * gamma + beta, eps    layers.py:154-155,159-160 --
+ * x,res,out bf16 [rows,d]; gamma,beta f32 [d]; mean,rstd f32 [rows] saved for the backward.    */
+int mgx_add_ln_fwd(const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta,
+                   uint16_t* out, float* mean, float* rstd, int rows, int d, float eps,
+                   float p_drop, uint64_t seed, void* stream);
+/* dout bf16 [rows,d] -> dx (grad of x, dropout applied), dres (grad of res) bf16 [rows,d];
+ * dgamma,dbeta f32 [d] are ACCUMULATED into.  dx may alias dres when p_drop == 0.              */
+int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,
+                   const float* mean, const float* rstd, uint16_t* dx, uint16_t* dres,
+                   float* dgamma, float* dbeta, int rows, int d, float p_drop, uint64_t seed,
+                   void* stream);
+
+/* ---- K9+K10: label-smoothed cross entropy + accuracy              criterion.py:43-67, metrics.py:22-60
+ * logits bf16 [rows,ld] (row stride ld >= V elements; columns >= V are ignored), target int32 [rows].
+ * stats f32 [4] is ACCUMULATED into: [0]=sum of per-row loss over target!=pad, [1]=#target!=pad,
+ *   [2]=#(argmax==target) over ALL rows, [3]=rows.   argmax int32 [rows] (LogitsBucketting).
+ * row_lse f32 [rows] is saved for the backward.                                               */
+int mgx_smooth_ce_fwd(const uint16_t* logits, const int32_t* target, float* stats, int32_t* argmax,
+                      float* row_lse, int rows, int V, int ld, float eps_ls, int pad, void* stream);
+/* dlogits bf16 [rows,ld] (columns >= V written as 0) = gscale/stats[1] * (softmax - q') for target!=pad rows, else 0.
+ * stats is read on the device (no host sync); gscale is the upstream gradient (1/accum).       */
+int mgx_smooth_ce_bwd(const uint16_t* logits, const int32_t* target, const float* stats,
+                      const float* row_lse, uint16_t* dlogits, int rows, int V, int ld,
+                      float eps_ls, int pad, float gscale, void* stream);
+
+/* ---- K11: Adam over one flat fp32 parameter buffer                train.py:143, criterion.py:81-87
+ * p,g,m,v f32 [n]; shadow bf16 [n] (the bf16 copy the GEMMs/attention read) written in the same
+ * pass.  step >= 1 (bias correction as torch.optim.Adam), gscale multiplies g (e.g. 1/world).   */
+int mgx_adam_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t n,
+                  float lr, float beta1, float beta2, float eps, int step, float gscale, void* stream);
+/* shadow bf16 [n] = round(p f32 [n]) */
+int mgx_cast_bf16(const float* p, uint16_t* shadow, size_t n, void* stream);
+
+/* ---- K2/K5/K7/K8: C = act(A @ W^T + bias)                         layers.py:71-84,108,157-158; network.py:39
+ * A bf16 [M,K] row-major, W bf16 [N,K] row-major (torch.nn.Linear layout), bias f32 [N] or NULL,
+ * C bf16 [M,N].  act: 0 none, 1 ReLU.  K % 64 == 0; M, N arbitrary (edge tiles are masked).   */
+int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C,
+                   int M, int N, int K, int act, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libmgx.so (include/mgx.h).  No fallback: if the library is missing or a call
+fails, the product path raises -- there is no CPU/eager substitute (the oracle lives in oracle/ and
+is never imported from here)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libmgx.so")
+
+_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
+SIGNATURES = {
+    "mgx_abi_version": [],
+    "mgx_device_count": [],
+    "mgx_embed_pe_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
+    "mgx_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
+    "mgx_pad_bitmap": [_vp, _vp, _i, _i, _i, _vp],
+    "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_add_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _vp],
+    "mgx_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _vp],
+    "mgx_smooth_ce_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "mgx_smooth_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp],
+    "mgx_adam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp],
+    "mgx_cast_bf16": [_vp, _vp, _sz, _vp],
+    "mgx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+}
+
+_lib = None
+
+
+class MgxError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libmgx.so (building it first if hipcc is available and the .so is absent/stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH) or os.environ.get("MGX_REBUILD") == "1":
+        from . import _build
+        _build.build()
+    if not os.path.exists(LIB_PATH):
+        raise MgxError(f"{LIB_PATH} is missing: run `python -m musicgeneration_amd._build` (needs hipcc)")
+    lib = C.CDLL(LIB_PATH)
+    lib.mgx_last_error.restype = C.c_char_p
+    lib.mgx_last_error.argtypes = []
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = C.c_int
+        fn.argtypes = argt
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mgx_last_error().decode("utf-8", "replace")
+        raise MgxError(f"{what} failed (status {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """device pointer of a torch tensor (or None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

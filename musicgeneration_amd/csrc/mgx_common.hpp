@@ -1,0 +1,100 @@
+// Shared device/host helpers for libmgx (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "mgx.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define MGX_DEV __device__ __forceinline__
+
+MGX_DEV float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+MGX_DEV float bf16lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+MGX_DEV float bf16hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// two f32 -> packed bf16x2 (lo in bits 0..15), RNE, NaN-preserving: compiles to v_cvt_pk_bf16_f32
+MGX_DEV uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+MGX_DEV uint16_t f32_to_bf16(float x) { return (uint16_t)(pack_bf16x2(x, 0.f) & 0xffffu); }
+
+MGX_DEV void unpack8(const u32x4& w, float* f) {
+    f[0] = bf16lo(w.x); f[1] = bf16hi(w.x); f[2] = bf16lo(w.y); f[3] = bf16hi(w.y);
+    f[4] = bf16lo(w.z); f[5] = bf16hi(w.z); f[6] = bf16lo(w.w); f[7] = bf16hi(w.w);
+}
+MGX_DEV u32x4 pack8(const float* f) {
+    u32x4 w;
+    w.x = pack_bf16x2(f[0], f[1]); w.y = pack_bf16x2(f[2], f[3]);
+    w.z = pack_bf16x2(f[4], f[5]); w.w = pack_bf16x2(f[6], f[7]);
+    return w;
+}
+
+// ---- stateless dropout RNG: keep decision is a pure function of (seed, element index) ---------
+MGX_DEV uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+struct DropCfg {
+    uint32_t thr16;   // drop iff 16-bit random < thr16
+    uint32_t mix;     // seed mix
+    float scale;      // 1/(1-p_actual)
+};
+static inline DropCfg make_drop(float p, uint64_t seed) {
+    DropCfg c;
+    if (p <= 0.f) { c.thr16 = 0; c.scale = 1.f; c.mix = 0; return c; }
+    double t = (double)p * 65536.0;
+    uint32_t thr = (uint32_t)(t + 0.5);
+    if (thr > 65535u) thr = 65535u;
+    c.thr16 = thr;
+    c.scale = (float)(1.0 / (1.0 - (double)thr / 65536.0));
+    uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    c.mix = lo * 0x9e3779b9u + (hi ^ 0x85ebca6bu) * 0xc2b2ae35u + 0x27d4eb2fu;
+    return c;
+}
+// multipliers (0 or scale) for the 8 consecutive elements of group g (g = element_index / 8)
+MGX_DEV void drop_mult8(const DropCfg& c, uint32_t g, float* mult) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t r = hash32((g * 4u + (uint32_t)k) ^ c.mix);
+        mult[2 * k] = ((r & 0xffffu) < c.thr16) ? 0.f : c.scale;
+        mult[2 * k + 1] = ((r >> 16) < c.thr16) ? 0.f : c.scale;
+    }
+}
+
+MGX_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MGX_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- host-side error plumbing -----------------------------------------------------------------
+void mgx_set_error(const char* fmt, ...);
+#define MGX_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            mgx_set_error(__VA_ARGS__);         \
+            return (code);                      \
+        }                                       \
+    } while (0)
+#define MGX_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            mgx_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return MGX_ERR_LAUNCH;                                                    \
+        }                                                                             \
+    } while (0)

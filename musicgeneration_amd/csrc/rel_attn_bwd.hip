@@ -1,0 +1,655 @@
+// Fused relative global attention, backward (autograd of layers.py:86-106 of the reference).
+//
+// With qs = q/8 (exact pre-scale), delta = i-j, Er[delta] = E[M-1-delta]:
+//     S[i,j]  = qs_i.k_j + qs_i.Er[i-j]            P = exp(S - lse_i)   (0 where masked)
+//     dP[i,j] = dO_i.v_j                           dS = P o (dP - rowsum(dO o O)_i)
+//     dqs_i   = sum_j dS[i,j] (k_j + Er[i-j])      dq = dqs/8
+//     dk_j    = sum_i dS[i,j] qs_i                 dv_j = sum_i P[i,j] dO_i
+//     dEr[dl] = sum_{b,h} sum_i dS[i,i-dl] qs_i
+//
+// Every output has a different "owner" axis (query row / key row / relative distance).  Summing a
+// non-owned output across workgroups with float atomics would cost >= 150 MB of atomic traffic per
+// layer at cfg2 (~1.3 TB/s chip-wide => > 100 us, more than the MFMA time), so each output gets its
+// own kernel that keeps it in registers for the whole sweep and recomputes P (flash style):
+//   K1 dq_kernel  : workgroup = 128 query rows, sweeps key tiles    (20 MFMA / 32x32 tile)
+//   K2 dkv_kernel : workgroup = 128 keys,       sweeps query tiles  (24 MFMA / tile)
+//   K3 de_kernel  : workgroup = 4 chunks of 32 relative distances, sweeps query tiles along its
+//                   diagonal band (24 MFMA / tile); one float-atomic flush of 32 KB per workgroup.
+// The skew / un-skew between (i,j) tiles and (i,delta) chunks is done through per-wave LDS band
+// buffers (see rel_attn_common.hpp); no L x L tensor ever exists.
+#include "rel_attn_common.hpp"
+
+using namespace relattn;
+
+namespace {
+constexpr int WAVES = 4;
+constexpr int E_SLOTS = 6;
+}  // namespace
+
+// ================================================================================================
+// delta[b,h,i] = sum_c dctx[b,i,h*64+c] * ctx[b,i,h*64+c]         (8 lanes per (row, head))
+// ================================================================================================
+__global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ ctx,
+                                                         const uint16_t* __restrict__ dctx,
+                                                         float* __restrict__ delta, int B, int L, int d) {
+    const int heads = d >> 6;
+    const long total = (long)B * L * heads * 8;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;   // total is a multiple of 8 and blockDim of 64: whole 8-lane groups exit together
+    const int sub = (int)(gid & 7);
+    const long rh = gid >> 3;                     // (row, head)
+    const int hd = (int)(rh % heads);
+    const long row = rh / heads;                  // b*L + i
+    const size_t off = (size_t)row * d + hd * 64 + sub * 8;
+    float a[8], g[8];
+    unpack8(*(const u32x4*)(ctx + off), a);
+    unpack8(*(const u32x4*)(dctx + off), g);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += a[k] * g[k];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (sub == 0) {
+        const int bb = (int)(row / L), i = (int)(row % L);
+        delta[((size_t)bb * heads + hd) * L + i] = s;
+    }
+}
+
+// natural-k transposed fragment: X[16*ks + 8*hh + j][32*ct + (lane&31)], j = 0..7, from an image-T tile
+MGX_DEV bf16x8 frag_Tn(const char* tile, int lane, int ks, int ct) {
+    const int i = lane & 15, g = lane >> 4, hh = lane >> 5;
+    const int rq = i >> 2;
+    const int chunk = 4 * ct + 2 * (g & 1) + ((i & 3) >> 1);
+    const int byte_in = 8 * (i & 1);
+    bf16x8 out;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int row = 16 * ks + 8 * hh + 4 * jq + rq;
+        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + imgT_off(row, chunk) + byte_in));
+        out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
+    }
+    return out;
+}
+
+MGX_DEV u32x4 scale8(const u32x4& raw, float sc) {
+    float f[8];
+    unpack8(raw, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] *= sc;
+    return pack8(f);
+}
+
+// store a transposed accumulator pair  T^T[c][x] (c = 32*ct + crow(r,hh) on registers, x on lanes)
+// as 64 consecutive bf16 of row x:  dst_row[c] = val * sc
+MGX_DEV void store_rowsT(uint16_t* dst_row, const f32x16& t0, const f32x16& t1, int hh, float sc) {
+    uint16_t* op = dst_row + 4 * hh;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        u32x2 w0 = {pack_bf16x2(t0[4 * g4] * sc, t0[4 * g4 + 1] * sc), pack_bf16x2(t0[4 * g4 + 2] * sc, t0[4 * g4 + 3] * sc)};
+        u32x2 w1 = {pack_bf16x2(t1[4 * g4] * sc, t1[4 * g4 + 1] * sc), pack_bf16x2(t1[4 * g4 + 2] * sc, t1[4 * g4 + 3] * sc)};
+        *(u32x2*)(op + 8 * g4) = w0;
+        *(u32x2*)(op + 32 + 8 * g4) = w1;
+    }
+}
+
+// ================================================================================================
+// K1: dQ.  Same sweep as the forward (query-block owner, key tiles 0..diagonal).
+//   orientation: keys on registers, queries on lanes (S^T, P^T, dP^T, dS^T), dqs^T[c][a] accumulators.
+// ================================================================================================
+namespace k1 {
+constexpr int OFF_KR = 0;                                  // 2 x 4K  K image R (row frags for S^T)
+constexpr int OFF_KT = OFF_KR + 2 * TILE_BYTES;            // 2 x 4K  K image T (K^T frags for dq)
+constexpr int OFF_VR = OFF_KT + 2 * TILE_BYTES;            // 2 x 4K  V image R (row frags for dP^T)
+constexpr int OFF_ER = OFF_VR + 2 * TILE_BYTES;            // 6 x 4K  Er chunk image R (QE)
+constexpr int OFF_ET = OFF_ER + E_SLOTS * TILE_BYTES;      // 6 x 4K  Er chunk image T (dq_rel)
+constexpr int OFF_BAND = OFF_ET + E_SLOTS * TILE_BYTES;    // 4 x 8K  fp32 [32][64] forward band
+constexpr int DB_STRIDE = 144;                             // bytes per dband row (64 bf16 + pad)
+constexpr int OFF_DBAND = OFF_BAND + WAVES * 8192;         // 4 x 4608 bf16 [32][72]
+constexpr int LDS_BYTES = OFF_DBAND + WAVES * 32 * DB_STRIDE;   // 123,392 B -> 1 workgroup per CU
+}  // namespace k1
+
+__global__ __launch_bounds__(256, 1) void rel_attn_dq_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint32_t* __restrict__ padbits,
+    const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
+    uint16_t* __restrict__ dqkv, int L, int d) {
+    using namespace k1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 31, hh = lane >> 5;
+    const int heads = d >> 6;
+    const int b = blockIdx.y / heads, hd = blockIdx.y % heads;
+    const int qb = gridDim.x - 1 - blockIdx.x;
+    const int I0 = qb * 128, Q0 = I0 >> 5, i0 = I0 + w * 32;
+    const int nchunk = L >> 5;
+    const bool wave_on = i0 < L;
+    const int nsteps = min(Q0 + 4, nchunk);
+    const size_t ld = (size_t)3 * d;
+    const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
+
+    const int srow = tid >> 3, sch = tid & 7;
+    const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
+    const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;
+    const uint16_t* vg = kg + d;
+    auto e_src = [&](int q) { return Er + (size_t)(L - 1 - 32 * q - srow) * 64 + sch * 8; };
+
+    {   // prologue staging
+        const u32x4 kk = *(const u32x4*)kg;
+        *(u32x4*)(smem + OFF_KR + st_offR) = kk;
+        *(u32x4*)(smem + OFF_KT + st_offT) = kk;
+        *(u32x4*)(smem + OFF_VR + st_offR) = *(const u32x4*)vg;
+#pragma unroll
+        for (int k = -1; k < 4; ++k) {
+            const int q = Q0 + k;
+            if (q >= 0 && q < nchunk) {
+                const u32x4 ee = *(const u32x4*)e_src(q);
+                *(u32x4*)(smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES + st_offR) = ee;
+                *(u32x4*)(smem + OFF_ET + (q % E_SLOTS) * TILE_BYTES + st_offT) = ee;
+            }
+        }
+        // zero the dS band (its never-written half must read as 0 on the first step)
+        for (int o = tid * 16; o < WAVES * 32 * DB_STRIDE; o += 256 * 16) *(u32x4*)(smem + OFF_DBAND + o) = u32x4{0, 0, 0, 0};
+    }
+    bf16x8 qf[4], dof[4];
+    float lse2 = 0.f, dlt = 0.f;
+    if (wave_on) {
+        const uint16_t* qp = qkv_b + (size_t)(i0 + a) * ld + hd * 64 + hh * 8;
+        const uint16_t* dp = dctx + ((size_t)b * L + i0 + a) * d + hd * 64 + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = __builtin_bit_cast(bf16x8, scale8(*(const u32x4*)(qp + ks * 16), 0.125f));
+            dof[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(dp + ks * 16));
+        }
+        const size_t si = ((size_t)b * heads + hd) * L + i0 + a;
+        lse2 = lse[si] * LOG2E;
+        dlt = delta[si];
+    }
+    __syncthreads();
+
+    char* band = smem + OFF_BAND + w * 8192;
+    char* dband = smem + OFF_DBAND + w * (32 * DB_STRIDE);
+    if (wave_on) {
+        const int q = Q0 + w;
+        const char* et = smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES;
+        f32x16 qe = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
+        const int cb = (q & 1) * 32 + a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+    }
+    f32x16 dq0 = zero16(), dq1 = zero16();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int cur = s & 1;
+        u32x4 kreg, vreg, ereg;
+        const bool have_next = (s + 1 < nsteps);
+        const int qnext = Q0 - s - 2;
+        const bool have_e = have_next && qnext >= 0;
+        if (have_next) {
+            kreg = *(const u32x4*)(kg + (size_t)(s + 1) * 32 * ld);
+            vreg = *(const u32x4*)(vg + (size_t)(s + 1) * 32 * ld);
+        }
+        if (have_e) ereg = *(const u32x4*)e_src(qnext);
+
+        const int dq = Q0 + w - s;
+        if (wave_on && dq >= 0) {
+            const int D = dq * 32;
+            if (dq >= 1) {
+                const int q = dq - 1;
+                const char* et = smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES;
+                f32x16 qe = zero16();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
+                const int cb = (q & 1) * 32 + a;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+            }
+            wave_lds_fence();
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = *(const float*)(band + (a * 64 + ((D + a - crow(r, hh)) & 63)) * 4);
+            const char* kt = smem + OFF_KR + cur * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
+            if (dq == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (crow(r, hh) > a) ? -INFINITY : c[r];
+            }
+            if (padbits) {
+                const uint32_t pw = padbits[(size_t)b * nchunk + s];
+                if (pw) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = ((pw >> crow(r, hh)) & 1u) ? -INFINITY : c[r];
+                }
+            }
+            // P^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(c[r], LOG2E, -lse2));
+            // dP^T = V dO^T
+            f32x16 dp = zero16();
+            const char* vt = smem + OFF_VR + cur * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(vt, a, hh, ks), dof[ks], dp);
+            // dS^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c[r] = c[r] * (dp[r] - dlt);
+            // dqs^T += K^T dS^T
+            const char* ktt = smem + OFF_KT + cur * TILE_BYTES;
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 df = acc_to_frag(c, ss);
+                dq0 = mfma(frag_T(ktt, lane, ss, 0), df, dq0);
+                dq1 = mfma(frag_T(ktt, lane, ss, 1), df, dq1);
+            }
+            // un-skew dS into the (query, delta) band, then the completed chunk dq feeds dq_rel
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *(uint16_t*)(dband + a * DB_STRIDE + ((D + a - crow(r, hh)) & 63) * 2) = f32_to_bf16(c[r]);
+            wave_lds_fence();
+            const char* ett = smem + OFF_ET + (dq % E_SLOTS) * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2);
+                dq0 = mfma(frag_Tn(ett, lane, ks, 0), gq, dq0);
+                dq1 = mfma(frag_Tn(ett, lane, ks, 1), gq, dq1);
+            }
+        }
+        if (have_next) {
+            *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
+            *(u32x4*)(smem + OFF_KT + (cur ^ 1) * TILE_BYTES + st_offT) = kreg;
+            *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
+        }
+        if (have_e) {
+            *(u32x4*)(smem + OFF_ER + (qnext % E_SLOTS) * TILE_BYTES + st_offR) = ereg;
+            *(u32x4*)(smem + OFF_ET + (qnext % E_SLOTS) * TILE_BYTES + st_offT) = ereg;
+        }
+        __syncthreads();
+    }
+    if (wave_on) store_rowsT(dqkv + ((size_t)b * L + i0 + a) * ld + hd * 64, dq0, dq1, hh, 0.125f);
+}
+
+// ================================================================================================
+// K2: dK, dV.  workgroup = 128 keys (wave = 32 keys, K/V row fragments in registers), sweeps query
+// tiles i0 = J0, J0+32, ...  orientation: queries on registers, keys on lanes (S, P, dP, dS);
+// accumulators dK^T[c][b], dV^T[c][b].
+// ================================================================================================
+namespace k2 {
+constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
+constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
+constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K  dO image R
+constexpr int OFF_OT = OFF_OR + 2 * TILE_BYTES;            // 2 x 4K  dO image T
+constexpr int OFF_ER = OFF_OT + 2 * TILE_BYTES;            // 6 x 4K  Er chunk image R
+constexpr int OFF_ST = OFF_ER + E_SLOTS * TILE_BYTES;      // 2 x 256 B: lse2[32], delta[32]
+constexpr int OFF_BAND = OFF_ST + 2 * 256;                 // 4 x 8K fp32 [32][64]
+constexpr int LDS_BYTES = OFF_BAND + WAVES * 8192;         // 90,624 B
+}  // namespace k2
+
+__global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint32_t* __restrict__ padbits,
+    const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
+    uint16_t* __restrict__ dqkv, int L, int d) {
+    using namespace k2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bl = lane & 31, hh = lane >> 5;
+    const int heads = d >> 6;
+    const int b = blockIdx.y / heads, hd = blockIdx.y % heads;
+    const int J0 = blockIdx.x * 128;                       // small J0 = longest sweep = launched first
+    const int j0 = J0 + w * 32;
+    const int nchunk = L >> 5;
+    const bool wave_on = j0 < L;
+    const int nT = (L - J0) >> 5;
+    const size_t ld = (size_t)3 * d;
+    const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
+    const size_t stat_base = ((size_t)b * heads + hd) * L;
+
+    const int srow = tid >> 3, sch = tid & 7;
+    const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
+    const uint16_t* qg = qkv_b + (size_t)(J0 + srow) * ld + hd * 64 + sch * 8;                  // + t*32*ld
+    const uint16_t* og = dctx + ((size_t)b * L + J0 + srow) * d + hd * 64 + sch * 8;            // + t*32*d
+    auto e_src = [&](int q) { return Er + (size_t)(L - 1 - 32 * q - srow) * 64 + sch * 8; };
+    auto stat_src = [&](int t) {   // tid < 64: lse (0..31) / delta (32..63) of query tile t
+        const int i = J0 + 32 * t + (tid & 31);
+        return (tid < 32) ? lse[stat_base + i] * LOG2E : delta[stat_base + i];
+    };
+
+    {
+        const u32x4 qq = scale8(*(const u32x4*)qg, 0.125f);
+        const u32x4 oo = *(const u32x4*)og;
+        *(u32x4*)(smem + OFF_QR + st_offR) = qq;
+        *(u32x4*)(smem + OFF_QT + st_offT) = qq;
+        *(u32x4*)(smem + OFF_OR + st_offR) = oo;
+        *(u32x4*)(smem + OFF_OT + st_offT) = oo;
+        *(u32x4*)(smem + OFF_ER + st_offR) = *(const u32x4*)e_src(0);      // chunk 0 -> slot 0
+        if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0);
+    }
+    bf16x8 kf[4], vf[4];
+    uint32_t padlane = 0;
+    if (wave_on) {
+        const uint16_t* kp = qkv_b + (size_t)(j0 + bl) * ld + d + hd * 64 + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + ks * 16));
+            vf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + d + ks * 16));
+        }
+        if (padbits) padlane = (padbits[(size_t)b * nchunk + (j0 >> 5)] >> bl) & 1u;
+    }
+    __syncthreads();
+    char* band = smem + OFF_BAND + w * 8192;
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+
+    for (int t = 0; t < nT; ++t) {
+        const int cur = t & 1;
+        u32x4 qreg, oreg, ereg;
+        float streg = 0.f;
+        const bool have_next = (t + 1 < nT);
+        if (have_next) {
+            qreg = *(const u32x4*)(qg + (size_t)(t + 1) * 32 * ld);
+            oreg = *(const u32x4*)(og + (size_t)(t + 1) * 32 * d);
+            ereg = *(const u32x4*)e_src(t + 1);            // chunk t+1 <= nT-1 < nchunk
+            if (tid < 64) streg = stat_src(t + 1);
+        }
+        const int dq = t - w;
+        if (wave_on && dq >= 0) {
+            const int D = dq * 32;
+            const char* qr = smem + OFF_QR + cur * TILE_BYTES;
+            bf16x8 qa[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_R(qr, bl, hh, ks);
+            // QE for chunks dq (and dq-1): rows = query a, cols = t
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const int q = dq - which;
+                if (q >= 0) {
+                    const char* et = smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES;
+                    f32x16 qe = zero16();
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], frag_R(et, bl, hh, ks), qe);
+                    const int cb = (q & 1) * 32 + bl;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+                }
+            }
+            wave_lds_fence();
+            f32x16 c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ar = crow(r, hh);
+                c[r] = *(const float*)(band + (ar * 64 + ((D + ar - bl) & 63)) * 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) c = mfma(qa[ks], kf[ks], c);
+            if (dq == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (bl > crow(r, hh)) ? -INFINITY : c[r];
+            }
+            if (padlane) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = -INFINITY;
+            }
+            const char* st = smem + OFF_ST + cur * 256;
+            f32x16 dp = zero16();
+            const char* orr = smem + OFF_OR + cur * TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(orr, bl, hh, ks), vf[ks], dp);
+            f32x16 ds;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
+                const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], LOG2E, -l4[k]));
+                    c[4 * g4 + k] = p;
+                    ds[4 * g4 + k] = p * (dp[4 * g4 + k] - d4[k]);
+                }
+            }
+            const char* ot = smem + OFF_OT + cur * TILE_BYTES;
+            const char* qt = smem + OFF_QT + cur * TILE_BYTES;
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 pf = acc_to_frag(c, ss);
+                const bf16x8 df = acc_to_frag(ds, ss);
+                dv0 = mfma(frag_T(ot, lane, ss, 0), pf, dv0);
+                dv1 = mfma(frag_T(ot, lane, ss, 1), pf, dv1);
+                dk0 = mfma(frag_T(qt, lane, ss, 0), df, dk0);
+                dk1 = mfma(frag_T(qt, lane, ss, 1), df, dk1);
+            }
+        }
+        if (have_next) {
+            const u32x4 qq = scale8(qreg, 0.125f);
+            *(u32x4*)(smem + OFF_QR + (cur ^ 1) * TILE_BYTES + st_offR) = qq;
+            *(u32x4*)(smem + OFF_QT + (cur ^ 1) * TILE_BYTES + st_offT) = qq;
+            *(u32x4*)(smem + OFF_OR + (cur ^ 1) * TILE_BYTES + st_offR) = oreg;
+            *(u32x4*)(smem + OFF_OT + (cur ^ 1) * TILE_BYTES + st_offT) = oreg;
+            *(u32x4*)(smem + OFF_ER + ((t + 1) % E_SLOTS) * TILE_BYTES + st_offR) = ereg;
+            if (tid < 64) *(float*)(smem + OFF_ST + (cur ^ 1) * 256 + tid * 4) = streg;
+        }
+        __syncthreads();
+    }
+    if (wave_on) {
+        uint16_t* row = dqkv + ((size_t)b * L + j0 + bl) * ld + hd * 64;
+        store_rowsT(row + d, dk0, dk1, hh, 1.f);
+        store_rowsT(row + 2 * d, dv0, dv1, hh, 1.f);
+    }
+}
+
+// ================================================================================================
+// K3: dE.  workgroup = 4 consecutive chunks of 32 relative distances (wave = chunk c, Er chunk
+// fragments + dEr[32][64] accumulators in registers).  For query tile i0 the band of chunk c
+// covers the lower triangle (b<=a) of key tile u = i0/32 - c and the upper triangle (b>a) of key
+// tile u-1: both tiles are computed and merged element-wise before exp/dS.
+// ================================================================================================
+namespace k3 {
+constexpr int KV_SLOTS = 6;
+constexpr int OFF_KR = 0;                                  // 6 x 4K K image R ring (slot = tile % 6)
+constexpr int OFF_VR = OFF_KR + KV_SLOTS * TILE_BYTES;     // 6 x 4K V image R ring
+constexpr int OFF_QR = OFF_VR + KV_SLOTS * TILE_BYTES;     // 2 x 4K qs image R
+constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K qs image T
+constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K dO image R
+constexpr int OFF_ST = OFF_OR + 2 * TILE_BYTES;            // 2 x 256 B
+constexpr int OFF_BAND = OFF_ST + 2 * 256;                 // 4 x 4K fp32 [32][32] (QE, then dS)
+constexpr int LDS_BYTES = OFF_BAND + WAVES * 4096;         // 90,624 B
+}  // namespace k3
+
+__global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint32_t* __restrict__ padbits,
+    const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
+    float* __restrict__ dEr /* = dE + (M-L)*64 */, int L, int d) {
+    using namespace k3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bl = lane & 31, hh = lane >> 5;
+    const int heads = d >> 6;
+    const int b = blockIdx.y / heads, hd = blockIdx.y % heads;
+    const int nchunk = L >> 5;
+    const int C0 = blockIdx.x * 4;                         // small C0 = longest sweep = launched first
+    const int cw = C0 + w;
+    const bool wave_on = cw < nchunk;
+    const int nT = nchunk - C0;
+    const size_t ld = (size_t)3 * d;
+    const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
+    const size_t stat_base = ((size_t)b * heads + hd) * L;
+    const uint32_t* pb = padbits ? padbits + (size_t)b * nchunk : nullptr;
+
+    const int srow = tid >> 3, sch = tid & 7;
+    const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
+    const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;                      // + u*32*ld
+    const uint16_t* qg = qkv_b + (size_t)(32 * C0 + srow) * ld + hd * 64 + sch * 8;              // + t*32*ld
+    const uint16_t* og = dctx + ((size_t)b * L + 32 * C0 + srow) * d + hd * 64 + sch * 8;        // + t*32*d
+    auto stat_src = [&](int t) {
+        const int i = 32 * (C0 + t) + (tid & 31);
+        return (tid < 32) ? lse[stat_base + i] * LOG2E : delta[stat_base + i];
+    };
+    {
+        *(u32x4*)(smem + OFF_KR + st_offR) = *(const u32x4*)kg;             // key tile 0 -> slot 0
+        *(u32x4*)(smem + OFF_VR + st_offR) = *(const u32x4*)(kg + d);
+        const u32x4 qq = scale8(*(const u32x4*)qg, 0.125f);
+        *(u32x4*)(smem + OFF_QR + st_offR) = qq;
+        *(u32x4*)(smem + OFF_QT + st_offT) = qq;
+        *(u32x4*)(smem + OFF_OR + st_offR) = *(const u32x4*)og;
+        if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0);
+    }
+    bf16x8 ef[4];
+    if (wave_on) {
+        const uint16_t* ep = Er + (size_t)(L - 1 - 32 * cw - bl) * 64 + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ef[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(ep + ks * 16));
+    }
+    __syncthreads();
+    char* band = smem + OFF_BAND + w * 4096;
+    f32x16 de0 = zero16(), de1 = zero16();
+
+    for (int t = 0; t < nT; ++t) {
+        const int cur = t & 1;
+        u32x4 kreg, vreg, qreg, oreg;
+        float streg = 0.f;
+        const bool have_next = (t + 1 < nT);
+        if (have_next) {
+            kreg = *(const u32x4*)(kg + (size_t)(t + 1) * 32 * ld);      // key tile t+1 <= nT-1 < nchunk
+            vreg = *(const u32x4*)(kg + d + (size_t)(t + 1) * 32 * ld);
+            qreg = *(const u32x4*)(qg + (size_t)(t + 1) * 32 * ld);
+            oreg = *(const u32x4*)(og + (size_t)(t + 1) * 32 * d);
+            if (tid < 64) streg = stat_src(t + 1);
+        }
+        const int u = t - w;                              // lower key tile; upper = u-1
+        if (wave_on && u >= 0) {
+            const char* qr = smem + OFF_QR + cur * TILE_BYTES;
+            bf16x8 qa[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_R(qr, bl, hh, ks);
+            f32x16 qe = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], ef[ks], qe);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 32 + bl) * 4) = qe[r];
+            wave_lds_fence();
+            f32x16 srel;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ar = crow(r, hh);
+                srel[r] = *(const float*)(band + (ar * 32 + ((ar - bl) & 31)) * 4);
+            }
+            const bool has_up = (u >= 1);
+            const char* klo = smem + OFF_KR + (u % KV_SLOTS) * TILE_BYTES;
+            const char* vlo = smem + OFF_VR + (u % KV_SLOTS) * TILE_BYTES;
+            const char* kup = smem + OFF_KR + ((u + KV_SLOTS - 1) % KV_SLOTS) * TILE_BYTES;
+            const char* vup = smem + OFF_VR + ((u + KV_SLOTS - 1) % KV_SLOTS) * TILE_BYTES;
+            f32x16 slo = srel, sup = srel;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) slo = mfma(qa[ks], frag_R(klo, bl, hh, ks), slo);
+            if (has_up) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) sup = mfma(qa[ks], frag_R(kup, bl, hh, ks), sup);
+            }
+            bool plo = false, pup = !has_up;              // "masked" flags of this lane's key in each tile
+            if (pb) {
+                plo = (pb[u] >> bl) & 1u;
+                if (has_up) pup = (pb[u - 1] >> bl) & 1u;
+            }
+            const char* orr = smem + OFF_OR + cur * TILE_BYTES;
+            bf16x8 oa[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) oa[ks] = frag_R(orr, bl, hh, ks);
+            f32x16 dlo = zero16(), dup = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dlo = mfma(oa[ks], frag_R(vlo, bl, hh, ks), dlo);
+            if (has_up) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dup = mfma(oa[ks], frag_R(vup, bl, hh, ks), dup);
+            }
+            const char* st = smem + OFF_ST + cur * 256;
+            f32x16 ds;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
+                const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * g4 + k;
+                    const bool lower = (bl <= crow(r, hh));
+                    const bool masked = lower ? plo : pup;
+                    const float sv = lower ? slo[r] : sup[r];
+                    const float dv = lower ? dlo[r] : dup[r];
+                    const float p = masked ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sv, LOG2E, -l4[k]));
+                    ds[r] = p * (dv - d4[k]);
+                }
+            }
+            // un-skew: dQE[a][t] = dS[a][b] with t = (a-b)&31, through the same band buffer
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ar = crow(r, hh);
+                *(float*)(band + (ar * 32 + ((ar - bl) & 31)) * 4) = ds[r];
+            }
+            wave_lds_fence();
+            f32x16 x;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = *(const float*)(band + (crow(r, hh) * 32 + bl) * 4);
+            wave_lds_fence();
+            const char* qt = smem + OFF_QT + cur * TILE_BYTES;
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 xf = acc_to_frag(x, ss);
+                de0 = mfma(xf, frag_T(qt, lane, ss, 0), de0);
+                de1 = mfma(xf, frag_T(qt, lane, ss, 1), de1);
+            }
+        }
+        if (have_next) {
+            *(u32x4*)(smem + OFF_KR + ((t + 1) % KV_SLOTS) * TILE_BYTES + st_offR) = kreg;
+            *(u32x4*)(smem + OFF_VR + ((t + 1) % KV_SLOTS) * TILE_BYTES + st_offR) = vreg;
+            const u32x4 qq = scale8(qreg, 0.125f);
+            *(u32x4*)(smem + OFF_QR + (cur ^ 1) * TILE_BYTES + st_offR) = qq;
+            *(u32x4*)(smem + OFF_QT + (cur ^ 1) * TILE_BYTES + st_offT) = qq;
+            *(u32x4*)(smem + OFF_OR + (cur ^ 1) * TILE_BYTES + st_offR) = oreg;
+            if (tid < 64) *(float*)(smem + OFF_ST + (cur ^ 1) * 256 + tid * 4) = streg;
+        }
+        __syncthreads();
+    }
+    // flush: dEr[delta = 32*cw + t][cc] += de[t][cc]; Er row index = L-1-delta.  One register of the
+    // accumulator = two 128-byte row segments per wave instruction (full-rate atomic shape).
+    if (wave_on) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dl = 32 * cw + crow(r, hh);
+            float* row = dEr + (size_t)(L - 1 - dl) * 64;
+            atomicAdd(row + bl, de0[r]);
+            atomicAdd(row + 32 + bl, de1[r]);
+        }
+    }
+}
+
+extern "C" int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const uint16_t* ctx,
+                                const uint16_t* dctx, const float* lse, uint16_t* dqkv, float* dE, float* delta,
+                                int B, int L, int d, int M, void* stream) {
+    MGX_REQUIRE(qkv && E && ctx && dctx && lse && dqkv && dE && delta, MGX_ERR_NULL, "mgx_rel_attn_bwd: NULL pointer");
+    MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
+                "mgx_rel_attn_bwd: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
+    MGX_REQUIRE((long)B * (d / 64) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: B*heads must be <= 65535");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_de_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3::LDS_BYTES);
+        attr_set = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int heads = d / 64;
+    const uint16_t* Er = E + (size_t)(M - L) * 64;
+    {
+        const long total = (long)B * L * heads * 8;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
+    }
+    const dim3 gq((L + 127) / 128, B * heads);
+    hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
+    hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
+    const dim3 ge(((L >> 5) + 3) / 4, B * heads);
+    hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(256), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
+                       dE + (size_t)(M - L) * 64, L, d);
+    MGX_CHECK_LAUNCH("mgx_rel_attn_bwd");
+    return MGX_OK;
+}

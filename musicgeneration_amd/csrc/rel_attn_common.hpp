@@ -1,0 +1,89 @@
+// Shared pieces of the relative-attention kernels (forward + the three backward kernels).
+//
+// Geometry (all kernels): MFMA v_mfma_f32_32x32x16_bf16, dh = 64, tiles of 32 queries x 32 keys.
+//   A operand lane l: row (l&31), k = 8*(l>>5)+j, j=0..7  -> 16 contiguous bytes of a row-major row
+//   B operand lane l: col (l&31), k = 8*(l>>5)+j          -> 16 contiguous bytes of a row-major row
+//   C/D       lane l: col (l&31), row(r) = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
+//
+// Relative term.  With delta = i - j >= 0 the reference's skewed Srel[i,j] = q_i . Er[delta] where
+// Er[delta] = E[M-1-delta]  (layers.py:89-92,111-133).  Er is cut into 32-row "chunks"
+// c = delta>>5.  For a 32x32 tile with D = i0-j0 (a multiple of 32) the tile needs
+// delta in [D-31, D+31], i.e. chunks D/32-1 and D/32.  One product Q_tile . Er_chunk^T (same cost
+// as Q K^T) therefore serves TWO consecutive key tiles: it is written once into a per-wave LDS
+// "band" buffer band[a][ (delta & 63) ] (a = query row in tile) and each tile reads
+// band[a][(D + a - b) & 63] -- the skew is a conflict-free diagonal LDS read, never a tensor.
+#pragma once
+#include "mgx_common.hpp"
+
+namespace relattn {
+
+constexpr int DH = 64;
+constexpr int TILE_BYTES = 32 * DH * 2;   // one 32-row x 64-col bf16 tile = 4 KiB
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float PAD_NEG = -1.0e9f;        // additive mask value of the reference (layers.py:100)
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+// row index (within the 32-row tile) held by accumulator register r of a lane in half hh
+MGX_DEV int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// LDS image "R" (row-fragment reads, ds_read_b128): 32 rows x 128 B, 16-byte chunk index XORed with
+// (row>>1)&7 so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-B slots.
+MGX_DEV int imgR_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// LDS image "T" (transposed reads, ds_read_b64_tr_b16): chunk XORed with ((row>>1)&1)<<2 so that
+// rows q and q+2 of a 4-row block land in different 128-B halves of the 256-B bank row.
+MGX_DEV int imgT_off(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+// A/B row-fragment (8 bf16 at k = 16*ks + 8*hh ..) of row `row` from an image-R tile
+MGX_DEV bf16x8 frag_R(const char* tile, int row, int hh, int ks) {
+    return *(const bf16x8*)(tile + imgR_off(row, 2 * ks + hh));
+}
+
+// Transposed fragment from an image-T tile holding X[32 rows][64 cols]:
+// returns, for this lane, X[kappa(j)][col0 + (lane&31)], j = 0..7, with
+// kappa(j) = 16*s + 8*(j>>2) + 4*hh + (j&3)  -- the k order of an accumulator tile used as operand.
+MGX_DEV bf16x8 frag_T(const char* tile, int lane, int s, int ct) {
+    const int i = lane & 15, g = lane >> 4, hh = lane >> 5;
+    const int rq = i >> 2;                               // row within the 4-row block this lane addresses
+    const int chunk = 4 * ct + 2 * (g & 1) + ((i & 3) >> 1);
+    const int byte_in = 8 * (i & 1);
+    bf16x8 out;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int row = 16 * s + 8 * jq + 4 * hh + rq;
+        const char* p = tile + imgT_off(row, chunk) + byte_in;
+        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p);
+        out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
+    }
+    return out;
+}
+
+// accumulator registers 8s..8s+7 -> bf16x8 operand fragment for k-step s (k order kappa, see frag_T)
+MGX_DEV bf16x8 acc_to_frag(const f32x16& c, int s) {
+    u32x4 w;
+    w.x = pack_bf16x2(c[8 * s + 0], c[8 * s + 1]);
+    w.y = pack_bf16x2(c[8 * s + 2], c[8 * s + 3]);
+    w.z = pack_bf16x2(c[8 * s + 4], c[8 * s + 5]);
+    w.w = pack_bf16x2(c[8 * s + 6], c[8 * s + 7]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+MGX_DEV f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+MGX_DEV f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// order LDS traffic of one wave (same-wave DS ops execute in order; this only pins the compiler)
+MGX_DEV void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace relattn

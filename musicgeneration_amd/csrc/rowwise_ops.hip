@@ -1,0 +1,518 @@
+// HBM-bound satellites of the hot path: embedding+PE, residual+LayerNorm, smoothed CE, Adam.
+// All are streaming kernels: 16-byte vector loads/stores, one wave per row for the row ops,
+// wave-shuffle reductions, fp32 statistics.  Roofline: HBM (algorithmic bytes in DESIGN.md).
+#include "mgx_common.hpp"
+
+// =================================================================================================
+// K1  out[r, :] = dropout(table[tok[r], :] * sqrt(d) + pe[r % L, :])        layers.py:226-229
+// =================================================================================================
+__global__ __launch_bounds__(256) void embed_pe_fwd_kernel(
+    const int32_t* __restrict__ tok, const float* __restrict__ table, const float* __restrict__ pe,
+    uint16_t* __restrict__ out, int rows, int L, int d, int V, float scale, DropCfg dc) {
+    const int gpr = d >> 3;   // 8-element groups per row
+    const long total = (long)rows * gpr;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(g / gpr), c = (int)(g % gpr) * 8;
+        int t = tok[r];
+        t = t < 0 ? 0 : (t >= V ? V - 1 : t);   // host validates; clamp keeps the load in bounds
+        const f32x4* tp = (const f32x4*)(table + (size_t)t * d + c);
+        const f32x4* pp = (const f32x4*)(pe + (size_t)(r % L) * d + c);
+        f32x4 a0 = tp[0], a1 = tp[1], p0 = pp[0], p1 = pp[1];
+        float f[8] = {a0.x * scale + p0.x, a0.y * scale + p0.y, a0.z * scale + p0.z, a0.w * scale + p0.w,
+                      a1.x * scale + p1.x, a1.y * scale + p1.y, a1.z * scale + p1.z, a1.w * scale + p1.w};
+        if (dc.thr16) {
+            float m[8];
+            drop_mult8(dc, (uint32_t)g, m);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] *= m[k];
+        }
+        *(u32x4*)(out + (size_t)r * d + c) = pack8(f);
+    }
+}
+
+// dtable[v, :] += sqrt(d) * sum_{r: tok[r]==v} dropmask * dout[r, :]     one block per vocab row
+// (deterministic: no atomics; tokens are re-scanned from L2 by every block).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(
+    const int32_t* __restrict__ tok, const uint16_t* __restrict__ dout, float* __restrict__ dtable,
+    int rows, int d, float scale, DropCfg dc) {
+    const int v = blockIdx.x;
+    const int gpr = d >> 3;
+    __shared__ int hits[256];
+    __shared__ int nhit;
+    // each thread owns 8-element groups tid, tid+256, ... (d <= 2048*... handled by loop)
+    for (int g0 = 0; g0 < gpr; g0 += 256) {
+        const int gi = g0 + threadIdx.x;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int base = 0; base < rows; base += 256) {
+            if (threadIdx.x == 0) nhit = 0;
+            __syncthreads();
+            const int r = base + threadIdx.x;
+            if (r < rows && tok[r] == v) hits[atomicAdd(&nhit, 1)] = r;
+            __syncthreads();
+            const int n = nhit;
+            if (gi < gpr) {
+                for (int k = 0; k < n; ++k) {
+                    const int rr = hits[k];
+                    u32x4 w = *(const u32x4*)(dout + (size_t)rr * d + gi * 8);
+                    float f[8];
+                    unpack8(w, f);
+                    if (dc.thr16) {
+                        float m[8];
+                        drop_mult8(dc, (uint32_t)((size_t)rr * gpr + gi), m);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) f[q] *= m[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] += f[q];
+                }
+            }
+            __syncthreads();
+        }
+        if (gi < gpr) {
+            float* dp = dtable + (size_t)v * d + gi * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dp[q] += acc[q] * scale;
+        }
+    }
+}
+// NOTE on determinism: hits[] order depends on LDS atomic arrival order, so the fp32 sum order can
+// vary between launches by rounding only; values are identical to ~1 ulp of the fp32 sum.
+
+extern "C" int mgx_embed_pe_fwd(const int32_t* tok, const float* table, const float* pe, uint16_t* out,
+                                int B, int L, int d, int V, float p_drop, uint64_t seed, void* stream) {
+    MGX_REQUIRE(tok && table && pe && out, MGX_ERR_NULL, "mgx_embed_pe_fwd: NULL pointer");
+    MGX_REQUIRE(B > 0 && L > 0 && V > 0 && d > 0 && d % 8 == 0, MGX_ERR_SHAPE,
+                "mgx_embed_pe_fwd: need B,L,V>0 and d%%8==0 (got B=%d L=%d d=%d V=%d)", B, L, d, V);
+    const long total = (long)B * L * (d / 8);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tok, table, pe, out,
+                       B * L, L, d, V, sqrtf((float)d), make_drop(p_drop, seed));
+    MGX_CHECK_LAUNCH("mgx_embed_pe_fwd");
+    return MGX_OK;
+}
+
+extern "C" int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dtable, int B, int L, int d, int V,
+                             float p_drop, uint64_t seed, void* stream) {
+    MGX_REQUIRE(tok && dout && dtable, MGX_ERR_NULL, "mgx_embed_bwd: NULL pointer");
+    MGX_REQUIRE(B > 0 && L > 0 && V > 0 && d > 0 && d % 8 == 0, MGX_ERR_SHAPE,
+                "mgx_embed_bwd: need B,L,V>0 and d%%8==0 (got B=%d L=%d d=%d V=%d)", B, L, d, V);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, tok, dout, dtable, B * L, d,
+                       sqrtf((float)d), make_drop(p_drop, seed));
+    MGX_CHECK_LAUNCH("mgx_embed_bwd");
+    return MGX_OK;
+}
+
+// =================================================================================================
+// A3  key-padding bitmap                                                     utils.py:73-77
+// =================================================================================================
+__global__ void pad_bitmap_kernel(const int32_t* __restrict__ tok, uint32_t* __restrict__ bits, int total, int pad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per token, 64 | blockDim
+    const bool p = (i < total) && (tok[i] == pad);
+    const unsigned long long m = __ballot(p);
+    const int lane = threadIdx.x & 63;
+    if (i < total) {
+        if (lane == 0) bits[i >> 5] = (uint32_t)m;
+        if (lane == 32) bits[i >> 5] = (uint32_t)(m >> 32);
+    }
+}
+extern "C" int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, int B, int L, int pad, void* stream) {
+    MGX_REQUIRE(tok && bits, MGX_ERR_NULL, "mgx_pad_bitmap: NULL pointer");
+    MGX_REQUIRE(B > 0 && L > 0 && L % 32 == 0, MGX_ERR_SHAPE, "mgx_pad_bitmap: need L%%32==0 (got L=%d)", L);
+    const int total = B * L;
+    hipLaunchKernelGGL(pad_bitmap_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, bits,
+                       total, pad);
+    MGX_CHECK_LAUNCH("mgx_pad_bitmap");
+    return MGX_OK;
+}
+
+// =================================================================================================
+// K6  out = LN(dropout(x) + res)      one wave per row, row held in registers (d <= 2048)
+// =================================================================================================
+constexpr int LN_MAXC = 4;   // chunks of 512 columns per wave
+
+template <int NC>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ beta, uint16_t* __restrict__ out, float* __restrict__ mean_o,
+    float* __restrict__ rstd_o, int rows, int d, float eps, DropCfg dc) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int gpr = d >> 3;
+    const float inv_d = 1.f / (float)d;
+    for (int r = wave; r < rows; r += nwave) {
+        float z[NC][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 512 + lane * 8;
+            if (col < d) {
+                float a[8], b[8];
+                unpack8(*(const u32x4*)(x + (size_t)r * d + col), a);
+                unpack8(*(const u32x4*)(res + (size_t)r * d + col), b);
+                if (dc.thr16) {
+                    float m[8];
+                    drop_mult8(dc, (uint32_t)((size_t)r * gpr + (col >> 3)), m);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a[k] *= m[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { z[c][k] = a[k] + b[k]; s += z[c][k]; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) z[c][k] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 512 + lane * 8;
+            if (col < d) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float t = z[c][k] - mean; q += t * t; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+        if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 512 + lane * 8;
+            if (col < d) {
+                const f32x4* gp = (const f32x4*)(gamma + col);
+                const f32x4* bp = (const f32x4*)(beta + col);
+                f32x4 g0 = gp[0], g1 = gp[1], b0 = bp[0], b1 = bp[1];
+                const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (z[c][k] - mean) * rstd * gg[k] + bb[k];
+                *(u32x4*)(out + (size_t)r * d + col) = pack8(o);
+            }
+        }
+    }
+}
+
+// backward.  z recomputed from x,res; dz = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma.
+// dgamma/dbeta: per-wave register partials over the rows it owns -> LDS -> one atomic per column/block.
+template <int NC>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(
+    const uint16_t* __restrict__ dout, const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
+    const float* __restrict__ gamma, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+    uint16_t* __restrict__ dx, uint16_t* __restrict__ dres, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int rows, int d, DropCfg dc) {
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const int gpr = d >> 3;
+    const float inv_d = 1.f / (float)d;
+    float ag[NC][8], ab[NC][8], gg[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int col = c * 512 + lane * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ag[c][k] = 0.f; ab[c][k] = 0.f; gg[c][k] = (col < d) ? gamma[col + k] : 0.f; }
+    }
+    for (int r = wave; r < rows; r += nwave) {
+        const float mean = mean_i[r], rstd = rstd_i[r];
+        float xh[NC][8], g[NC][8], mult[NC][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 512 + lane * 8;
+            if (col < d) {
+                float a[8], b[8], dy[8];
+                unpack8(*(const u32x4*)(x + (size_t)r * d + col), a);
+                unpack8(*(const u32x4*)(res + (size_t)r * d + col), b);
+                unpack8(*(const u32x4*)(dout + (size_t)r * d + col), dy);
+                if (dc.thr16) drop_mult8(dc, (uint32_t)((size_t)r * gpr + (col >> 3)), mult[c]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) mult[c][k] = 1.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float z = a[k] * mult[c][k] + b[k];
+                    xh[c][k] = (z - mean) * rstd;
+                    g[c][k] = dy[k] * gg[c][k];
+                    s1 += g[c][k];
+                    s2 += g[c][k] * xh[c][k];
+                    ag[c][k] += dy[k] * xh[c][k];
+                    ab[c][k] += dy[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { xh[c][k] = 0.f; g[c][k] = 0.f; mult[c][k] = 0.f; }
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = c * 512 + lane * 8;
+            if (col < d) {
+                float dz[8], dxa[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    dz[k] = rstd * (g[c][k] - c1 - xh[c][k] * c2);
+                    dxa[k] = dz[k] * mult[c][k];
+                }
+                *(u32x4*)(dres + (size_t)r * d + col) = pack8(dz);
+                if (dc.thr16 || dx != dres) *(u32x4*)(dx + (size_t)r * d + col) = pack8(dxa);
+            }
+        }
+    }
+    // block reduce of the column partials over the 4 waves, then one atomic per column
+    __shared__ float red[4][512];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) red[wid][lane * 8 + k] = pass ? ab[c][k] : ag[c][k];
+            __syncthreads();
+            for (int j = threadIdx.x; j < 512; j += 256) {
+                const int col = c * 512 + j;
+                if (col < d) {
+                    const float v = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+                    atomicAdd((pass ? dbeta : dgamma) + col, v);
+                }
+            }
+        }
+    }
+}
+
+template <int NC>
+static void launch_ln_fwd(const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta,
+                          uint16_t* out, float* mean, float* rstd, int rows, int d, float eps, DropCfg dc,
+                          hipStream_t s) {
+    int grid = (rows + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(add_ln_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, x, res, gamma, beta, out, mean, rstd,
+                       rows, d, eps, dc);
+}
+template <int NC>
+static void launch_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,
+                          const float* mean, const float* rstd, uint16_t* dx, uint16_t* dres, float* dgamma,
+                          float* dbeta, int rows, int d, DropCfg dc, hipStream_t s) {
+    int grid = (rows + 3) / 4;
+    if (grid > 512) grid = 512;   // fewer blocks -> fewer dgamma/dbeta atomics (512 cols x 512 blocks)
+    hipLaunchKernelGGL(add_ln_bwd_kernel<NC>, dim3(grid), dim3(256), 0, s, dout, x, res, gamma, mean, rstd, dx,
+                       dres, dgamma, dbeta, rows, d, dc);
+}
+
+extern "C" int mgx_add_ln_fwd(const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta,
+                              uint16_t* out, float* mean, float* rstd, int rows, int d, float eps, float p_drop,
+                              uint64_t seed, void* stream) {
+    MGX_REQUIRE(x && res && gamma && beta && out && mean && rstd, MGX_ERR_NULL, "mgx_add_ln_fwd: NULL pointer");
+    MGX_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 512 * LN_MAXC, MGX_ERR_SHAPE,
+                "mgx_add_ln_fwd: need d%%8==0 and d<=%d (got rows=%d d=%d)", 512 * LN_MAXC, rows, d);
+    const DropCfg dc = make_drop(p_drop, seed);
+    const int nc = (d + 511) / 512;
+    hipStream_t s = (hipStream_t)stream;
+    switch (nc) {
+        case 1: launch_ln_fwd<1>(x, res, gamma, beta, out, mean, rstd, rows, d, eps, dc, s); break;
+        case 2: launch_ln_fwd<2>(x, res, gamma, beta, out, mean, rstd, rows, d, eps, dc, s); break;
+        case 3: launch_ln_fwd<3>(x, res, gamma, beta, out, mean, rstd, rows, d, eps, dc, s); break;
+        default: launch_ln_fwd<4>(x, res, gamma, beta, out, mean, rstd, rows, d, eps, dc, s); break;
+    }
+    MGX_CHECK_LAUNCH("mgx_add_ln_fwd");
+    return MGX_OK;
+}
+
+extern "C" int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,
+                              const float* mean, const float* rstd, uint16_t* dx, uint16_t* dres, float* dgamma,
+                              float* dbeta, int rows, int d, float p_drop, uint64_t seed, void* stream) {
+    MGX_REQUIRE(dout && x && res && gamma && mean && rstd && dx && dres && dgamma && dbeta, MGX_ERR_NULL,
+                "mgx_add_ln_bwd: NULL pointer");
+    MGX_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 512 * LN_MAXC, MGX_ERR_SHAPE,
+                "mgx_add_ln_bwd: need d%%8==0 and d<=%d (got rows=%d d=%d)", 512 * LN_MAXC, rows, d);
+    MGX_REQUIRE(p_drop <= 0.f || dx != dres, MGX_ERR_SHAPE, "mgx_add_ln_bwd: dx may alias dres only when p_drop==0");
+    const DropCfg dc = make_drop(p_drop, seed);
+    const int nc = (d + 511) / 512;
+    hipStream_t s = (hipStream_t)stream;
+    switch (nc) {
+        case 1: launch_ln_bwd<1>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
+        case 2: launch_ln_bwd<2>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
+        case 3: launch_ln_bwd<3>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
+        default: launch_ln_bwd<4>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
+    }
+    MGX_CHECK_LAUNCH("mgx_add_ln_bwd");
+    return MGX_OK;
+}
+
+// =================================================================================================
+// K9+K10  label-smoothed CE + accuracy + argmax, one wave per row     criterion.py:51-67
+//   loss_r = lse - (1-eps) x_t - (eps/V) sum_v x_v      (closed form of -sum q' log softmax)
+// =================================================================================================
+__global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
+    const uint16_t* __restrict__ logits, const int32_t* __restrict__ target, float* __restrict__ stats,
+    int32_t* __restrict__ argmax_o, float* __restrict__ row_lse, int rows, int V, int ld, float eps_ls, int pad) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    float loss_acc = 0.f, cnt_acc = 0.f, hit_acc = 0.f, row_acc = 0.f;
+    for (int r = wave; r < rows; r += nwave) {
+        const uint16_t* lp = logits + (size_t)r * ld;
+        float mx = -INFINITY, sx = 0.f;
+        int am = 0x7fffffff;
+        for (int v = lane; v < V; v += 64) {
+            const float xv = bf16_to_f32(lp[v]);
+            sx += xv;
+            if (xv > mx) { mx = xv; am = v; }
+        }
+        // wave arg-max: max value, lowest index among ties (torch.argmax picks the first)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float omx = __shfl_xor(mx, o, 64);
+            const int oam = __shfl_xor(am, o, 64);
+            if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+        }
+        float se = 0.f;
+        for (int v = lane; v < V; v += 64) se += __expf(bf16_to_f32(lp[v]) - mx);
+        se = wave_sum(se);
+        sx = wave_sum(sx);
+        const float lse = mx + __logf(se);
+        const int t = target[r];
+        if (lane == 0) {
+            const float xt = (t >= 0 && t < V) ? bf16_to_f32(lp[t]) : 0.f;
+            row_lse[r] = lse;
+            argmax_o[r] = am;
+            if (t != pad) {
+                loss_acc += lse - (1.f - eps_ls) * xt - (eps_ls / (float)V) * sx;
+                cnt_acc += 1.f;
+            }
+            hit_acc += (am == t) ? 1.f : 0.f;
+            row_acc += 1.f;
+        }
+    }
+    __shared__ float red[4][4];
+    if (lane == 0) { red[wid][0] = loss_acc; red[wid][1] = cnt_acc; red[wid][2] = hit_acc; red[wid][3] = row_acc; }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(stats + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                            red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void smooth_ce_bwd_kernel(
+    const uint16_t* __restrict__ logits, const int32_t* __restrict__ target, const float* __restrict__ stats,
+    const float* __restrict__ row_lse, uint16_t* __restrict__ dlogits, int rows, int V, int ld, float eps_ls,
+    int pad, float gscale) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwave = (gridDim.x * blockDim.x) >> 6;
+    const float cnt = stats[1];
+    const float sc = gscale / cnt;
+    const float u = eps_ls / (float)V;
+    for (int r = wave; r < rows; r += nwave) {
+        const uint16_t* lp = logits + (size_t)r * ld;
+        uint16_t* dp = dlogits + (size_t)r * ld;
+        const int t = target[r];
+        const float lse = row_lse[r];
+        const bool keep = (t != pad);
+        for (int v = lane; v < ld; v += 64) {
+            float gval = 0.f;
+            if (keep && v < V) {
+                const float p = __expf(bf16_to_f32(lp[v]) - lse);
+                gval = sc * (p - u - ((v == t) ? (1.f - eps_ls) : 0.f));
+            }
+            dp[v] = f32_to_bf16(gval);
+        }
+    }
+}
+
+extern "C" int mgx_smooth_ce_fwd(const uint16_t* logits, const int32_t* target, float* stats, int32_t* argmax,
+                                 float* row_lse, int rows, int V, int ld, float eps_ls, int pad, void* stream) {
+    MGX_REQUIRE(logits && target && stats && argmax && row_lse, MGX_ERR_NULL, "mgx_smooth_ce_fwd: NULL pointer");
+    MGX_REQUIRE(rows > 0 && V > 0 && ld >= V, MGX_ERR_SHAPE, "mgx_smooth_ce_fwd: need ld>=V (rows=%d V=%d ld=%d)",
+                rows, V, ld);
+    int grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(smooth_ce_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
+                       argmax, row_lse, rows, V, ld, eps_ls, pad);
+    MGX_CHECK_LAUNCH("mgx_smooth_ce_fwd");
+    return MGX_OK;
+}
+extern "C" int mgx_smooth_ce_bwd(const uint16_t* logits, const int32_t* target, const float* stats,
+                                 const float* row_lse, uint16_t* dlogits, int rows, int V, int ld, float eps_ls,
+                                 int pad, float gscale, void* stream) {
+    MGX_REQUIRE(logits && target && stats && row_lse && dlogits, MGX_ERR_NULL, "mgx_smooth_ce_bwd: NULL pointer");
+    MGX_REQUIRE(rows > 0 && V > 0 && ld >= V, MGX_ERR_SHAPE, "mgx_smooth_ce_bwd: need ld>=V (rows=%d V=%d ld=%d)",
+                rows, V, ld);
+    int grid = (rows + 3) / 4;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(smooth_ce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
+                       row_lse, dlogits, rows, V, ld, eps_ls, pad, gscale);
+    MGX_CHECK_LAUNCH("mgx_smooth_ce_bwd");
+    return MGX_OK;
+}
+
+// =================================================================================================
+// K11  Adam on one flat buffer + bf16 shadow                                train.py:143
+// =================================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   uint16_t* __restrict__ shadow, size_t n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2s, float gscale) {
+    // torch.optim.Adam: p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    const size_t n4 = n >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * gscale;
+            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            pp[k] -= (lr / bc1) * mm[k] / (sqrtf(vv[k]) / bc2s + eps);
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        if (shadow) {
+            u32x2 w = {pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w)};
+            ((u32x2*)shadow)[i] = w;
+        }
+    }
+    // tail (n % 4)
+    const size_t t0 = n4 << 2;
+    const size_t i = t0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float gk = g[i] * gscale;
+        const float mk = b1 * m[i] + (1.f - b1) * gk, vk = b2 * v[i] + (1.f - b2) * gk * gk;
+        m[i] = mk; v[i] = vk;
+        const float pk = p[i] - (lr / bc1) * mk / (sqrtf(vk) / bc2s + eps);
+        p[i] = pk;
+        if (shadow) shadow[i] = f32_to_bf16(pk);
+    }
+}
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ p, uint16_t* __restrict__ s, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s[i] = f32_to_bf16(p[i]);
+}
+
+extern "C" int mgx_adam_step(float* p, const float* g, float* m, float* v, uint16_t* shadow, size_t n, float lr,
+                             float beta1, float beta2, float eps, int step, float gscale, void* stream) {
+    MGX_REQUIRE(p && g && m && v, MGX_ERR_NULL, "mgx_adam_step: NULL pointer");
+    MGX_REQUIRE(n > 0 && step >= 1, MGX_ERR_SHAPE, "mgx_adam_step: need n>0 and step>=1 (step=%d)", step);
+    MGX_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 &&
+                    ((uintptr_t)shadow & 7) == 0,
+                MGX_ERR_SHAPE, "mgx_adam_step: buffers must be 16-byte aligned");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n,
+                       lr, beta1, beta2, eps, bc1, bc2s, gscale);
+    MGX_CHECK_LAUNCH("mgx_adam_step");
+    return MGX_OK;
+}
+extern "C" int mgx_cast_bf16(const float* p, uint16_t* shadow, size_t n, void* stream) {
+    MGX_REQUIRE(p && shadow, MGX_ERR_NULL, "mgx_cast_bf16: NULL pointer");
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, shadow, n);
+    MGX_CHECK_LAUNCH("mgx_cast_bf16");
+    return MGX_OK;
+}

@@ -1,0 +1,248 @@
+"""Host-side wrappers over the C ABI (include/mgx.h): thin launch helpers + torch.autograd glue.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every op below runs a
+hand-written HIP kernel from libmgx.so on the current HIP stream.  Nothing here falls back to
+eager PyTorch: a missing library or a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+BF16 = torch.bfloat16
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.MgxError("mgx ops need CUDA/HIP tensors (no CPU fallback); got a CPU tensor")
+        if t is not None and not t.is_contiguous():
+            raise _lib.MgxError("mgx ops need contiguous tensors")
+
+
+# --------------------------------------------------------------------------------------------------
+# raw launchers (no autograd)
+# --------------------------------------------------------------------------------------------------
+def pad_bitmap(tok: torch.Tensor, pad: int) -> torch.Tensor:
+    """tok int32 [B,L] -> uint32 bitmap [B, L/32] (stored as int32)."""
+    _need_cuda(tok)
+    B, L = tok.shape
+    bits = torch.empty(B, L // 32, dtype=torch.int32, device=tok.device)
+    check(_lib.load().mgx_pad_bitmap(ptr(tok), ptr(bits), B, L, pad, stream_ptr()), "mgx_pad_bitmap")
+    return bits
+
+
+def embed_pe_fwd(tok, table, pe, p_drop=0.0, seed=0):
+    _need_cuda(tok, table, pe)
+    B, L = tok.shape
+    V, d = table.shape
+    out = torch.empty(B, L, d, dtype=BF16, device=tok.device)
+    check(_lib.load().mgx_embed_pe_fwd(ptr(tok), ptr(table), ptr(pe), ptr(out), B, L, d, V, float(p_drop),
+                                       int(seed), stream_ptr()), "mgx_embed_pe_fwd")
+    return out
+
+
+def embed_bwd(tok, dout, dtable, p_drop=0.0, seed=0):
+    _need_cuda(tok, dout, dtable)
+    B, L = tok.shape
+    V, d = dtable.shape
+    check(_lib.load().mgx_embed_bwd(ptr(tok), ptr(dout), ptr(dtable), B, L, d, V, float(p_drop), int(seed),
+                                    stream_ptr()), "mgx_embed_bwd")
+
+
+def rel_attn_fwd(qkv, E, padbits, M=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """qkv bf16 [B,L,3d], E bf16 [M,64], padbits int32 [B,L/32] or None -> (ctx bf16 [B,L,d], lse f32 [B,h,L])"""
+    _need_cuda(qkv, E, padbits)
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    M = E.shape[0] if M is None else M
+    ctx = torch.empty(B, L, d, dtype=BF16, device=qkv.device)
+    lse = torch.empty(B, d // 64, L, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().mgx_rel_attn_fwd(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(lse), B, L, d, M, stream_ptr()),
+          "mgx_rel_attn_fwd")
+    return ctx, lse
+
+
+def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE) -> torch.Tensor:
+    """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place."""
+    _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    check(_lib.load().mgx_rel_attn_bwd(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv),
+                                       ptr(dE), ptr(delta), B, L, d, E.shape[0], stream_ptr()), "mgx_rel_attn_bwd")
+    return dqkv
+
+
+def add_ln_fwd(x, res, gamma, beta, eps=1e-6, p_drop=0.0, seed=0):
+    _need_cuda(x, res, gamma, beta)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    out = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().mgx_add_ln_fwd(ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(out), ptr(mean), ptr(rstd), rows,
+                                     d, float(eps), float(p_drop), int(seed), stream_ptr()), "mgx_add_ln_fwd")
+    return out, mean, rstd
+
+
+def add_ln_bwd(dout, x, res, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0):
+    _need_cuda(dout, x, res, gamma, mean, rstd, dgamma, dbeta)
+    d = x.shape[-1]
+    rows = x.numel() // d
+    dres = torch.empty_like(x)
+    dx = torch.empty_like(x) if p_drop > 0 else dres
+    check(_lib.load().mgx_add_ln_bwd(ptr(dout), ptr(x), ptr(res), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                     ptr(dres), ptr(dgamma), ptr(dbeta), rows, d, float(p_drop), int(seed),
+                                     stream_ptr()), "mgx_add_ln_bwd")
+    return dx, dres
+
+
+def smooth_ce_fwd(logits, target, V, eps_ls, pad):
+    """logits bf16 [rows, ld] -> (stats f32[4], argmax int32[rows], row_lse f32[rows])"""
+    _need_cuda(logits, target)
+    ld = logits.shape[-1]
+    rows = logits.numel() // ld
+    stats = torch.zeros(4, dtype=torch.float32, device=logits.device)
+    argmax = torch.empty(rows, dtype=torch.int32, device=logits.device)
+    row_lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    check(_lib.load().mgx_smooth_ce_fwd(ptr(logits), ptr(target), ptr(stats), ptr(argmax), ptr(row_lse), rows, V, ld,
+                                        float(eps_ls), int(pad), stream_ptr()), "mgx_smooth_ce_fwd")
+    return stats, argmax, row_lse
+
+
+def smooth_ce_bwd(logits, target, stats, row_lse, V, eps_ls, pad, gscale=1.0):
+    _need_cuda(logits, target, stats, row_lse)
+    ld = logits.shape[-1]
+    rows = logits.numel() // ld
+    dlogits = torch.empty_like(logits)
+    check(_lib.load().mgx_smooth_ce_bwd(ptr(logits), ptr(target), ptr(stats), ptr(row_lse), ptr(dlogits), rows, V, ld,
+                                        float(eps_ls), int(pad), float(gscale), stream_ptr()), "mgx_smooth_ce_bwd")
+    return dlogits
+
+
+def adam_step(p, g, m, v, shadow, lr, beta1, beta2, eps, step, gscale=1.0):
+    _need_cuda(p, g, m, v, shadow)
+    check(_lib.load().mgx_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), float(lr), float(beta1),
+                                    float(beta2), float(eps), int(step), float(gscale), stream_ptr()), "mgx_adam_step")
+
+
+def cast_bf16(p, shadow):
+    _need_cuda(p, shadow)
+    check(_lib.load().mgx_cast_bf16(ptr(p), ptr(shadow), p.numel(), stream_ptr()), "mgx_cast_bf16")
+
+
+def linear_fwd(a, w, bias, act=0):
+    """a bf16 [M,K], w bf16 [N,K], bias f32 [N] or None -> bf16 [M,N] = act(a @ w.T + bias)"""
+    _need_cuda(a, w, bias)
+    K = a.shape[-1]
+    Mrows = a.numel() // K
+    N = w.shape[0]
+    out = torch.empty(*a.shape[:-1], N, dtype=BF16, device=a.device)
+    check(_lib.load().mgx_linear_fwd(ptr(a), ptr(w), ptr(bias), ptr(out), Mrows, N, K, int(act), stream_ptr()),
+          "mgx_linear_fwd")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd glue
+# --------------------------------------------------------------------------------------------------
+class _EmbedPE(torch.autograd.Function):
+    """K1: dropout(emb[x]*sqrt(d) + PE)                       layers.py:226-229"""
+
+    @staticmethod
+    def forward(ctx, tok, table, pe, p_drop, seed):
+        ctx.save_for_backward(tok)
+        ctx.p_drop, ctx.seed, ctx.shape = p_drop, seed, table.shape
+        return embed_pe_fwd(tok, table, pe, p_drop, seed)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tok,) = ctx.saved_tensors
+        dtable = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        embed_bwd(tok, dout.contiguous(), dtable, ctx.p_drop, ctx.seed)
+        return None, dtable, None, None, None
+
+
+class _RelAttn(torch.autograd.Function):
+    """K3+K4 (+K4b): fused relative attention over a fused qkv projection.   layers.py:86-106
+    E_master (fp32 parameter) only routes the gradient; the kernels read its bf16 shadow."""
+
+    @staticmethod
+    def forward(ctx, qkv, E_master, E_shadow, padbits):
+        out, lse = rel_attn_fwd(qkv, E_shadow, padbits)
+        ctx.save_for_backward(qkv, E_shadow, out, lse)
+        ctx.padbits = padbits
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qkv, E_shadow, out, lse = ctx.saved_tensors
+        dE = torch.zeros(E_shadow.shape, dtype=torch.float32, device=qkv.device)
+        dqkv = rel_attn_bwd(qkv, E_shadow, ctx.padbits, out, dctx.contiguous(), lse, dE)
+        return dqkv, dE, None, None
+
+
+class _AddLN(torch.autograd.Function):
+    """K6: LayerNorm(dropout(x) + res), eps 1e-6                 layers.py:154-155,159-160"""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed):
+        out, mean, rstd = add_ln_fwd(x, res, gamma, beta, eps, p_drop, seed)
+        ctx.save_for_backward(x, res, gamma, mean, rstd)
+        ctx.p_drop, ctx.seed = p_drop, seed
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, res, gamma, mean, rstd = ctx.saved_tensors
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(gamma)
+        dx, dres = add_ln_bwd(dout.contiguous(), x, res, gamma, mean, rstd, dgamma, dbeta, ctx.p_drop, ctx.seed)
+        return dx, dres, dgamma, dbeta, None, None, None
+
+
+class _SmoothCE(torch.autograd.Function):
+    """K9+K10: smoothed CE (mean over non-pad) with accuracy/argmax side outputs.   criterion.py:43-67"""
+
+    @staticmethod
+    def forward(ctx, logits, target, V, eps_ls, pad):
+        stats, argmax, row_lse = smooth_ce_fwd(logits, target, V, eps_ls, pad)
+        ctx.save_for_backward(logits, target, stats, row_lse)
+        ctx.cfg = (V, eps_ls, pad)
+        ctx.mark_non_differentiable(stats, argmax)
+        loss = stats[0] / stats[1]
+        return loss, stats, argmax
+
+    @staticmethod
+    def backward(ctx, gloss, _gs, _ga):
+        logits, target, stats, row_lse = ctx.saved_tensors
+        V, eps_ls, pad = ctx.cfg
+        # gloss is a 0-d device tensor; keep it on device (no host sync): fold it in afterwards
+        dl = smooth_ce_bwd(logits, target, stats, row_lse, V, eps_ls, pad, 1.0)
+        if not (isinstance(gloss, float) and gloss == 1.0):
+            dl = dl * gloss.to(dl.dtype)
+        return dl, None, None, None, None
+
+
+def embed_pe(tok, table, pe, p_drop=0.0, seed=0):
+    return _EmbedPE.apply(tok, table, pe, float(p_drop), int(seed))
+
+
+def rel_attn(qkv, E_master, E_shadow, padbits):
+    return _RelAttn.apply(qkv, E_master, E_shadow, padbits)
+
+
+def add_ln(x, res, gamma, beta, eps=1e-6, p_drop=0.0, seed=0):
+    return _AddLN.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed))
+
+
+def smooth_ce(logits, target, V, eps_ls, pad):
+    """returns (loss scalar tensor, stats f32[4], argmax int32[rows])"""
+    return _SmoothCE.apply(logits, target, int(V), float(eps_ls), int(pad))

@@ -63,6 +63,24 @@ def srel_from_qe(q: torch.Tensor, E: torch.Tensor, len_k: int) -> torch.Tensor:
     return srel * valid.to(q.dtype)
 
 
+def attn_core(qkv: torch.Tensor, E: torch.Tensor, mask: Optional[torch.Tensor], h: int):
+    """The part of RGA.forward between the q/k/v projections and `fc` (layers.py:86-106), on a fused
+    qkv tensor [B,L,3d] (columns q|k|v, head hd at hd*dh..).  Returns (ctx [B,L,d], weights, logits)."""
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // h
+
+    def heads(t):
+        return t.reshape(B, L, h, dh).permute(0, 2, 1, 3)
+
+    q, k, v = heads(qkv[..., :d]), heads(qkv[..., d:2 * d]), heads(qkv[..., 2 * d:])
+    logits = (q @ k.transpose(-1, -2) + srel_from_qe(q, E, L)) / math.sqrt(dh)
+    if mask is not None:
+        logits = logits + (mask.to(torch.int64) * -1e9).to(logits.dtype)
+    w = torch.softmax(logits, -1)
+    return (w @ v).permute(0, 2, 1, 3).reshape(B, L, d), w, logits
+
+
 def rga_forward(p: Params, prefix: str, x: torch.Tensor, mask: Optional[torch.Tensor], h: int
                 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """RelativeGlobalAttention.forward with q=k=v=x.           layers.py:64-109
