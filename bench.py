@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- training events/sec of the Music Transformer hot path on MI355X.
+
+Metric (BASELINE.json): training events/sec, whole node, REMI seq_len=2048.  A "step" is one pass of
+the hot path over one synthetic batch: forward + label-smoothed CE/accuracy + backward + Adam/Noam
+step (+ gradient all-reduce when N > 1), dropout 0.2 as in the reference config.  Inputs are
+device-resident before the timed region.  Workload = BASELINE.json configs[1] (cfg2):
+REMI vocabulary V=337 (336 + pad), 6 layers, d_model=512 (8 heads x 64), L = max_seq = 2048, bf16
+kernels with fp32 master weights / statistics / accumulation, per-GPU batch 8 (weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the driver contract): value, roofline (dominant kernel, timed
+live with HIP events on the launch stream) and cpu_baseline (the oracle's eager fp32 CPU restatement
+of the same step on a bounded sample, rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# MI355X peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense bf16 MFMA; HBM3E spec)
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+CFG2 = dict(vocab=337, layers=6, d_model=512, seq_len=2048)
+
+
+def train_flops_per_event(nl, d, L, V):
+    """ALGORITHMIC training FLOPs per event: 3 x [nl (10 d^2 + 3 L d) + 2 d V];
+    causal half only, no credit for recompute / band over-compute / padding."""
+    return 3.0 * (nl * (10.0 * d * d + 3.0 * L * d) + 2.0 * d * V)
+
+
+def attn_flops_per_launch(B, L, d, units):
+    """relative attention: one 'unit' = one L x L/2 x 64 product per head = B * L^2 * d flops
+    (2*64 flops x L(L)/2 pairs x heads = L^2 d); forward = 3 units, backward = 6 units."""
+    return units * float(B) * L * L * d
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--seq-len", type=int, default=CFG2["seq_len"])
+    ap.add_argument("--d-model", type=int, default=CFG2["d_model"])
+    ap.add_argument("--layers", type=int, default=CFG2["layers"])
+    ap.add_argument("--vocab", type=int, default=CFG2["vocab"])
+    ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def time_kernels(B, L, d, M, reps=10):
+    """Per-kernel durations (ms) of the attention kernels at the bench shape, HIP events on the
+    current stream (the stream libmgx launches on)."""
+    from musicgeneration_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    E = (torch.randn(M, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dctx = torch.randn(B, L, d, generator=g).to(torch.bfloat16).to(dev)
+    dE = torch.zeros(M, 64, device=dev)
+    ctx, lse = ops.rel_attn_fwd(qkv, E, None)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, delta)
+    torch.cuda.synchronize()
+
+    def timed(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    out = {"rel_attn_fwd_kernel": timed(lambda: ops.rel_attn_fwd(qkv, E, None))}
+    for name, bit in (("attn_delta_kernel", 1), ("rel_attn_dq_kernel", 2), ("rel_attn_dkv_kernel", 4),
+                      ("rel_attn_de_kernel", 8)):
+        out[name] = timed(lambda bit=bit: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, bit, dqkv, delta))
+    return out
+
+
+def cpu_baseline(args):
+    """The oracle's eager-PyTorch fp32 CPU restatement of the same training step (reference semantics:
+    materialised L x L attention, dropout 0.2, Adam + Noam), bounded to ~10-30 s of CPU work."""
+    from oracle import ref_cpu as R
+    # a 1-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(16, avail))
+    torch.set_num_threads(ncores)
+    V, d, nl, L = args.vocab, args.d_model, args.layers, args.seq_len
+    Bc = args.cpu_batch
+    p = R.init_params(V, d, nl, L, seed=0)
+    tr = R.CpuTrainer(p, pad=V - 1, d_cfg=d, dropout=args.dropout, accum=1)
+    gen = torch.Generator().manual_seed(1234)
+    nsteps, t_used = 0, 0.0
+    while nsteps < 1 or (t_used < args.cpu_seconds and nsteps < 3):
+        xf = torch.randint(0, V - 1, (Bc, L + 1), generator=gen)
+        t0 = time.time()
+        tr.step(xf[:, :-1].to(torch.int32), xf[:, 1:].to(torch.int32))
+        t_used += time.time() - t0
+        nsteps += 1
+    return {"value": Bc * L * nsteps / t_used, "unit": "events/s", "cores": ncores, "kind": "port",
+            "sample": f"{nsteps} step(s) of the same cfg2 training step at batch {Bc} x L {L} "
+                      f"(oracle/ref_cpu.py CpuTrainer, eager PyTorch fp32, {ncores} threads, {t_used:.1f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
+    from musicgeneration_amd.dp import DataParallel
+    from musicgeneration_amd.metrics import CategoricalAccuracy, LogitsBucketting, MetricsSet
+    from musicgeneration_amd.network import MusicTransformer
+    from musicgeneration_amd.optim import FusedAdam
+
+    V, d, nl, L, B = args.vocab, args.d_model, args.layers, args.seq_len, args.batch
+    torch.manual_seed(0)
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=args.dropout).to(dev)
+    mt.train()
+    dp = DataParallel(mt)
+    opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale)
+    sch = CustomSchedule(d, optimizer=opt)
+    ms = MetricsSet({"accuracy": CategoricalAccuracy(), "loss": SmoothCrossEntropyLoss(0.1, V, V - 1),
+                     "bucket": LogitsBucketting(V)})
+    # device-resident synthetic batch ring (uniform over real tokens; pad id V-1 never drawn)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    ring = []
+    for _ in range(4):
+        xf = torch.randint(0, V - 1, (B, L + 1), generator=gen)
+        ring.append((xf[:, :-1].to(torch.int32).contiguous().to(dev), xf[:, 1:].to(torch.int32).contiguous().to(dev)))
+
+    def step(i):
+        x, y = ring[i % len(ring)]
+        m = ms(mt(x), y)
+        m["loss"].backward()
+        sch.step()
+        opt.zero_grad()
+        return m
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for i in range(args.warmup):
+        last = step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    events = float(world) * B * L * args.steps
+    value = events / dt
+    loss_val = float(last["loss"].item())
+
+    out = {
+        "metric": "training events/sec (whole node), REMI seq_len=2048",
+        "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"cfg2 REMI_EventSeq MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} "
+                               f"bf16, fwd+smoothed-CE+bwd+Adam/Noam, dropout {args.dropout}",
+                   "global_batch": world * B, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
+                   "final_loss": loss_val},
+        "model_mfma_frac": value * train_flops_per_event(nl, d, L, V) / (world * PEAK_BF16_TFLOPS * 1e12),
+    }
+    if rank == 0 and not args.no_kernel_timing:
+        kt = time_kernels(B, L, d, L)
+        units = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 2.5, "rel_attn_dkv_kernel": 2.5,
+                 "rel_attn_de_kernel": 1.0}
+        dom = max(units, key=lambda k: kt[k])
+        ach = attn_flops_per_launch(B, L, d, units[dom]) / (kt[dom] * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                           "launch_ms": kt[dom], "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, units[dom])}
+        out["kernel_ms"] = kt
+        out["attention_all_kernels"] = {
+            "ms_per_layer": sum(kt.values()),
+            "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

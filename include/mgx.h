@@ -73,6 +73,12 @@ int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* pad
                      const uint16_t* ctx, const uint16_t* dctx, const float* lse,
                      uint16_t* dqkv, float* dE, float* delta,
                      int B, int L, int d, int M, void* stream);
+/* same, running only the selected sub-kernels (bit0 delta pre-pass, bit1 dQ, bit2 dK+dV, bit3 dE);
+ * used by bench.py to time each kernel on its own.  parts == 15 is mgx_rel_attn_bwd.             */
+int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
+                           const uint16_t* ctx, const uint16_t* dctx, const float* lse,
+                           uint16_t* dqkv, float* dE, float* delta,
+                           int B, int L, int d, int M, int parts, void* stream);
 
 /* ---- K6: out = LayerNorm(dropout(x) + res) * gamma + beta, eps    layers.py:154-155,159-160 --
  * x,res,out bf16 [rows,d]; gamma,beta f32 [d]; mean,rstd f32 [rows] saved for the backward.    */

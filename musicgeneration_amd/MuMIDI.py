@@ -1,0 +1,144 @@
+"""MuMIDI multi-track event codec (array side), mirroring mg/model/utils/MuMIDI.py:340-431,543-574.
+
+Vocabulary (485 ids): empty 0, note_on 1-256 (drums +128), note_duration 257-288,
+note_velocity 289-320, bar 321, position 322-354, track 355-360, tempo_class 361-363,
+tempo_value 364-423, chord 424-484.  Reference quirk kept: ``from_array`` names a track token by
+its track ('melody' ... 'drum'), which ``to_array`` cannot encode (KeyError) -- MuMIDI.py:396-397."""
+from __future__ import annotations
+
+import collections
+
+import numpy as np
+
+DEFAULT_FRACTION = 32
+DEFAULT_DURATION_STEP = 60
+DEFAULT_DURATION_RANGE = range(DEFAULT_DURATION_STEP, 1921)
+DEFAULT_DURATION_BINS = np.arange(DEFAULT_DURATION_RANGE.start, DEFAULT_DURATION_RANGE.stop,
+                                  DEFAULT_DURATION_STEP, dtype=int)
+DEFAULT_TEMPO_INTERVALS = [range(30, 90), range(90, 150), range(150, 210)]
+DEFAULT_VELOCITY = 100
+DEFAULT_PITCH_RANGE = range(1, 129)
+DEFAULT_VELOCITY_STEPS = 4
+DEFAULT_VELOCITY_RANGE = range(DEFAULT_VELOCITY_STEPS, 129)
+DEFAULT_VELOCITY_BINS = np.arange(DEFAULT_VELOCITY_RANGE.start, DEFAULT_VELOCITY_RANGE.stop, DEFAULT_VELOCITY_STEPS)
+DEFAULT_DRUM_TYPE = range(1, 129)
+DEFAULT_RESOLUTION = 480
+DEFAULT_TRACKS = ['melody', 'piano', 'bass', 'guitar', 'string', 'drum']
+tracks_idx = {track: idx for idx, track in enumerate(DEFAULT_TRACKS)}
+
+chord_quality = ['maj', 'min', 'dim', 'aug', 'dom']
+chord_root = ['C', 'C#', 'D', 'D#', 'E', 'F', 'F#', 'G', 'G#', 'A', 'A#', 'B']
+chord_map = {}
+for _qi, _q in enumerate(chord_quality):
+    for _ri, _r in enumerate(chord_root):
+        chord_map[_r + ':' + _q] = _qi * len(chord_root) + _ri
+chord_map['N:N'] = len(chord_quality) * len(chord_root)
+inv_chord_map = {v: k for k, v in chord_map.items()}
+
+
+class Event(object):
+    def __init__(self, name, time, value, text):
+        self.name = name
+        self.time = time
+        self.value = value
+        self.text = text
+
+    def __repr__(self):
+        return 'Event(name={}, time={}, value={}, text={})'.format(self.name, self.time, self.value, self.text)
+
+
+class MuMIDI_EventSeq:
+    pitch_range = DEFAULT_PITCH_RANGE
+    velocity_range = DEFAULT_VELOCITY_RANGE
+    velocity_steps = DEFAULT_VELOCITY_STEPS
+    duration_bins = DEFAULT_DURATION_BINS
+    feats_ranges = None
+    idxs_feats = None
+
+    def __init__(self, events=[]):
+        pass
+
+    @staticmethod
+    def dim():
+        return sum(MuMIDI_EventSeq.feat_dims().values())
+
+    @staticmethod
+    def feat_dims():
+        """MuMIDI.py:352-386"""
+        feat_dims = collections.OrderedDict()
+        feat_dims['empty'] = 1
+        feat_dims['note_on'] = len(MuMIDI_EventSeq.pitch_range) + len(DEFAULT_DRUM_TYPE)
+        feat_dims['note_duration'] = len(MuMIDI_EventSeq.duration_bins)
+        feat_dims['note_velocity'] = len(DEFAULT_VELOCITY_BINS)
+        feat_dims['bar'] = 1
+        feat_dims['position'] = DEFAULT_FRACTION + 1
+        feat_dims['track'] = len(DEFAULT_TRACKS)
+        feat_dims['tempo_class'] = len(DEFAULT_TEMPO_INTERVALS)
+        feat_dims['tempo_value'] = len(DEFAULT_TEMPO_INTERVALS[0])
+        feat_dims['chord'] = len(chord_map)
+        return feat_dims
+
+    @staticmethod
+    def feat_ranges():
+        if MuMIDI_EventSeq.feats_ranges is not None:
+            return MuMIDI_EventSeq.feats_ranges
+        offset = 0
+        feat_ranges = collections.OrderedDict()
+        for feat_name, feat_dim in MuMIDI_EventSeq.feat_dims().items():
+            feat_ranges[feat_name] = range(offset, offset + feat_dim)
+            offset += feat_dim
+        MuMIDI_EventSeq.feats_ranges = feat_ranges
+        return feat_ranges
+
+    @staticmethod
+    def dims_feat():
+        """index -> (name, value); track ids map to the TRACK's name (MuMIDI.py:388-405)"""
+        if MuMIDI_EventSeq.idxs_feats is not None:
+            return MuMIDI_EventSeq.idxs_feats
+        idxs_feat = collections.OrderedDict()
+        for feat_name, r in MuMIDI_EventSeq.feat_ranges().items():
+            for i, idx in enumerate(r):
+                idxs_feat[idx] = (DEFAULT_TRACKS[i], i) if feat_name == 'track' else (feat_name, i)
+        MuMIDI_EventSeq.idxs_feats = idxs_feat
+        return idxs_feat
+
+    @staticmethod
+    def get_track_id(track_name):
+        return MuMIDI_EventSeq.feat_ranges()['track'][0] + tracks_idx[track_name]
+
+    @staticmethod
+    def check(feat_name, idx):
+        return idx in MuMIDI_EventSeq.feat_ranges()[feat_name]
+
+    @staticmethod
+    def to_array(events):
+        """MuMIDI.py:543-556 ('track_<name>' events use the first five characters as the feature)"""
+        feat_idxs = MuMIDI_EventSeq.feat_ranges()
+        idxs = []
+        for event in events:
+            if event.name == 'chord':
+                idxs.append(feat_idxs[event.name][chord_map[event.value]])
+            elif event.name.startswith('track'):
+                idxs.append(feat_idxs[event.name[:5]][event.value])
+            else:
+                idxs.append(feat_idxs[event.name][event.value])
+        dtype = np.uint8 if MuMIDI_EventSeq.dim() <= 256 else np.uint16
+        return np.array(idxs, dtype=dtype)
+
+    @staticmethod
+    def to_event(words):
+        """MuMIDI.py:558-569"""
+        idxs_feat = MuMIDI_EventSeq.dims_feat()
+        events = []
+        for word in words:
+            event_name, event_value = idxs_feat[int(word)]
+            if event_name == 'chord':
+                event_value = inv_chord_map[event_value]
+            if event_name == 'track':   # never true: dims_feat already substituted the track's name
+                event_name = event_name + '_' + DEFAULT_TRACKS[event_value]
+            events.append(Event(event_name, None, event_value, None))
+        return events
+
+    @staticmethod
+    def from_array(words):
+        return MuMIDI_EventSeq.to_event(words)

@@ -1,0 +1,125 @@
+"""REMI event codec (array side), mirroring mg/model/utils/REMI.py:404-536.
+
+Vocabulary (336 ids): note_on 0-126, note_duration 127-190, note_velocity 191-194, bar 195,
+position 196-211, tempo_class 212-214, tempo_value 215-274, chord 275-335 (chord values are the
+strings 'C:maj' ... 'N:N').  Reference quirk kept: note_velocity has only 4 slots, so
+``to_array`` raises IndexError for a velocity value >= 4 (REMI.py:452 vs :206-209)."""
+from __future__ import annotations
+
+import collections
+
+import numpy as np
+
+DEFAULT_FRACTION = 16
+DEFAULT_DURATION_RANGE = range(60, 3841)
+DEFAULT_DURATION_STEP = 60
+DEFAULT_DURATION_BINS = np.arange(DEFAULT_DURATION_RANGE.start, DEFAULT_DURATION_RANGE.stop,
+                                  DEFAULT_DURATION_STEP, dtype=int)
+DEFAULT_tempo_INTERVALS = [range(30, 90), range(90, 150), range(150, 210)]
+DEFAULT_VELOCITY = 100
+DEFAULT_PITCH_RANGE = range(0, 127)
+DEFAULT_VELOCITY_STEPS = 4
+DEFAULT_VELOCITY_RANGE = range(DEFAULT_VELOCITY_STEPS, 128)
+DEFAULT_VELOCITY_BINS = np.arange(DEFAULT_VELOCITY_RANGE.start, DEFAULT_VELOCITY_RANGE.stop, DEFAULT_VELOCITY_STEPS)
+DEFAULT_RESOLUTION = 480
+
+chord_quality = ['maj', 'min', 'dim', 'aug', 'dom']
+chord_root = ['C', 'C#', 'D', 'D#', 'E', 'F', 'F#', 'G', 'G#', 'A', 'A#', 'B']
+chord_map = {}
+for _qi, _q in enumerate(chord_quality):
+    for _ri, _r in enumerate(chord_root):
+        chord_map[_r + ':' + _q] = _qi * len(chord_root) + _ri
+chord_map['N:N'] = len(chord_quality) * len(chord_root)
+inv_chord_map = {v: k for k, v in chord_map.items()}
+
+
+class Event(object):
+    def __init__(self, name, time, value, text):
+        self.name = name
+        self.time = time
+        self.value = value
+        self.text = text
+
+    def __repr__(self):
+        return 'Event(name={}, time={}, value={}, text={})'.format(self.name, self.time, self.value, self.text)
+
+
+class REMI_EventSeq:
+    pitch_range = DEFAULT_PITCH_RANGE
+    velocity_range = DEFAULT_VELOCITY_RANGE
+    velocity_steps = DEFAULT_VELOCITY_STEPS
+    duration_bins = DEFAULT_DURATION_BINS
+
+    def __init__(self, events=[]):
+        pass
+
+    @staticmethod
+    def dim():
+        return sum(REMI_EventSeq.feat_dims().values())
+
+    @staticmethod
+    def feat_dims():
+        """REMI.py:434-460"""
+        feat_dims = collections.OrderedDict()
+        feat_dims['note_on'] = len(REMI_EventSeq.pitch_range)
+        feat_dims['note_duration'] = len(REMI_EventSeq.duration_bins)
+        feat_dims['note_velocity'] = REMI_EventSeq.velocity_steps
+        feat_dims['bar'] = 1
+        feat_dims['position'] = DEFAULT_FRACTION
+        feat_dims['tempo_class'] = len(DEFAULT_tempo_INTERVALS)
+        feat_dims['tempo_value'] = len(DEFAULT_tempo_INTERVALS[0])
+        feat_dims['chord'] = len(chord_map)
+        return feat_dims
+
+    @staticmethod
+    def feat_ranges():
+        offset = 0
+        feat_ranges = collections.OrderedDict()
+        for feat_name, feat_dim in REMI_EventSeq.feat_dims().items():
+            feat_ranges[feat_name] = range(offset, offset + feat_dim)
+            offset += feat_dim
+        return feat_ranges
+
+    @staticmethod
+    def dims_feat():
+        """index -> (feature name, value)          REMI.py:462-474"""
+        idxs_feat = collections.OrderedDict()
+        for feat_name, r in REMI_EventSeq.feat_ranges().items():
+            for i, idx in enumerate(r):
+                idxs_feat[idx] = (feat_name, i)
+        return idxs_feat
+
+    @staticmethod
+    def get_velocity_bins():
+        n = REMI_EventSeq.velocity_range.stop - REMI_EventSeq.velocity_range.start
+        return np.arange(REMI_EventSeq.velocity_range.start, REMI_EventSeq.velocity_range.stop,
+                         n / (REMI_EventSeq.velocity_steps - 1))
+
+    @staticmethod
+    def to_array(events):
+        """REMI.py:510-520"""
+        feat_idxs = REMI_EventSeq.feat_ranges()
+        idxs = []
+        for event in events:
+            if event.name == 'chord':
+                idxs.append(feat_idxs[event.name][chord_map[event.value]])
+            else:
+                idxs.append(feat_idxs[event.name][event.value])   # IndexError beyond the feature's slots
+        dtype = np.uint8 if REMI_EventSeq.dim() <= 256 else np.uint16
+        return np.array(idxs, dtype=dtype)
+
+    @staticmethod
+    def to_event(words):
+        """REMI.py:522-531"""
+        idxs_feat = REMI_EventSeq.dims_feat()
+        events = []
+        for word in words:
+            event_name, event_value = idxs_feat[int(word)]
+            if event_name == 'chord':
+                event_value = inv_chord_map[event_value]
+            events.append(Event(event_name, None, event_value, None))
+        return events
+
+    @staticmethod
+    def from_array(words):
+        return REMI_EventSeq.to_event(words)

@@ -20,6 +20,7 @@ SIGNATURES = {
     "mgx_pad_bitmap": [_vp, _vp, _i, _i, _i, _vp],
     "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_bwd_parts": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mgx_add_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _vp],
     "mgx_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _vp],
     "mgx_smooth_ce_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
@@ -41,6 +42,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must load ITS libamdhip64 first: libmgx.so then binds to the same HIP runtime instance
+    # (loading libmgx first would pull in /opt/rocm's copy and leave two runtimes in one process).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH) or os.environ.get("MGX_REBUILD") == "1":
         from . import _build
         _build.build()

@@ -1,0 +1,65 @@
+"""Mirror of mg/model/MusicTransformer/criterion.py: SmoothCrossEntropyLoss + CustomSchedule."""
+from __future__ import annotations
+
+import torch
+from torch.nn.modules.loss import _Loss
+
+from . import ops
+
+
+class SmoothCrossEntropyLoss(_Loss):
+    """criterion.py:28-67.  ``forward(input [.., V] logits, target [..])`` -> scalar mean over
+    non-``ignore_index`` targets of -sum q' log softmax, q' = (1-eps) onehot + eps/V.
+    Runs the fused libmgx kernel (closed form, no one-hot tensor); logits are consumed in bf16."""
+    __constants__ = ['label_smoothing', 'vocab_size', 'ignore_index', 'reduction']
+
+    def __init__(self, label_smoothing, vocab_size, ignore_index=-100, reduction='mean', is_logits=True):
+        assert 0.0 <= label_smoothing <= 1.0
+        super().__init__(reduction=reduction)
+        self.label_smoothing = label_smoothing
+        self.vocab_size = vocab_size
+        self.ignore_index = ignore_index
+        self.input_is_logits = is_logits
+
+    def fused(self, input, target):
+        """-> (loss, stats f32[4] = [loss_sum, n_nonpad, n_correct, n_rows], argmax int32[rows])"""
+        if input.dtype != torch.bfloat16:
+            input = input.to(torch.bfloat16)
+        return ops.smooth_ce(input.contiguous(), target.to(torch.int32).contiguous(), self.vocab_size,
+                             self.label_smoothing, self.ignore_index)
+
+    def forward(self, input, target):
+        loss, stats, _ = self.fused(input, target)
+        if self.reduction == 'mean':
+            return loss
+        elif self.reduction == 'sum':
+            return loss * stats[1]
+        raise NotImplementedError
+
+
+class CustomSchedule:
+    """criterion.py:70-96 (Noam schedule driving ``optimizer.step()``)."""
+
+    def __init__(self, d_model, warmup_steps=4000, optimizer=None):
+        super(CustomSchedule, self).__init__()
+        self.d_model = d_model
+        self.optimizer = optimizer
+        self.warmup_steps = warmup_steps
+        self._step = 0
+        self._rate = 0
+
+    def step(self):
+        "Update parameters and rate"
+        self._step += 1
+        rate = self.rate()
+        for p in self.optimizer.param_groups:
+            p['lr'] = rate
+        self._rate = rate
+        self.optimizer.step()
+
+    def rate(self, step=None):
+        if step is None:
+            step = self._step
+        arg1 = step ** (-0.5)
+        arg2 = step * (self.warmup_steps ** -1.5)
+        return self.d_model ** (-0.5) * min(arg1, arg2)

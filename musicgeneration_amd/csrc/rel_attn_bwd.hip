@@ -623,9 +623,9 @@ __global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
     }
 }
 
-extern "C" int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const uint16_t* ctx,
-                                const uint16_t* dctx, const float* lse, uint16_t* dqkv, float* dE, float* delta,
-                                int B, int L, int d, int M, void* stream) {
+extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
+                                      const uint16_t* ctx, const uint16_t* dctx, const float* lse, uint16_t* dqkv,
+                                      float* dE, float* delta, int B, int L, int d, int M, int parts, void* stream) {
     MGX_REQUIRE(qkv && E && ctx && dctx && lse && dqkv && dE && delta, MGX_ERR_NULL, "mgx_rel_attn_bwd: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
                 "mgx_rel_attn_bwd: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
@@ -640,16 +640,22 @@ extern "C" int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const ui
     hipStream_t s = (hipStream_t)stream;
     const int heads = d / 64;
     const uint16_t* Er = E + (size_t)(M - L) * 64;
-    {
+    if (parts & 1) {
         const long total = (long)B * L * heads * 8;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
     }
     const dim3 gq((L + 127) / 128, B * heads);
-    hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
-    hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
+    if (parts & 2) hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
+    if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
     const dim3 ge(((L >> 5) + 3) / 4, B * heads);
-    hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(256), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
+    if (parts & 8) hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(256), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
                        dE + (size_t)(M - L) * 64, L, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_bwd");
     return MGX_OK;
+}
+
+extern "C" int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const uint16_t* ctx,
+                                const uint16_t* dctx, const float* lse, uint16_t* dqkv, float* dE, float* delta,
+                                int B, int L, int d, int M, void* stream) {
+    return mgx_rel_attn_bwd_parts(qkv, E, padbits, ctx, dctx, lse, dqkv, dE, delta, B, L, d, M, 15, stream);
 }

@@ -1,0 +1,182 @@
+"""Host-side mirror of the reference's ``layers.py`` (mg/model/MusicTransformer/layers.py).
+
+Same class names, constructor arguments and ``state_dict`` keys (``Decoder.enc_layers.{i}.rga.Wq.weight``
+...), so reference checkpoints load unchanged -- but the arithmetic runs in libmgx.so:
+
+* parameters live in ONE flat fp32 buffer (``FlatStore``), gradients in one flat fp32 buffer the
+  backward kernels accumulate into directly (no per-parameter autograd accumulation), and a flat bf16
+  shadow is what the GEMM / attention kernels read.  Wq|Wk|Wv are adjacent, so the fused
+  ``[3d, d]`` QKV weight is a zero-copy view (one GEMM instead of the reference's three,
+  layers.py:71-84).
+* a layer's gradient segment is contiguous => it is the data-parallel all-reduce bucket
+  (``musicgeneration_amd.dp``), launched as soon as the layer's backward has finished.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+ALIGN = 64  # elements; keeps every fp32/bf16 view 128-byte aligned
+
+
+def sinusoid(max_seq: int, embedding_dim: int) -> np.ndarray:
+    """float64 [1, max_seq, d] table; same values as the reference's nested loops (layers.py:9-19)."""
+    pos = np.arange(max_seq, dtype=np.float64)[:, None]
+    i = np.arange(embedding_dim, dtype=np.float64)[None, :]
+    par = np.mod(i, 2)
+    ang = pos * np.exp(-math.log(10000) * i / embedding_dim) * np.exp(math.log(10000) / embedding_dim * par) \
+        + 0.5 * math.pi * par
+    return np.sin(ang)[None]
+
+
+class DynamicPositionEmbedding(torch.nn.Module):
+    """layers.py:22-39.  The table is built once in float64 and kept device-resident in fp32
+    (the reference re-uploads the fp64 table on every forward)."""
+
+    def __init__(self, embedding_dim, max_seq=2048):
+        super().__init__()
+        self.positional_embedding = sinusoid(max_seq, embedding_dim)
+        self.register_buffer("_pe", torch.from_numpy(self.positional_embedding[0]).to(torch.float32),
+                             persistent=False)
+
+    def table(self) -> torch.Tensor:
+        return self._pe
+
+    def forward(self, x):   # API parity; the fused path uses table() inside embed_pe
+        return x + self._pe[: x.size(1)].to(x.dtype)[None]
+
+
+class RelativeGlobalAttention(torch.nn.Module):
+    """Parameter container with the reference's names (layers.py:47-62); compute is in EncoderLayer."""
+
+    def __init__(self, h=4, d=256, add_emb=False, max_seq=2048, **kwargs):
+        super().__init__()
+        if d // h != 64:
+            raise ValueError("the MI355X kernels fix dh = d/h = 64 (the reference always uses h = d//64, layers.py:219)")
+        self.len_k = None
+        self.max_seq = max_seq
+        self.h = h
+        self.d = d
+        self.dh = d // h
+        self.Wq = torch.nn.Linear(self.d, self.d)
+        self.Wk = torch.nn.Linear(self.d, self.d)
+        self.Wv = torch.nn.Linear(self.d, self.d)
+        self.fc = torch.nn.Linear(d, d)
+        self.additional = add_emb
+        self.E = torch.nn.Parameter(torch.randn([self.max_seq, int(self.dh)]))
+
+
+class EncoderLayer(torch.nn.Module):
+    """layers.py:137-161: post-LN block, FFN d -> d/2 -> d with ReLU, LayerNorm eps 1e-6."""
+
+    def __init__(self, d_model, rate=0.1, h=16, additional=False, max_seq=2048):
+        super().__init__()
+        self.d_model = d_model
+        self.rate = rate
+        self.rga = RelativeGlobalAttention(h=h, d=d_model, max_seq=max_seq, add_emb=additional)
+        self.FFN_pre = torch.nn.Linear(self.d_model, self.d_model // 2)
+        self.FFN_suf = torch.nn.Linear(self.d_model // 2, self.d_model)
+        self.layernorm1 = torch.nn.LayerNorm(self.d_model, eps=1e-6)
+        self.layernorm2 = torch.nn.LayerNorm(self.d_model, eps=1e-6)
+        self.dropout1 = torch.nn.Dropout(rate)
+        self.dropout2 = torch.nn.Dropout(rate)
+
+    # order of this layer's parameters inside the flat buffers (Wq|Wk|Wv adjacent!)
+    FLAT_ORDER = ["rga.Wq.weight", "rga.Wk.weight", "rga.Wv.weight", "rga.Wq.bias", "rga.Wk.bias", "rga.Wv.bias",
+                  "rga.fc.weight", "rga.fc.bias", "rga.E", "layernorm1.weight", "layernorm1.bias",
+                  "FFN_pre.weight", "FFN_pre.bias", "FFN_suf.weight", "FFN_suf.bias",
+                  "layernorm2.weight", "layernorm2.bias"]
+
+
+class FlatStore:
+    """Flat fp32 parameter / gradient buffers + bf16 shadow for an ordered list of parameters."""
+
+    def __init__(self, named: List[Tuple[str, torch.nn.Parameter]], device, buckets: List[Tuple[str, List[str]]]):
+        self.names = [n for n, _ in named]
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for n, p in named:
+            self.offsets[n] = (off, p.numel())
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.param = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=device)
+        self.params = {}
+        for n, p in named:
+            o, k = self.offsets[n]
+            view = self.param[o:o + k].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + k].view(p.shape)
+            self.params[n] = p
+        # bucket = (name, start, end) contiguous range of the flat buffers
+        self.buckets: List[Tuple[str, int, int]] = []
+        for bname, members in buckets:
+            lo = min(self.offsets[m][0] for m in members)
+            hi = max(self.offsets[m][0] + (self.offsets[m][1] + ALIGN - 1) // ALIGN * ALIGN for m in members)
+            self.buckets.append((bname, lo, hi))
+        self._synced_version = -1
+        self.sync_shadow(force=True)
+
+    # ---- views ------------------------------------------------------------------------------------
+    def w(self, name):          # bf16 shadow view with the parameter's shape
+        o, k = self.offsets[name]
+        return self.shadow[o:o + k].view(self.params[name].shape)
+
+    def g(self, name):          # fp32 gradient view
+        o, k = self.offsets[name]
+        return self.grad[o:o + k].view(self.params[name].shape)
+
+    def fused(self, first, last, rows, cols, what="shadow"):
+        """one view over adjacent parameters first..last (e.g. Wq|Wk|Wv -> [3d, d])"""
+        o = self.offsets[first][0]
+        buf = {"shadow": self.shadow, "grad": self.grad, "param": self.param}[what]
+        end = self.offsets[last][0] + self.offsets[last][1]
+        assert end - o == rows * cols, "fused view needs adjacent, unpadded parameters"
+        return buf[o:end].view(rows, cols)
+
+    # ---- shadow / grad maintenance ------------------------------------------------------------------
+    def sync_shadow(self, force=False):
+        """Re-round the bf16 shadow if the fp32 parameters were modified by anything but our Adam kernel
+        (torch in-place ops bump the version counter shared by all views of ``param``)."""
+        v = self.param._version
+        if force or v != self._synced_version:
+            ops.cast_bf16(self.param, self.shadow)
+            self._synced_version = self.param._version
+
+    def attach_grads(self):
+        """``optimizer.zero_grad(set_to_none=True)`` drops our views: re-attach (and zero) them."""
+        lost = False
+        for n, p in self.params.items():
+            o, k = self.offsets[n]
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                lost = True
+                break
+        if lost:
+            self.grad.zero_()
+            for n, p in self.params.items():
+                o, k = self.offsets[n]
+                p.grad = self.grad[o:o + k].view(p.shape)
+
+
+class Encoder(torch.nn.Module):
+    """layers.py:208-233.  ``forward`` runs the whole stack through the HIP kernels."""
+
+    def __init__(self, num_layers, d_model, input_vocab_size, rate=0.1, max_len=None):
+        super().__init__()
+        self.d_model = d_model
+        self.num_layers = num_layers
+        self.rate = rate
+        self.max_len = max_len
+        self.embedding = torch.nn.Embedding(num_embeddings=input_vocab_size, embedding_dim=d_model)
+        self.pos_encoding = DynamicPositionEmbedding(self.d_model, max_seq=max_len)
+        self.enc_layers = torch.nn.ModuleList(
+            [EncoderLayer(d_model, rate, h=self.d_model // 64, additional=False, max_seq=max_len)
+             for _ in range(num_layers)])
+        self.dropout = torch.nn.Dropout(rate)

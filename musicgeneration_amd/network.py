@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's ``network.py`` (mg/model/MusicTransformer/network.py:14-84).
+
+``MusicTransformer`` keeps the reference's constructor, attributes, ``state_dict`` keys and the
+three-way ``forward`` convention (train -> logits; eval -> (logits, weights); after ``test()`` ->
+``generate(...).tolist()``), and runs on the HIP kernels of libmgx.so.  There is no eager/CPU
+fallback: ``forward`` on a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import config, ops
+from .layers import Encoder, EncoderLayer, FlatStore
+
+
+class MusicTransformer(torch.nn.Module):
+    def __init__(self, embedding_dim=256, vocab_size=388 + 2, num_layer=6,
+                 max_seq=2048, dropout=0.2, debug=False, loader_path=None, dist=False, writer=None):
+        super().__init__()
+        self.infer = False
+        if loader_path is not None:
+            raise NotImplementedError("loader_path: the reference calls an undefined load_config_file "
+                                      "(network.py:19-20); pass the hyper-parameters explicitly")
+        self._debug = debug
+        self.max_seq = max_seq
+        self.num_layer = num_layer
+        self.embedding_dim = embedding_dim
+        self.vocab_size = vocab_size
+        self.dist = dist
+        self.writer = writer
+        self.dropout_rate = dropout
+        # the reference reads the pad id from the global config module (network.py:37); the default
+        # is the same rule (pad = last vocabulary id), overridable per model
+        self.pad_token = vocab_size - 1
+        self.Decoder = Encoder(num_layers=self.num_layer, d_model=self.embedding_dim,
+                               input_vocab_size=self.vocab_size, rate=dropout, max_len=max_seq)
+        self.fc = torch.nn.Linear(self.embedding_dim, self.vocab_size)
+        self.return_attention_weights = False   # eval-mode [B,h,L,L] weights are a debug output
+        self._store: Optional[FlatStore] = None
+        self._seed_ctr = 0
+        self._dp = None                          # set by dp.DataParallel
+
+    # ------------------------------------------------------------------------------------------
+    # flat storage
+    # ------------------------------------------------------------------------------------------
+    def _flat_order(self):
+        named = dict(self.named_parameters())
+        order = ["Decoder.embedding.weight"]
+        buckets = [("embedding", ["Decoder.embedding.weight"])]
+        for i in range(self.num_layer):
+            names = [f"Decoder.enc_layers.{i}.{n}" for n in EncoderLayer.FLAT_ORDER]
+            order += names
+            buckets.append((f"layer{i}", names))
+        order += ["fc.weight", "fc.bias"]
+        buckets.append(("fc", ["fc.weight", "fc.bias"]))
+        assert set(order) == set(named), "flat order must cover every parameter exactly once"
+        return [(n, named[n]) for n in order], buckets
+
+    def store(self) -> FlatStore:
+        dev = self.fc.weight.device
+        if self._store is None or self._store.param.device != dev:
+            if dev.type != "cuda":
+                raise ops._lib.MgxError("MusicTransformer runs on the MI355X kernels only: move it to a HIP "
+                                        "device first (model.to('cuda')); there is no CPU fallback")
+            named, buckets = self._flat_order()
+            self._store = FlatStore(named, dev, buckets)
+        return self._store
+
+    def _apply(self, fn, *a, **k):     # .to()/.cuda() re-materialise parameters: rebuild lazily
+        self._store = None
+        return super()._apply(fn, *a, **k)
+
+    def _next_seed(self) -> int:
+        self._seed_ctr += 1
+        return (torch.initial_seed() * 1000003 + self._seed_ctr * 64) & 0x7FFFFFFFFFFFFFFF
+
+    # ------------------------------------------------------------------------------------------
+    # the hot path: tokens -> logits                 network.py:37-39 + layers.py:223-233,152-161
+    # ------------------------------------------------------------------------------------------
+    def _logits(self, x: torch.Tensor) -> torch.Tensor:
+        st = self.store()
+        st.sync_shadow()
+        training = self.training and torch.is_grad_enabled()
+        if training:
+            st.attach_grads()
+        B, L = x.shape
+        if L % 32 != 0 or L > self.max_seq:
+            raise ValueError(f"sequence length {L} must be a multiple of 32 and <= max_seq={self.max_seq}")
+        tok = x.to(torch.int32).contiguous()
+        d = self.embedding_dim
+        p = self.dropout_rate if self.training else 0.0
+        seed = self._next_seed()
+        dp = self._dp
+        done = (lambda name: (lambda: dp.bucket_ready(name))) if (dp is not None and training) else (lambda name: None)
+
+        padbits = ops.pad_bitmap(tok, self.pad_token)
+        pe = self.Decoder.pos_encoding.table()
+        P = st.params
+        h = ops.embed_pe(tok, P["Decoder.embedding.weight"], pe, p, seed, st.g("Decoder.embedding.weight"),
+                         done("embedding"))
+        for i in range(self.num_layer):
+            pre = f"Decoder.enc_layers.{i}."
+            wqkv = st.fused(pre + "rga.Wq.weight", pre + "rga.Wv.weight", 3 * d, d)
+            gqkv = st.fused(pre + "rga.Wq.weight", pre + "rga.Wv.weight", 3 * d, d, "grad")
+            bqkv = st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "param").view(3 * d)
+            gbqkv = st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "grad").view(3 * d)
+            # the layer's bucket is complete when its first op (QKV projection) has run its backward
+            qkv = ops.linear(h, P[pre + "rga.Wq.weight"], wqkv, bqkv, 0, gqkv, gbqkv, done(f"layer{i}"))
+            ctx = ops.rel_attn(qkv, P[pre + "rga.E"], st.w(pre + "rga.E"), padbits, st.g(pre + "rga.E"))
+            a = ops.linear(ctx, P[pre + "rga.fc.weight"], st.w(pre + "rga.fc.weight"), P[pre + "rga.fc.bias"].data,
+                           0, st.g(pre + "rga.fc.weight"), st.g(pre + "rga.fc.bias"))
+            o1 = ops.add_ln(a, h, P[pre + "layernorm1.weight"].data, P[pre + "layernorm1.bias"].data, 1e-6, p,
+                            seed + 4 * i + 1, st.g(pre + "layernorm1.weight"), st.g(pre + "layernorm1.bias"))
+            f = ops.linear(o1, P[pre + "FFN_pre.weight"], st.w(pre + "FFN_pre.weight"), P[pre + "FFN_pre.bias"].data,
+                           1, st.g(pre + "FFN_pre.weight"), st.g(pre + "FFN_pre.bias"))
+            f = ops.linear(f, P[pre + "FFN_suf.weight"], st.w(pre + "FFN_suf.weight"), P[pre + "FFN_suf.bias"].data,
+                           0, st.g(pre + "FFN_suf.weight"), st.g(pre + "FFN_suf.bias"))
+            h = ops.add_ln(f, o1, P[pre + "layernorm2.weight"].data, P[pre + "layernorm2.bias"].data, 1e-6, p,
+                           seed + 4 * i + 2, st.g(pre + "layernorm2.weight"), st.g(pre + "layernorm2.bias"))
+        logits = ops.linear(h, P["fc.weight"], st.w("fc.weight"), P["fc.bias"].data, 0, st.g("fc.weight"),
+                            st.g("fc.bias"), done("fc"))
+        return logits
+
+    def forward(self, x, length=None, writer=None):
+        if self.training or not self.infer:
+            logits = self._logits(x)
+            if self.training:
+                return logits
+            if self.return_attention_weights:
+                raise NotImplementedError("materialised [B,h,L,L] attention weights are not built yet")
+            return logits, []
+        return self.generate(x, length, None).contiguous().tolist()
+
+    # ------------------------------------------------------------------------------------------
+    # sampling                                                                   network.py:44-80
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def next_token_probs(self, window: torch.Tensor) -> torch.Tensor:
+        """softmax of the logits that follow the last token of ``window`` [B,W] (causal semantics:
+        the training-time mask, see DESIGN.md 'decode semantics').  The window is right-padded to a
+        multiple of 32 with pad tokens, which lie in the masked future of every real position."""
+        B, W = window.shape
+        Lp = (W + 31) // 32 * 32
+        if Lp != W:
+            padcol = torch.full((B, Lp - W), self.pad_token, dtype=window.dtype, device=window.device)
+            window = torch.cat([window, padcol], 1)
+        was = self.training
+        self.eval()
+        logits = self._logits(window)[:, W - 1].float()
+        self.train(was)
+        return torch.softmax(logits, -1)
+
+    @torch.no_grad()
+    def generate(self, prior: torch.Tensor, length=2048, tf_board_writer=None, temperature: float = 1.0,
+                 top_k: int = 0, top_p: float = 1.0):
+        """Autoregressive sampling with the reference's sliding window (config.threshold_len) and
+        full-softmax categorical sampling by default (top_k=0, top_p=1.0 == the reference's
+        OneHotCategorical, network.py:73-74); top-k / top-p / temperature are opt-in extras."""
+        decode_array = prior
+        result_array = prior
+        for _ in range(length):
+            if decode_array.size(1) >= config.threshold_len:
+                decode_array = decode_array[:, 1:]
+            probs = self.next_token_probs(decode_array)
+            probs = filter_probs(probs, temperature, top_k, top_p)
+            nxt = torch.multinomial(probs, 1).to(decode_array.dtype)
+            decode_array = torch.cat((decode_array, nxt), dim=-1)
+            result_array = torch.cat((result_array, nxt), dim=-1)
+        return result_array
+
+    def test(self):
+        self.eval()
+        self.infer = True
+
+
+def filter_probs(probs: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0) -> torch.Tensor:
+    """temperature / top-k / nucleus filtering of a probability matrix [B,V]; identity at defaults."""
+    if temperature != 1.0:
+        probs = torch.softmax(torch.log(probs.clamp_min(1e-30)) / temperature, -1)
+    if top_k and top_k < probs.shape[-1]:
+        kth = probs.topk(top_k, -1).values[:, -1:]
+        probs = torch.where(probs >= kth, probs, torch.zeros_like(probs))
+    if top_p < 1.0:
+        sp, si = probs.sort(-1, descending=True)
+        cum = sp.cumsum(-1)
+        keep = (cum - sp) < top_p * cum[:, -1:]
+        sp = torch.where(keep, sp, torch.zeros_like(sp))
+        probs = torch.zeros_like(probs).scatter(-1, si, sp)
+    return probs / probs.sum(-1, keepdim=True)

@@ -68,15 +68,16 @@ def rel_attn_fwd(qkv, E, padbits, M=None) -> Tuple[torch.Tensor, torch.Tensor]:
     return ctx, lse
 
 
-def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE) -> torch.Tensor:
-    """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place."""
+def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, delta=None) -> torch.Tensor:
+    """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench)."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
     B, L, d3 = qkv.shape
     d = d3 // 3
-    dqkv = torch.empty_like(qkv)
-    delta = torch.empty_like(lse)
-    check(_lib.load().mgx_rel_attn_bwd(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv),
-                                       ptr(dE), ptr(delta), B, L, d, E.shape[0], stream_ptr()), "mgx_rel_attn_bwd")
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
+    delta = torch.empty_like(lse) if delta is None else delta
+    check(_lib.load().mgx_rel_attn_bwd_parts(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse),
+                                             ptr(dqkv), ptr(dE), ptr(delta), B, L, d, E.shape[0], int(parts),
+                                             stream_ptr()), "mgx_rel_attn_bwd")
     return dqkv
 
 
@@ -152,60 +153,111 @@ def linear_fwd(a, w, bias, act=0):
 
 # --------------------------------------------------------------------------------------------------
 # autograd glue
+#
+# Master (fp32) parameters are passed to each Function only to anchor the autograd graph: their
+# gradients are NOT returned (None) but accumulated by the kernels straight into the fp32 views of
+# the model's flat gradient buffer (``g*`` arguments).  ``done`` is an optional callable invoked at
+# the end of backward (the data-parallel bucket hook, see dp.py).
 # --------------------------------------------------------------------------------------------------
+_MM_OUT_DTYPE = None
+
+
+def _mm_f32(a, b):
+    """a,b bf16 -> a @ b in fp32 (library GEMM; interim until the TN kernel lands in libmgx)."""
+    global _MM_OUT_DTYPE
+    if _MM_OUT_DTYPE is None:
+        try:
+            torch.mm(a[:1], b[:, :1], out_dtype=torch.float32)
+            _MM_OUT_DTYPE = True
+        except Exception:
+            _MM_OUT_DTYPE = False
+    if _MM_OUT_DTYPE:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return torch.mm(a, b).float()
+
+
 class _EmbedPE(torch.autograd.Function):
     """K1: dropout(emb[x]*sqrt(d) + PE)                       layers.py:226-229"""
 
     @staticmethod
-    def forward(ctx, tok, table, pe, p_drop, seed):
+    def forward(ctx, tok, table, pe, p_drop, seed, gtable, done):
         ctx.save_for_backward(tok)
-        ctx.p_drop, ctx.seed, ctx.shape = p_drop, seed, table.shape
+        ctx.cfg = (p_drop, seed, gtable, done)
         return embed_pe_fwd(tok, table, pe, p_drop, seed)
 
     @staticmethod
     def backward(ctx, dout):
         (tok,) = ctx.saved_tensors
-        dtable = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
-        embed_bwd(tok, dout.contiguous(), dtable, ctx.p_drop, ctx.seed)
-        return None, dtable, None, None, None
+        p_drop, seed, gtable, done = ctx.cfg
+        embed_bwd(tok, dout.contiguous(), gtable, p_drop, seed)
+        if done is not None:
+            done()
+        return None, None, None, None, None, None, None
 
 
 class _RelAttn(torch.autograd.Function):
-    """K3+K4 (+K4b): fused relative attention over a fused qkv projection.   layers.py:86-106
-    E_master (fp32 parameter) only routes the gradient; the kernels read its bf16 shadow."""
+    """K3+K4 (+K4b): fused relative attention over a fused qkv projection.   layers.py:86-106"""
 
     @staticmethod
-    def forward(ctx, qkv, E_master, E_shadow, padbits):
+    def forward(ctx, qkv, E_master, E_shadow, padbits, gE):
         out, lse = rel_attn_fwd(qkv, E_shadow, padbits)
         ctx.save_for_backward(qkv, E_shadow, out, lse)
-        ctx.padbits = padbits
+        ctx.cfg = (padbits, gE)
         return out
 
     @staticmethod
     def backward(ctx, dctx):
         qkv, E_shadow, out, lse = ctx.saved_tensors
-        dE = torch.zeros(E_shadow.shape, dtype=torch.float32, device=qkv.device)
-        dqkv = rel_attn_bwd(qkv, E_shadow, ctx.padbits, out, dctx.contiguous(), lse, dE)
-        return dqkv, dE, None, None
+        padbits, gE = ctx.cfg
+        dqkv = rel_attn_bwd(qkv, E_shadow, padbits, out, dctx.contiguous(), lse, gE)
+        return dqkv, None, None, None, None
 
 
 class _AddLN(torch.autograd.Function):
     """K6: LayerNorm(dropout(x) + res), eps 1e-6                 layers.py:154-155,159-160"""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed):
+    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta):
         out, mean, rstd = add_ln_fwd(x, res, gamma, beta, eps, p_drop, seed)
         ctx.save_for_backward(x, res, gamma, mean, rstd)
-        ctx.p_drop, ctx.seed = p_drop, seed
+        ctx.cfg = (p_drop, seed, ggamma, gbeta)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, res, gamma, mean, rstd = ctx.saved_tensors
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(gamma)
-        dx, dres = add_ln_bwd(dout.contiguous(), x, res, gamma, mean, rstd, dgamma, dbeta, ctx.p_drop, ctx.seed)
-        return dx, dres, dgamma, dbeta, None, None, None
+        p_drop, seed, ggamma, gbeta = ctx.cfg
+        dx, dres = add_ln_bwd(dout.contiguous(), x, res, gamma, mean, rstd, ggamma, gbeta, p_drop, seed)
+        return dx, dres, None, None, None, None, None, None, None
+
+
+class _Linear(torch.autograd.Function):
+    """K2/K5/K7/K8: y = act(x @ W^T + b).  Forward: libmgx MFMA GEMM with fused bias/ReLU epilogue.
+    Backward: dx = dy @ W, dW += dy^T @ x (fp32), db += colsum(dy)."""
+
+    @staticmethod
+    def forward(ctx, x, w_master, w_shadow, bias, act, gw, gb, done):
+        y = linear_fwd(x, w_shadow, bias, act)
+        ctx.save_for_backward(x, w_shadow, y if act else None)
+        ctx.cfg = (act, gw, gb, done)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_shadow, y = ctx.saved_tensors
+        act, gw, gb, done = ctx.cfg
+        if act:
+            dy = torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
+        N, K = w_shadow.shape
+        dy2 = dy.reshape(-1, N)
+        x2 = x.reshape(-1, K)
+        dx = torch.mm(dy2, w_shadow).view(x.shape)
+        gw.add_(_mm_f32(dy2.t(), x2))
+        if gb is not None:
+            gb.add_(dy2.sum(0, dtype=torch.float32))
+        if done is not None:
+            done()
+        return dx, None, None, None, None, None, None, None
 
 
 class _SmoothCE(torch.autograd.Function):
@@ -224,23 +276,26 @@ class _SmoothCE(torch.autograd.Function):
     def backward(ctx, gloss, _gs, _ga):
         logits, target, stats, row_lse = ctx.saved_tensors
         V, eps_ls, pad = ctx.cfg
-        # gloss is a 0-d device tensor; keep it on device (no host sync): fold it in afterwards
+        # gloss is a 0-d device tensor: folding it in on the device avoids a host sync
         dl = smooth_ce_bwd(logits, target, stats, row_lse, V, eps_ls, pad, 1.0)
-        if not (isinstance(gloss, float) and gloss == 1.0):
-            dl = dl * gloss.to(dl.dtype)
+        dl = dl * gloss.to(dl.dtype)
         return dl, None, None, None, None
 
 
-def embed_pe(tok, table, pe, p_drop=0.0, seed=0):
-    return _EmbedPE.apply(tok, table, pe, float(p_drop), int(seed))
+def embed_pe(tok, table, pe, p_drop=0.0, seed=0, gtable=None, done=None):
+    return _EmbedPE.apply(tok, table, pe, float(p_drop), int(seed), gtable, done)
 
 
-def rel_attn(qkv, E_master, E_shadow, padbits):
-    return _RelAttn.apply(qkv, E_master, E_shadow, padbits)
+def rel_attn(qkv, E_master, E_shadow, padbits, gE):
+    return _RelAttn.apply(qkv, E_master, E_shadow, padbits, gE)
 
 
-def add_ln(x, res, gamma, beta, eps=1e-6, p_drop=0.0, seed=0):
-    return _AddLN.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed))
+def add_ln(x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta):
+    return _AddLN.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed), ggamma, gbeta)
+
+
+def linear(x, w_master, w_shadow, bias, act, gw, gb, done=None):
+    return _Linear.apply(x, w_master, w_shadow, bias, int(act), gw, gb, done)
 
 
 def smooth_ce(logits, target, V, eps_ls, pad):

@@ -1,0 +1,68 @@
+"""Fused Adam over the model's flat buffers (replaces torch.optim.Adam of train.py:143).
+
+One kernel launch updates every parameter, both moments and the bf16 shadow.  ``state_dict`` /
+``load_state_dict`` use torch.optim.Adam's layout (per-parameter ``step``, ``exp_avg``,
+``exp_avg_sq``) so the reference's checkpoints (train.py:201-207) round-trip."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, model, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale: float = 1.0):
+        self.model = model
+        store = model.store()
+        self.store = store
+        params = [store.params[n] for n in store.names]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.m = torch.zeros_like(store.param)
+        self.v = torch.zeros_like(store.param)
+        self._t = 0
+        self.grad_scale = grad_scale
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.store.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._t += 1
+        dp = getattr(self.model, "_dp", None)
+        if dp is not None:
+            dp.wait_all()                 # gradients of every bucket reduced (sum) before the update
+        ops.adam_step(self.store.param, self.store.grad, self.m, self.v, self.store.shadow, g["lr"], g["betas"][0],
+                      g["betas"][1], g["eps"], self._t, self.grad_scale)
+
+    # ---- torch.optim.Adam-compatible checkpoint format --------------------------------------------
+    def state_dict(self):
+        st = self.store
+        state = {}
+        for i, n in enumerate(st.names):
+            o, k = st.offsets[n]
+            shp = st.params[n].shape
+            state[i] = {"step": torch.tensor(float(self._t)), "exp_avg": self.m[o:o + k].view(shp).clone(),
+                        "exp_avg_sq": self.v[o:o + k].view(shp).clone()}
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": g["betas"], "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(st.names)))}
+        return {"state": state, "param_groups": [group], "param_names": list(st.names)}
+
+    def load_state_dict(self, sd):
+        st = self.store
+        names = sd.get("param_names")
+        if names is None:
+            # a torch.optim.Adam checkpoint: parameters are numbered in model.parameters() order
+            names = [n for n, _ in self.model.named_parameters()]
+        for i, n in enumerate(names):
+            if i not in sd["state"]:
+                continue
+            o, k = st.offsets[n]
+            s = sd["state"][i]
+            self.m[o:o + k].copy_(s["exp_avg"].reshape(-1))
+            self.v[o:o + k].copy_(s["exp_avg_sq"].reshape(-1))
+            self._t = int(float(s["step"]))
+        g = sd["param_groups"][0]
+        self.param_groups[0]["lr"] = g["lr"]

@@ -1,0 +1,227 @@
+"""MIDI-like event codec (array side), mirroring mg/model/utils/sequence.py (and its twin
+mg/model/MusicTransformer/sequence.py): ``EventSeq.from_array / to_array / feat_dims / feat_ranges /
+dim``, ``Event``, plus the note-level helpers that need no MIDI library.
+
+Vocabulary (308 ids): note_on 0-87 (pitch 21..108), note_off 88-175, velocity 176-207 (32 bins),
+time_shift 208-307 (0.01 s .. 1.00 s).  Index work is integer and bit-exact with the reference
+(tests/test_codecs.py against tests/golden/g5_codecs.json).  MIDI file I/O uses pretty_midi when it
+is installed (optional; absent in this image)."""
+from __future__ import annotations
+
+import collections
+import copy
+
+import numpy as np
+
+DEFAULT_SAVING_PROGRAM = 1
+DEFAULT_LOADING_PROGRAMS = range(128)
+DEFAULT_RESOLUTION = 220
+DEFAULT_TEMPO = 120
+DEFAULT_VELOCITY = 64
+DEFAULT_PITCH_RANGE = range(21, 109)
+DEFAULT_VELOCITY_RANGE = range(21, 109)
+DEFAULT_NORMALIZATION_BASELINE = 60
+
+USE_VELOCITY = True
+BEAT_LENGTH = 60 / DEFAULT_TEMPO
+DEFAULT_TIME_SHIFT_BINS = 0.01 * np.arange(1, 101)
+DEFAULT_VELOCITY_STEPS = 32
+DEFAULT_NOTE_LENGTH = BEAT_LENGTH * 2
+MIN_NOTE_LENGTH = BEAT_LENGTH / 2
+
+
+class Note:
+    """Minimal stand-in for pretty_midi.Note (velocity, pitch, start, end)."""
+
+    def __init__(self, velocity, pitch, start, end):
+        self.velocity, self.pitch, self.start, self.end = velocity, pitch, start, end
+
+    def __repr__(self):
+        return 'Note(start={}, end={}, pitch={}, velocity={})'.format(self.start, self.end, self.pitch, self.velocity)
+
+
+class NoteSeq:
+    """sequence.py:44-124 (the parts that do not need a MIDI parser)."""
+
+    def __init__(self, notes=[]):
+        self.notes = []
+        if notes:
+            self.add_notes(sorted(notes, key=lambda note: note.start))
+
+    def add_notes(self, notes):
+        self.notes += notes
+        self.notes.sort(key=lambda note: note.start)
+
+    @staticmethod
+    def from_midi_file(path, *args, **kwargs):
+        from pretty_midi import PrettyMIDI   # optional dependency
+        import itertools
+        midi = PrettyMIDI(path)
+        programs = kwargs.get('programs', DEFAULT_LOADING_PROGRAMS)
+        notes = itertools.chain(*[inst.notes for inst in midi.instruments
+                                  if inst.program in programs and not inst.is_drum])
+        return NoteSeq(list(notes))
+
+    def to_midi_file(self, path, program=DEFAULT_SAVING_PROGRAM, resolution=DEFAULT_RESOLUTION,
+                     tempo=DEFAULT_TEMPO):
+        from pretty_midi import PrettyMIDI, Instrument, Note as PMNote   # optional dependency
+        midi = PrettyMIDI(resolution=resolution, initial_tempo=tempo)
+        inst = Instrument(program, False, 'NoteSeq')
+        inst.notes = [PMNote(int(n.velocity), int(n.pitch), n.start, n.end) for n in self.notes]
+        midi.instruments.append(inst)
+        midi.write(path)
+
+
+class Event:
+    def __init__(self, type, time, value):
+        self.type = type
+        self.time = time
+        self.value = value
+
+    def __repr__(self):
+        return 'Event(type={}, time={}, value={})'.format(self.type, self.time, self.value)
+
+
+class EventSeq:
+    pitch_range = DEFAULT_PITCH_RANGE
+    velocity_range = DEFAULT_VELOCITY_RANGE
+    velocity_steps = DEFAULT_VELOCITY_STEPS
+    time_shift_bins = DEFAULT_TIME_SHIFT_BINS
+
+    # ---- vocabulary ------------------------------------------------------------------------------
+    @staticmethod
+    def feat_dims():
+        """sequence.py:204-212"""
+        feat_dims = collections.OrderedDict()
+        feat_dims['note_on'] = len(EventSeq.pitch_range)
+        feat_dims['note_off'] = len(EventSeq.pitch_range)
+        if USE_VELOCITY:
+            feat_dims['velocity'] = EventSeq.velocity_steps
+        feat_dims['time_shift'] = len(EventSeq.time_shift_bins)
+        return feat_dims
+
+    @staticmethod
+    def feat_ranges():
+        """sequence.py:214-221"""
+        offset = 0
+        feat_ranges = collections.OrderedDict()
+        for feat_name, feat_dim in EventSeq.feat_dims().items():
+            feat_ranges[feat_name] = range(offset, offset + feat_dim)
+            offset += feat_dim
+        return feat_ranges
+
+    @staticmethod
+    def dim():
+        return sum(EventSeq.feat_dims().values())
+
+    @staticmethod
+    def get_velocity_bins():
+        n = EventSeq.velocity_range.stop - EventSeq.velocity_range.start
+        return np.arange(EventSeq.velocity_range.start, EventSeq.velocity_range.stop,
+                         n / (EventSeq.velocity_steps - 1))
+
+    # ---- index array <-> events --------------------------------------------------------------------
+    @staticmethod
+    def decode_arrays(event_indeces):
+        """Vectorised core of from_array: -> (type_id int[T], value int[T], time float64[T]).
+        type_id indexes feat_ranges() order; ids outside the vocabulary get type_id -1 (the
+        reference silently drops them, sequence.py:189-196)."""
+        idx = np.asarray(event_indeces).astype(np.int64).reshape(-1)
+        starts = np.array([r.start for r in EventSeq.feat_ranges().values()] + [EventSeq.dim()], dtype=np.int64)
+        tid = np.searchsorted(starts, idx, side='right') - 1
+        valid = (idx >= 0) & (idx < EventSeq.dim())
+        tid = np.where(valid, tid, -1)
+        val = idx - starts[np.clip(tid, 0, len(starts) - 2)]
+        names = list(EventSeq.feat_ranges().keys())
+        ts = names.index('time_shift')
+        # the reference accumulates time with sequential float adds: reproduce that order exactly
+        inc = np.where(tid == ts, EventSeq.time_shift_bins[np.clip(val, 0, len(EventSeq.time_shift_bins) - 1)], 0.0)
+        time = np.zeros(len(idx), dtype=np.float64)
+        acc = 0.0
+        for i in range(len(idx)):          # sequential: float addition is not associative
+            time[i] = acc
+            acc += inc[i]
+        return tid, val, time
+
+    @staticmethod
+    def from_array(event_indeces):
+        """sequence.py:185-198"""
+        tid, val, time = EventSeq.decode_arrays(event_indeces)
+        names = list(EventSeq.feat_ranges().keys())
+        events = [Event(names[t], tm, int(v)) for t, v, tm in zip(tid, val, time) if t >= 0]
+        return EventSeq(events)
+
+    def __init__(self, events=[]):
+        for event in events:
+            assert isinstance(event, Event)
+        self.events = copy.deepcopy(events)
+        time = 0
+        for event in self.events:
+            event.time = time
+            if event.type == 'time_shift':
+                time += EventSeq.time_shift_bins[event.value]
+
+    def to_array(self):
+        """sequence.py:283-287"""
+        feat_idxs = EventSeq.feat_ranges()
+        idxs = [feat_idxs[event.type][event.value] for event in self.events]
+        dtype = np.uint8 if EventSeq.dim() <= 256 else np.uint16
+        return np.array(idxs, dtype=dtype)
+
+    # ---- notes <-> events (no MIDI library needed) ---------------------------------------------------
+    @staticmethod
+    def from_note_seq(note_seq):
+        """sequence.py:145-183"""
+        note_events = []
+        velocity_bins = EventSeq.get_velocity_bins()
+        for note in note_seq.notes:
+            if note.pitch in EventSeq.pitch_range:
+                if USE_VELOCITY:
+                    velocity = min(max(note.velocity, EventSeq.velocity_range.start), EventSeq.velocity_range.stop - 1)
+                    note_events.append(Event('velocity', note.start, int(np.searchsorted(velocity_bins, velocity))))
+                pitch_index = note.pitch - EventSeq.pitch_range.start
+                note_events.append(Event('note_on', note.start, pitch_index))
+                note_events.append(Event('note_off', note.end, pitch_index))
+        note_events.sort(key=lambda event: event.time)
+        events = []
+        for i, event in enumerate(note_events):
+            events.append(event)
+            if event is note_events[-1]:
+                break
+            interval = note_events[i + 1].time - event.time
+            shift = 0
+            while interval - shift >= EventSeq.time_shift_bins[0]:
+                index = int(np.searchsorted(EventSeq.time_shift_bins, interval - shift, side='right') - 1)
+                events.append(Event('time_shift', event.time + shift, index))
+                shift += EventSeq.time_shift_bins[index]
+        return EventSeq(events)
+
+    def to_note_seq(self):
+        """sequence.py:235-272"""
+        time = 0
+        notes = []
+        velocity = DEFAULT_VELOCITY
+        velocity_bins = EventSeq.get_velocity_bins()
+        last_notes = {}
+        for event in self.events:
+            if event.type == 'note_on':
+                pitch = event.value + EventSeq.pitch_range.start
+                note = Note(velocity, pitch, time, None)
+                notes.append(note)
+                last_notes[pitch] = note
+            elif event.type == 'note_off':
+                pitch = event.value + EventSeq.pitch_range.start
+                if pitch in last_notes:
+                    note = last_notes[pitch]
+                    note.end = max(time, note.start + MIN_NOTE_LENGTH)
+                    del last_notes[pitch]
+            elif event.type == 'velocity':
+                index = min(event.value, velocity_bins.size - 1)
+                velocity = velocity_bins[index]
+            elif event.type == 'time_shift':
+                time += EventSeq.time_shift_bins[event.value]
+        for note in notes:
+            if note.end is None:
+                note.end = note.start + DEFAULT_NOTE_LENGTH
+            note.velocity = int(note.velocity)
+        return NoteSeq(notes)
