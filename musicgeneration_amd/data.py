@@ -1,0 +1,89 @@
+"""Mirror of mg/model/MusicTransformer/data.py: ``Data(dir_path, max_length)`` with
+``batch / slide_seq2seq_batch / seq2seq_batch / smallest_encoder_batch`` and ``file_dict``.
+
+File format: each ``*.data`` file is ``torch.save(np.ndarray[uint8|uint16, T])`` written
+by the reference's preprocess_*.py.  The reference unpickles every sampled file on every step
+(data.py:96-107); here every file is loaded ONCE into host memory at construction (so the GPU is
+not starved), and each rank may use its own ``random.Random`` stream (data-parallel sharding).
+MuMIDI files hold a dict {'melody','arrangement'}; the reference's filter drops them
+(len(dict) == 2 < max_length) -- pass ``field='melody'`` to train on one of the two arrays."""
+from __future__ import annotations
+
+import random
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import utils
+
+
+def _load_array(fname, field=None):
+    obj = torch.load(fname, weights_only=False)
+    if isinstance(obj, dict):
+        if field is None:
+            return None, len(obj)
+        obj = obj[field]
+    arr = np.asarray(obj)
+    return arr, len(arr)
+
+
+class Data:
+    def __init__(self, dir_path, max_length, field: Optional[str] = None, rng: Optional[random.Random] = None):
+        self.files = list(utils.find_files_by_extensions(dir_path, ['.data']))
+        self.field = field
+        self._rng = rng if rng is not None else random
+        self._cache: Dict[str, np.ndarray] = {}
+        n = len(self.files)
+        self.file_dict = {
+            'train': self.file_filter(self.files[:int(n * 0.8)], max_length),
+            'valid': self.file_filter(self.files[int(n * 0.8): int(n * 0.9)], max_length),
+            'test': self.file_filter(self.files[int(n * 0.9):], max_length),
+        }
+        self._seq_file_name_idx = 0
+        self._seq_idx = 0
+
+    def __repr__(self):
+        return (f"<class Data has train: {len(self.file_dict['train'])}, val: {len(self.file_dict['valid'])},"
+                f"test: {len(self.file_dict['test'])} files>")
+
+    def file_filter(self, files, max_length):
+        """keep files with len(data) >= max_length (data.py:33-40); arrays stay cached in RAM"""
+        kept = []
+        for fname in files:
+            arr, n = _load_array(fname, self.field)
+            if arr is not None and max_length <= n:
+                self._cache[fname] = arr
+                kept.append(fname)
+        return kept
+
+    def _get_seq(self, fname, max_length=None):
+        """random crop of max_length events (data.py:96-107); IndexError when the file is too short"""
+        data = self._cache.get(fname)
+        if data is None:
+            data, _ = _load_array(fname, self.field)
+            self._cache[fname] = data
+        if max_length is not None:
+            if max_length <= len(data):
+                start = self._rng.randrange(0, len(data) - max_length)
+                data = data[start:start + max_length]
+            else:
+                raise IndexError
+        return data
+
+    def batch(self, batch_size, length, mode='train'):
+        batch_files = self._rng.sample(self.file_dict[mode], k=batch_size)
+        batch_data = [self._get_seq(file, length) for file in batch_files]
+        return np.array(batch_data, dtype=np.int16)
+
+    def seq2seq_batch(self, batch_size, length, mode='train'):
+        data = self.batch(batch_size, length * 2, mode)
+        return data[:, :length], data[:, length:]
+
+    def smallest_encoder_batch(self, batch_size, length, mode='train'):
+        data = self.batch(batch_size, length * 2, mode)
+        return data[:, :length // 100], data[:, length // 100:length // 100 + length]
+
+    def slide_seq2seq_batch(self, batch_size, length, mode='train'):
+        data = self.batch(batch_size, length + 1, mode)
+        return data[:, :-1], data[:, 1:]

@@ -1,0 +1,71 @@
+"""Drop-in for mg/model/MusicTransformer/generate.py:18-123: load a checkpoint, print a 2-sample test
+loss/accuracy, sample ``--max-length`` events from a prior and write them out.
+MIDI output needs pretty_midi (optional); without it the event-index arrays are saved as .npy."""
+from __future__ import annotations
+
+import optparse
+import os
+
+import numpy as np
+import torch
+
+from . import config, utils
+from .criterion import SmoothCrossEntropyLoss
+from .data import Data
+from .metrics import CategoricalAccuracy, LogitsBucketting, MetricsSet
+from .network import MusicTransformer
+from .train import vocab_of
+
+
+def get_options(argv=None):
+    parser = optparse.OptionParser()
+    parser.add_option('-b', '--batch-size', dest='batch_size', type='int', default=8)
+    parser.add_option('-s', '--load_path', dest='load_path', type='string', default=None)
+    parser.add_option('-o', '--output-dir', dest='output_dir', type='string', default='./output/generate/')
+    parser.add_option('-d', '--dataset', dest='data_path', type='string', default=config.pickle_dir)
+    parser.add_option('-l', '--max-length', dest='max_len', type='int', default=config.length)
+    parser.add_option('-T', '--temperature', dest='temperature', type='float', default=1.0)
+    parser.add_option('--top-k', dest='top_k', type='int', default=0)
+    parser.add_option('--top-p', dest='top_p', type='float', default=1.0)
+    parser.add_option('--num-layers', dest='num_layers', type='int', default=config.num_layers)
+    parser.add_option('--d-model', dest='d_model', type='int', default=config.embedding_dim)
+    parser.add_option('--repr', dest='repr', type='string', default='midi_like')
+    parser.add_option('-M', '--max_seq', dest='max_seq', type='int', default=config.max_seq)
+    return parser.parse_args(argv)[0]
+
+
+def main(argv=None):
+    o = get_options(argv)
+    device = torch.device('cuda:0')
+    vocab = vocab_of(o.repr)
+    mt = MusicTransformer(embedding_dim=o.d_model, vocab_size=vocab, num_layer=o.num_layers, max_seq=o.max_seq,
+                          dropout=0)
+    if o.load_path:
+        mt.load_state_dict(torch.load(o.load_path, map_location='cpu', weights_only=False)['net'])
+    mt.to(device).eval()
+    if o.data_path and os.path.isdir(o.data_path):
+        ds = Data(o.data_path, o.max_seq)
+        if len(ds.file_dict['test']) >= 2:
+            ms = MetricsSet({'accuracy': CategoricalAccuracy(), 'loss': SmoothCrossEntropyLoss(config.label_smooth, vocab, vocab - 1),
+                             'bucket': LogitsBucketting(vocab)})
+            x, y = ds.slide_seq2seq_batch(2, o.max_seq, 'test')
+            with torch.no_grad():
+                pred, _ = mt(torch.from_numpy(x).to(device, dtype=torch.int))
+                m = ms(pred, torch.from_numpy(y).to(device, dtype=torch.int))
+            print('Test >>>> Loss: {:6.6}, Accuracy: {}'.format(m['loss'], m['accuracy']))
+    mt.test()
+    prior = torch.tensor([[24, 28, 31]] * o.batch_size, dtype=torch.long, device=device)
+    res = mt.generate(prior, o.max_len, temperature=o.temperature, top_k=o.top_k, top_p=o.top_p).cpu().numpy()
+    os.makedirs(o.output_dir, exist_ok=True)
+    for i, seq in enumerate(res):
+        name = os.path.join(o.output_dir, f'gen-{i:03d}')
+        try:
+            n = utils.event_indeces_to_midi_file(seq, name + '.mid')
+            print('===> {} ({} notes)'.format(name + '.mid', n))
+        except ImportError:
+            np.save(name + '.npy', seq.astype(np.uint16))
+            print('===> {} (pretty_midi absent: event indices saved)'.format(name + '.npy'))
+
+
+if __name__ == '__main__':
+    main()

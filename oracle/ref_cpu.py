@@ -22,6 +22,20 @@ import torch.nn.functional as F
 
 Params = Dict[str, torch.Tensor]
 
+# bf16 emulation: when True, every tensor the MI355X path stores in bf16 (GEMM weights, E, the
+# embedding/LN/GEMM/attention outputs and the attention probabilities) is rounded to bf16 at the
+# same point, with fp32 arithmetic in between -- i.e. the oracle computes what the kernels compute
+# up to accumulation order.  The fp32 reference semantics are EMULATE_BF16 = False (default).
+EMULATE_BF16 = False
+
+
+def _r(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32) if EMULATE_BF16 else t
+
+
+def _lin(x, w, b):
+    return _r(F.linear(x, _r(w), b))
+
 
 # --------------------------------------------------------------------------------------
 # masks / positional table
@@ -74,11 +88,11 @@ def attn_core(qkv: torch.Tensor, E: torch.Tensor, mask: Optional[torch.Tensor], 
         return t.reshape(B, L, h, dh).permute(0, 2, 1, 3)
 
     q, k, v = heads(qkv[..., :d]), heads(qkv[..., d:2 * d]), heads(qkv[..., 2 * d:])
-    logits = (q @ k.transpose(-1, -2) + srel_from_qe(q, E, L)) / math.sqrt(dh)
+    logits = (q @ k.transpose(-1, -2) + srel_from_qe(q, _r(E), L)) / math.sqrt(dh)
     if mask is not None:
         logits = logits + (mask.to(torch.int64) * -1e9).to(logits.dtype)
     w = torch.softmax(logits, -1)
-    return (w @ v).permute(0, 2, 1, 3).reshape(B, L, d), w, logits
+    return _r((w @ v).permute(0, 2, 1, 3).reshape(B, L, d)), w, logits
 
 
 def rga_forward(p: Params, prefix: str, x: torch.Tensor, mask: Optional[torch.Tensor], h: int
@@ -91,16 +105,16 @@ def rga_forward(p: Params, prefix: str, x: torch.Tensor, mask: Optional[torch.Te
     def heads(t):
         return t.reshape(B, L, h, dh).permute(0, 2, 1, 3)
 
-    q = heads(F.linear(x, p[prefix + "Wq.weight"], p[prefix + "Wq.bias"]))
-    k = heads(F.linear(x, p[prefix + "Wk.weight"], p[prefix + "Wk.bias"]))
-    v = heads(F.linear(x, p[prefix + "Wv.weight"], p[prefix + "Wv.bias"]))
-    srel = srel_from_qe(q, p[prefix + "E"], L)
+    q = heads(_lin(x, p[prefix + "Wq.weight"], p[prefix + "Wq.bias"]))
+    k = heads(_lin(x, p[prefix + "Wk.weight"], p[prefix + "Wk.bias"]))
+    v = heads(_lin(x, p[prefix + "Wv.weight"], p[prefix + "Wv.bias"]))
+    srel = srel_from_qe(q, _r(p[prefix + "E"]), L)
     logits = (q @ k.transpose(-1, -2) + srel) / math.sqrt(dh)
     if mask is not None:
         logits = logits + (mask.to(torch.int64) * -1e9).to(logits.dtype)   # layers.py:99-100
     w = torch.softmax(logits, -1)
-    ctx = (w @ v).permute(0, 2, 1, 3).reshape(B, L, d)
-    return F.linear(ctx, p[prefix + "fc.weight"], p[prefix + "fc.bias"]), w
+    ctx = _r((w @ v).permute(0, 2, 1, 3).reshape(B, L, d))
+    return _lin(ctx, p[prefix + "fc.weight"], p[prefix + "fc.bias"]), w
 
 
 # --------------------------------------------------------------------------------------
@@ -111,11 +125,11 @@ def encoder_layer(p: Params, pre: str, x: torch.Tensor, mask, h: int, rate: floa
     d = x.shape[-1]
     a, w = rga_forward(p, pre + "rga.", x, mask, h)
     a = F.dropout(a, rate, training)
-    o1 = F.layer_norm(a + x, (d,), p[pre + "layernorm1.weight"], p[pre + "layernorm1.bias"], 1e-6)
-    f = F.relu(F.linear(o1, p[pre + "FFN_pre.weight"], p[pre + "FFN_pre.bias"]))
-    f = F.linear(f, p[pre + "FFN_suf.weight"], p[pre + "FFN_suf.bias"])
+    o1 = _r(F.layer_norm(a + x, (d,), p[pre + "layernorm1.weight"], p[pre + "layernorm1.bias"], 1e-6))
+    f = F.relu(_lin(o1, p[pre + "FFN_pre.weight"], p[pre + "FFN_pre.bias"]))
+    f = _lin(f, p[pre + "FFN_suf.weight"], p[pre + "FFN_suf.bias"])
     f = F.dropout(f, rate, training)
-    o2 = F.layer_norm(o1 + f, (d,), p[pre + "layernorm2.weight"], p[pre + "layernorm2.bias"], 1e-6)
+    o2 = _r(F.layer_norm(o1 + f, (d,), p[pre + "layernorm2.weight"], p[pre + "layernorm2.bias"], 1e-6))
     return o2, w
 
 
@@ -133,7 +147,7 @@ def decoder_stack(p: Params, x: torch.Tensor, mask, rate: float = 0.0, training:
     h = d // 64                                             # layers.py:219
     L = x.shape[1]
     hcur = emb[x.long()] * math.sqrt(d)
-    hcur = hcur + sinusoid_table(L, d).to(hcur.dtype)[None]
+    hcur = _r(hcur + sinusoid_table(L, d).to(hcur.dtype)[None])
     hcur = F.dropout(hcur, rate, training)
     ws = []
     for li in range(num_layers_of(p)):
@@ -148,7 +162,7 @@ def model_forward(p: Params, x: torch.Tensor, pad: int, rate: float = 0.0, train
     causal=False restates generate()'s mask=None call (network.py:60-62)."""
     mask = look_ahead_mask(x, pad) if causal else None
     hcur, ws = decoder_stack(p, x, mask, rate, training)
-    return F.linear(hcur, p["fc.weight"], p["fc.bias"]), ws
+    return _lin(hcur, p["fc.weight"], p["fc.bias"]), ws
 
 
 # --------------------------------------------------------------------------------------

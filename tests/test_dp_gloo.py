@@ -1,0 +1,121 @@
+"""The N>1 path on CPU: world_size 2, gloo.  Checks the bucketed all-reduce (dp.DataParallel) --
+rank-0 broadcast of the flat parameter buffer, per-bucket sum all-reduce issued from the
+bucket-ready callbacks, no_sync() for accumulation micro-batches -- and the DP parity statement
+'2 ranks x batch B/2 == 1 rank x batch B' on the oracle model (mean-of-means, pad-free data)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class _Store:
+    """the FlatStore surface dp.py uses (param/grad flat buffers + buckets), on CPU tensors"""
+
+    def __init__(self, n, buckets):
+        self.param = torch.zeros(n)
+        self.grad = torch.zeros(n)
+        self.buckets = buckets
+        self.synced = 0
+
+    def sync_shadow(self, force=False):
+        self.synced += 1
+
+
+class _Model:
+    def __init__(self, st):
+        self._st = st
+        self._dp = None
+
+    def store(self):
+        return self._st
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from musicgeneration_amd.dp import DataParallel
+        from oracle import ref_cpu as R
+        torch.manual_seed(rank)                       # ranks start with DIFFERENT parameters
+        V, d, nl, L = 50, 64, 1, 16
+        p = R.init_params(V, d, nl, L, seed=rank)
+        names = list(p.keys())
+        sizes = [p[n].numel() for n in names]
+        offs = [sum(sizes[:i]) for i in range(len(names))]
+        n = sum(sizes)
+        half = len(names) // 2
+        buckets = [("a", 0, offs[half]), ("b", offs[half], n)]
+        st = _Store(n, buckets)
+        for nm, o, s in zip(names, offs, sizes):
+            st.param[o:o + s] = p[nm].flatten()
+        model = _Model(st)
+        dp = DataParallel(model)
+        assert dp.world == 2 and st.synced == 1     # broadcast + shadow refresh
+        views = {nm: st.param[o:o + s].view(p[nm].shape).requires_grad_(False) for nm, o, s in zip(names, offs, sizes)}
+        # after the broadcast both ranks hold rank 0's parameters
+        p0 = R.init_params(V, d, nl, L, seed=0)
+        for nm in names:
+            assert torch.equal(views[nm], p0[nm])
+
+        # local gradients of this rank's half of the global batch
+        gen = torch.Generator().manual_seed(7)
+        xf = torch.randint(0, V - 1, (4, L + 1), generator=gen)        # global batch of 4, pad-free
+        mine = xf[2 * rank: 2 * rank + 2]
+
+        def grads(batch):
+            pr = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+            lg, _ = R.model_forward(pr, batch[:, :-1], V - 1)
+            R.smooth_ce(lg, batch[:, 1:], 0.1, V, V - 1).backward()
+            return torch.cat([pr[nm].grad.flatten() for nm in names])
+
+        # accumulation micro-batch: no_sync() must NOT reduce
+        with dp.no_sync():
+            st.grad.copy_(grads(mine))
+            dp.bucket_ready("b"); dp.bucket_ready("a")
+            dp.wait_all()
+        assert torch.equal(st.grad, grads(mine))
+        # last micro-batch: buckets reduced in backward order, then scaled by 1/world in the optimiser
+        dp.bucket_ready("b")
+        dp.bucket_ready("a")
+        dp.wait_all()
+        avg = st.grad * dp.grad_scale
+        ref = grads(xf)                                   # 1 rank x global batch
+        err = (avg - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-5, err
+        assert dp.bytes_reduced == 4 * n
+        with pytest.raises(KeyError):
+            dp.bucket_ready("nope")
+        m = dp.all_reduce_scalar_mean(torch.tensor(float(rank)))
+        assert abs(m.item() - 0.5) < 1e-7
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

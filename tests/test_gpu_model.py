@@ -57,9 +57,21 @@ def test_g2_logits_loss_grads(golden_dir):
     assert (gap[mism] <= 6e-2 * ref.abs().max().item()).all() and mism.float().mean() < 0.1
     m["loss"].backward()
     torch.cuda.synchronize()
-    st = mt.store()
+    # (a) vs the fp32 reference (golden): bf16 tolerance.  Per-token quantities (the embedding rows)
+    #     see un-averaged bf16 activation rounding, so their bound is looser.
+    # (b) vs the oracle with bf16 rounding emulated at the kernels' storage points: tight.
+    from oracle import ref_cpu as R
+    R.EMULATE_BF16 = True
+    try:
+        pr = {k[2:]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith("p.")}
+        emu_logits, _ = R.model_forward(pr, torch.from_numpy(g["x"]), V - 1)
+        R.smooth_ce(emu_logits, torch.from_numpy(g["y"]), 0.1, V, V - 1).backward()
+    finally:
+        R.EMULATE_BF16 = False
+    assert (logits.float().cpu() - emu_logits.detach()).abs().max().item() <= 2 * 2 ** -8 * ref.abs().max().item()
     for name, p in mt.named_parameters():
         ref_g = torch.from_numpy(g["g." + name])
+        emu_g = pr[name].grad
         got = p.grad.cpu()
         assert got.shape == ref_g.shape
         small = ref_g.numel() <= 1024
@@ -69,9 +81,12 @@ def test_g2_logits_loss_grads(golden_dir):
             wq = torch.from_numpy(g["g." + name.replace("Wk", "Wq")])
             assert got.abs().max().item() <= 2e-2 * wq.abs().max().item()
             continue
+        per_token = name == "Decoder.embedding.weight"
         c, r = _cos(got, ref_g), _rel(got, ref_g)
-        assert c > (0.99 if small else 0.999), f"{name}: cos {c}"
-        assert r < (1e-1 if small else 3e-2), f"{name}: rel {r}"
+        assert c > (0.98 if per_token else 0.99 if small else 0.999), f"{name}: cos vs fp32 {c}"
+        assert r < (2e-1 if per_token else 1e-1 if small else 3e-2), f"{name}: rel vs fp32 {r}"
+        c2 = _cos(got, emu_g)
+        assert c2 > (0.995 if small else 0.999), f"{name}: cos vs bf16-emulated oracle {c2}"
     # eval convention: (logits, weights-list)
     mt.eval()
     with torch.no_grad():
