@@ -119,6 +119,17 @@ int mgx_cast_bf16(const float* p, uint16_t* shadow, size_t n, void* stream);
 int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C,
                    int M, int N, int K, int act, void* stream);
 
+/* backward of the above (autograd of the same reference lines):
+ * dX bf16 [M,K] = dY bf16 [M,N] @ W bf16 [N,K]; if relu_y (bf16 [M,K]) is given, dX is zeroed where
+ * relu_y <= 0 (the backward of a ReLU fused into the producer of this layer's input).
+ * N % 8 == 0, K % 8 == 0.                                                                         */
+int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y, uint16_t* dX,
+                  int M, int N, int K, void* stream);
+/* gW f32 [N,K] += dY^T @ X (dY bf16 [M,N], X bf16 [M,K]); gb f32 [N] += column sums of dY (or NULL).
+ * Both ACCUMULATE (fp32 atomics), so gradient accumulation over micro-batches needs no extra pass. */
+int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, float* gb,
+                  int M, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

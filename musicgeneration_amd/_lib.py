@@ -28,6 +28,8 @@ SIGNATURES = {
     "mgx_adam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp],
     "mgx_cast_bf16": [_vp, _vp, _sz, _vp],
     "mgx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_linear_dx": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mgx_linear_dw": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }
 
 _lib = None

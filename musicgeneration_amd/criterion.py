@@ -7,6 +7,16 @@ from torch.nn.modules.loss import _Loss
 from . import ops
 
 
+def _rows_with_stride(x: torch.Tensor) -> torch.Tensor:
+    """The model returns logits as a [B,L,V] view of a [B,L,Vp] buffer (vocabulary rows padded to the GEMM
+    tile).  The kernels take a row stride, so hand them the padded base tensor instead of copying."""
+    b = x._base
+    if (b is not None and b.is_contiguous() and b.dim() == x.dim() and b.shape[:-1] == x.shape[:-1]
+            and b.data_ptr() == x.data_ptr() and x.stride(-1) == 1 and b.dtype == x.dtype):
+        return b
+    return x.contiguous()
+
+
 class SmoothCrossEntropyLoss(_Loss):
     """criterion.py:28-67.  ``forward(input [.., V] logits, target [..])`` -> scalar mean over
     non-``ignore_index`` targets of -sum q' log softmax, q' = (1-eps) onehot + eps/V.
@@ -25,7 +35,7 @@ class SmoothCrossEntropyLoss(_Loss):
         """-> (loss, stats f32[4] = [loss_sum, n_nonpad, n_correct, n_rows], argmax int32[rows])"""
         if input.dtype != torch.bfloat16:
             input = input.to(torch.bfloat16)
-        return ops.smooth_ce(input.contiguous(), target.to(torch.int32).contiguous(), self.vocab_size,
+        return ops.smooth_ce(_rows_with_stride(input), target.to(torch.int32).contiguous(), self.vocab_size,
                              self.label_smoothing, self.ignore_index)
 
     def forward(self, input, target):

@@ -1,21 +1,58 @@
-// C = act(A @ W^T + bias): the projection / FFN / vocabulary GEMMs of the hot path
-// (layers.py:71-84,108,157-158; network.py:39).  A [M,K] and W [N,K] are both K-contiguous, so both
-// MFMA operands are plain 16-byte row fragments (no transposed reads).
+// Projection / FFN / vocabulary GEMMs of the hot path (layers.py:71-84,108,157-158; network.py:39)
+// and their backward, all on v_mfma_f32_32x32x16_bf16 with 128 x 128 output tiles, 4 waves (2 x 2),
+// each wave 64 x 64 = 2 x 2 MFMA tiles, XOR-swizzled LDS images, register-staged prefetch of the next
+// reduction tile while the current one is multiplied (one barrier per tile), XCD-aware tile order.
 //
-// Tile 128 x 128 x 64, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA 32x32x16 tiles per k-step.
-// LDS: two 16 KiB images per buffer, double buffered (64 KiB -> 2 workgroups / CU), XOR-swizzled
-// 16-byte chunks (conflict-free ds_read_b128), register-staged prefetch of the next K tile while the
-// current one is multiplied (one barrier per K tile).
+//   forward  C  = act(A W^T + b)   "NT": A [M,K], W [N,K] both K-contiguous -> plain row fragments
+//   dX       dX = dY W (o relu')   "NN": dY [M,N] row fragments; W [N,K] is read as [k=n][col] through
+//                                        ds_read_b64_tr_b16 on a row-major LDS image (no W^T copy)
+//   dW       gW += dY^T X          "TN": both operands have the reduction index (rows m) outermost:
+//                                        both fragments come from transposed LDS reads; the M range is
+//                                        split over workgroups and partial tiles are added with fp32
+//                                        atomics (128-byte row segments) straight into the flat grad
+//                                        buffer -- gradient accumulation across micro-batches for free.
+//   colsum   gb += column sums of dY (bias gradients).
 #include "rel_attn_common.hpp"
 
 using namespace relattn;
 
 namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int IMG = BM * BK * 2;             // 16 KiB
-constexpr int LDS_BYTES = 4 * IMG;           // A0 W0 A1 W1
+constexpr int IMG = BM * BK * 2;             // 16 KiB: 128 rows x 64 k (image R)  or  4 sub-tiles of 32 x 64 (image T)
+constexpr int LDS_BYTES = 4 * IMG;           // two operands, double buffered = 64 KiB -> 2 workgroups / CU
+
+MGX_DEV int xcd_remap(int bid, int nwg) {    // bijective: one XCD walks a contiguous run of tiles
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// natural-k transposed fragment (see rel_attn_bwd.hip): X[16*ks + 8*hh + j][32*ct + (lane&31)]
+MGX_DEV bf16x8 fragTn(const char* tile, int lane, int ks, int ct) {
+    const int i = lane & 15, g = lane >> 4, hh = lane >> 5;
+    const int rq = i >> 2;
+    const int chunk = 4 * ct + 2 * (g & 1) + ((i & 3) >> 1);
+    const int byte_in = 8 * (i & 1);
+    bf16x8 out;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int row = 16 * ks + 8 * hh + 4 * jq + rq;
+        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + imgT_off(row, chunk) + byte_in));
+        out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
+    }
+    return out;
+}
+
+MGX_DEV void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+}
 }  // namespace
 
+// =================================================================================================
+// forward (NT)
+// =================================================================================================
 __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __restrict__ A,
                                                             const uint16_t* __restrict__ W,
                                                             const float* __restrict__ bias,
@@ -25,16 +62,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __re
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int l31 = lane & 31, hh = lane >> 5;
-    // XCD-aware tile order: consecutive blocks (which share an XCD's L2 only every 8th) are remapped so
-    // that one XCD walks a contiguous run of row-tiles for the same column tile (A panel reuse in L2).
-    const int ntn = (N + BN - 1) / BN;
-    const int ntm = (M + BM - 1) / BM;
-    const int nwg = ntm * ntn;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective remap
-    }
+    const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, ntm * ntn);
     const int tn = bid % ntn, tm = bid / ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -59,13 +88,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __re
             *(u32x4*)(wt + imgR_off(row, sch)) = wreg[i];
         }
     };
-
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-
+    zero_acc(acc);
     const int nk = K / BK;
     load_tiles(0);
     store_tiles(0);
@@ -110,20 +134,265 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __re
     }
 }
 
+// =================================================================================================
+// dX = dY W   (NN; optional epilogue mask: dX *= (relu_y > 0), the backward of a fused ReLU)
+//   tile: 128 rows m x 128 cols k', reduction over n in steps of 64
+//   LDS:  dY tile [128 m][64 n] image R;  W tile [64 n][128 k'] as 4 sub-tiles (2 n-blocks x 2 col halves)
+//         of [32][64] image T
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __restrict__ dY,
+                                                           const uint16_t* __restrict__ W,
+                                                           const uint16_t* __restrict__ relu_y,
+                                                           uint16_t* __restrict__ dX, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ntk = (K + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, ntm * ntk);
+    const int tk = bid % ntk, tm = bid / ntk;
+    const int m0 = tm * BM, k0 = tk * BN;
+
+    // staging: dY tile as in the forward (row = srow + 32 i, 16-byte chunk sch of 64 n);
+    //          W tile: 64 rows n x 256 B; thread -> (n row = tid >> 2 [0..63], chunks 4*(tid&3) .. +3 of 16)
+    const int srow = tid >> 3, sch = tid & 7;
+    const int wrow = tid >> 2, wc0 = (tid & 3) * 4;
+    u32x4 areg[4], wreg[4];
+    auto load_tiles = [&](int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + srow + 32 * i;
+            const int gn = n0 + sch * 8;                                  // N % 8 == 0 (host-checked)
+            areg[i] = (gm < M && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
+            const int wn_ = n0 + wrow, wk = k0 + (wc0 + i) * 8;
+            wreg[i] = (wn_ < N && wk < K) ? *(const u32x4*)(W + (size_t)wn_ * K + wk) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* at = smem + buf * 2 * IMG;
+        char* wt = at + IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)(at + imgR_off(srow + 32 * i, sch)) = areg[i];
+            const int ch = wc0 + i;                                       // 16-byte chunk 0..15 of the 128 columns
+            const int sub = (wrow >> 5) * 2 + (ch >> 3);                  // (n block, column half)
+            *(u32x4*)(wt + sub * TILE_BYTES + imgT_off(wrow & 31, ch & 7)) = wreg[i];
+        }
+    };
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int nn = (N + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int nt = 0; nt < nn; ++nt) {
+        const int cur = nt & 1;
+        if (nt + 1 < nn) load_tiles((nt + 1) * BK);
+        const char* at = smem + cur * 2 * IMG;
+        const char* wt = at + IMG;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 a0 = frag_R(at, 64 * wm + l31, hh, ks);
+            const bf16x8 a1 = frag_R(at, 64 * wm + 32 + l31, hh, ks);
+            const char* sub = wt + ((ks >> 1) * 2 + wn) * TILE_BYTES;
+            const bf16x8 b0 = fragTn(sub, lane, ks & 1, 0);
+            const bf16x8 b1 = fragTn(sub, lane, ks & 1, 1);
+            acc[0][0] = mfma(a0, b0, acc[0][0]);
+            acc[0][1] = mfma(a0, b1, acc[0][1]);
+            acc[1][0] = mfma(a1, b0, acc[1][0]);
+            acc[1][1] = mfma(a1, b1, acc[1][1]);
+        }
+        if (nt + 1 < nn) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int k = k0 + 64 * wn + 32 * ct + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 64 * wm + 32 * rt + crow(r, hh);
+                if (m < M) {
+                    float v = acc[rt][ct][r];
+                    if (relu_y && !(bf16_to_f32(relu_y[(size_t)m * K + k]) > 0.f)) v = 0.f;
+                    dX[(size_t)m * K + k] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// gW[N,K] += dY^T X   (TN), M split over gridDim.y workgroups; partial tiles added with fp32 atomics
+//   tile: 128 rows n x 128 cols k, reduction over m in steps of 64
+//   LDS:  dY tile [64 m][128 n] and X tile [64 m][128 k], each as 4 sub-tiles [32][64] image T
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __restrict__ dY,
+                                                           const uint16_t* __restrict__ X,
+                                                           float* __restrict__ gW, int M, int N, int K, int mchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ntk = (K + BN - 1) / BN;
+    const int tk = blockIdx.x % ntk, tn = blockIdx.x / ntk;
+    const int n0 = tn * BM, k0 = tk * BN;
+    const int mbeg = blockIdx.y * mchunk, mend = min(M, mbeg + mchunk);
+
+    const int wrow = tid >> 2, wc0 = (tid & 3) * 4;      // 64 rows m x 16 chunks
+    u32x4 areg[4], breg[4];
+    auto load_tiles = [&](int mm) {
+        const int gm = mm + wrow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gn = n0 + (wc0 + i) * 8, gk = k0 + (wc0 + i) * 8;
+            areg[i] = (gm < mend && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
+            breg[i] = (gm < mend && gk < K) ? *(const u32x4*)(X + (size_t)gm * K + gk) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* at = smem + buf * 2 * IMG;
+        char* bt = at + IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = wc0 + i;
+            const int off = ((wrow >> 5) * 2 + (ch >> 3)) * TILE_BYTES + imgT_off(wrow & 31, ch & 7);
+            *(u32x4*)(at + off) = areg[i];
+            *(u32x4*)(bt + off) = breg[i];
+        }
+    };
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int nm = (mend - mbeg + BK - 1) / BK;
+    if (nm > 0) {
+        load_tiles(mbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int mt = 0; mt < nm; ++mt) {
+        const int cur = mt & 1;
+        if (mt + 1 < nm) load_tiles(mbeg + (mt + 1) * BK);
+        const char* at = smem + cur * 2 * IMG;
+        const char* bt = at + IMG;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const char* asub = at + ((ks >> 1) * 2 + wm) * TILE_BYTES;
+            const char* bsub = bt + ((ks >> 1) * 2 + wn) * TILE_BYTES;
+            const bf16x8 a0 = fragTn(asub, lane, ks & 1, 0);
+            const bf16x8 a1 = fragTn(asub, lane, ks & 1, 1);
+            const bf16x8 b0 = fragTn(bsub, lane, ks & 1, 0);
+            const bf16x8 b1 = fragTn(bsub, lane, ks & 1, 1);
+            acc[0][0] = mfma(a0, b0, acc[0][0]);
+            acc[0][1] = mfma(a0, b1, acc[0][1]);
+            acc[1][0] = mfma(a1, b0, acc[1][0]);
+            acc[1][1] = mfma(a1, b1, acc[1][1]);
+        }
+        if (mt + 1 < nm) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+    // D[n][k]: k on the lane -> one register = two 128-byte row segments per wave-instruction
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int k = k0 + 64 * wn + 32 * ct + l31;
+        if (k >= K) continue;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 64 * wm + 32 * rt + crow(r, hh);
+                if (n < N) atomicAdd(gW + (size_t)n * K + k, acc[rt][ct][r]);
+            }
+        }
+    }
+}
+
+// gb[n] += sum_m dY[m][n]      thread = 8 columns, rows strided over gridDim.y * 32 row-lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ dY, float* __restrict__ gb, int M,
+                                                     int N) {
+    const int cg = blockIdx.x * 8 + (threadIdx.x & 7);            // column group (8 columns)
+    const int rl = threadIdx.x >> 3;                              // 0..31
+    __shared__ float red[32][8][8];
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cg * 8 < N) {
+        for (int m = blockIdx.y * 32 + rl; m < M; m += gridDim.y * 32) {
+            float f[8];
+            unpack8(*(const u32x4*)(dY + (size_t)m * N + cg * 8), f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += f[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl][threadIdx.x & 7][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c8 = threadIdx.x >> 3, k = threadIdx.x & 7;
+        float t = 0.f;
+        for (int r = 0; r < 32; ++r) t += red[r][c8][k];
+        const int col = (blockIdx.x * 8 + c8) * 8 + k;
+        if (col < N) atomicAdd(gb + col, t);
+    }
+}
+
+// =================================================================================================
+static bool g_attr_set = false;
+static void set_attrs() {
+    if (g_attr_set) return;
+    hipFuncSetAttribute((const void*)linear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    g_attr_set = true;
+}
+
 extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C, int M, int N,
                               int K, int act, void* stream) {
     MGX_REQUIRE(A && W && C, MGX_ERR_NULL, "mgx_linear_fwd: NULL pointer");
     MGX_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, MGX_ERR_SHAPE,
                 "mgx_linear_fwd: need K%%64==0 (got M=%d N=%d K=%d)", M, N, K);
     MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)linear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    set_attrs();
     const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL(linear_fwd_kernel, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, A, W, bias, C, M, N,
                        K, act);
     MGX_CHECK_LAUNCH("mgx_linear_fwd");
+    return MGX_OK;
+}
+
+extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y, uint16_t* dX, int M, int N,
+                             int K, void* stream) {
+    MGX_REQUIRE(dY && W && dX, MGX_ERR_NULL, "mgx_linear_dx: NULL pointer");
+    MGX_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, MGX_ERR_SHAPE,
+                "mgx_linear_dx: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
+    set_attrs();
+    const int nwg = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
+    hipLaunchKernelGGL(linear_dx_kernel, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, W, relu_y, dX, M, N,
+                       K);
+    MGX_CHECK_LAUNCH("mgx_linear_dx");
+    return MGX_OK;
+}
+
+extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, float* gb, int M, int N, int K,
+                             void* stream) {
+    MGX_REQUIRE(dY && X && gW, MGX_ERR_NULL, "mgx_linear_dw: NULL pointer");
+    MGX_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, MGX_ERR_SHAPE,
+                "mgx_linear_dw: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
+    set_attrs();
+    const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+    // split M so that the grid has ~2 workgroups per CU; chunk is a multiple of 64 rows
+    int splits = (512 + tiles - 1) / tiles;
+    int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
+    if (mchunk < 64) mchunk = 64;
+    splits = (M + mchunk - 1) / mchunk;
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, M, N,
+                       K, mchunk);
+    if (gb) {
+        int ysplit = (M + 2047) / 2048;
+        if (ysplit < 1) ysplit = 1;
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, ysplit), dim3(256), 0, (hipStream_t)stream, dY, gb, M, N);
+    }
+    MGX_CHECK_LAUNCH("mgx_linear_dw");
     return MGX_OK;
 }

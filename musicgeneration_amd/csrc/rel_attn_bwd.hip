@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dq_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
-    const int b = blockIdx.y / heads, hd = blockIdx.y % heads;
-    const int qb = gridDim.x - 1 - blockIdx.x;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;   // x = (b,h) fast, y = heaviness rank slow
+    const int qb = gridDim.y - 1 - blockIdx.y;
     const int I0 = qb * 128, Q0 = I0 >> 5, i0 = I0 + w * 32;
     const int nchunk = L >> 5;
     const bool wave_on = i0 < L;
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bl = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
-    const int b = blockIdx.y / heads, hd = blockIdx.y % heads;
-    const int J0 = blockIdx.x * 128;                       // small J0 = longest sweep = launched first
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int J0 = blockIdx.y * 128;                       // small J0 = longest sweep = dispatched first
     const int j0 = J0 + w * 32;
     const int nchunk = L >> 5;
     const bool wave_on = j0 < L;
@@ -465,9 +465,9 @@ __global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bl = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
-    const int b = blockIdx.y / heads, hd = blockIdx.y % heads;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int nchunk = L >> 5;
-    const int C0 = blockIdx.x * 4;                         // small C0 = longest sweep = launched first
+    const int C0 = blockIdx.y * 4;                         // small C0 = longest sweep = dispatched first
     const int cw = C0 + w;
     const bool wave_on = cw < nchunk;
     const int nT = nchunk - C0;
@@ -629,7 +629,7 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     MGX_REQUIRE(qkv && E && ctx && dctx && lse && dqkv && dE && delta, MGX_ERR_NULL, "mgx_rel_attn_bwd: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
                 "mgx_rel_attn_bwd: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
-    MGX_REQUIRE((long)B * (d / 64) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: B*heads must be <= 65535");
+    MGX_REQUIRE((L + 127) / 128 <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L too large");
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
@@ -644,10 +644,10 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
         const long total = (long)B * L * heads * 8;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
     }
-    const dim3 gq((L + 127) / 128, B * heads);
+    const dim3 gq(B * heads, (L + 127) / 128);
     if (parts & 2) hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
     if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
-    const dim3 ge(((L >> 5) + 3) / 4, B * heads);
+    const dim3 ge(B * heads, ((L >> 5) + 3) / 4);
     if (parts & 8) hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(256), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
                        dE + (size_t)(M - L) * 64, L, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_bwd");

@@ -79,6 +79,31 @@ MGX_DEV f32x16 zero16() {
     return z;
 }
 
+// ---- rotated band (skew buffer) ---------------------------------------------------------------------
+// One band row per query a of the tile, 64 fp32 columns + 4 pad = 272 B (17 16-byte slots: the 16
+// lanes of a ds_read_b128 group land on 16 distinct slots).  Relative distance delta lives at column
+//     col(a, delta) = (a - delta) & 63.
+// * swapped orientation (keys on registers, queries on lanes): the 4 registers of group g4 hold keys
+//   b = 8*g4 + 4*hh + j, delta = D + a - b  =>  col = (b - D) & 63: four ascending, 16-byte aligned
+//   columns that never wrap => ONE ds_read_b128 at  a*272 + 16*hh + 32*g4 (+128 when D/32 is odd).
+// * natural orientation (queries on registers, keys on lanes): col = (bl - D) & 63 = bl (+32) =>
+//   ds_read_b32 at  a_r*272 + 4*bl (+128): one base register + immediates.
+// * QE[a_r][t] (t on lanes) of chunk q is written at col (a_r - t - 32q) & 63: per-lane wrap, so the 16
+//   byte offsets are precomputed once for even q (wa0) and odd q (wa1 = column ^ 32).
+constexpr int BAND_STRIDE = 272;
+constexpr int BAND_BYTES = 32 * BAND_STRIDE;   // 8,704 B per wave
+MGX_DEV int band_off(int row, int col) { return row * BAND_STRIDE + col * 4; }
+// store an accumulator tile through precomputed offsets; `odd` must be wave-uniform
+MGX_DEV void band_store(char* band, const int (&wa0)[16], const int (&wa1)[16], int odd, const f32x16& v) {
+    if (odd) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *(float*)(band + wa1[r]) = v[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *(float*)(band + wa0[r]) = v[r];
+    }
+}
+
 // order LDS traffic of one wave (same-wave DS ops execute in order; this only pins the compiler)
 MGX_DEV void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

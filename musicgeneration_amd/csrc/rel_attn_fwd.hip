@@ -25,8 +25,8 @@ constexpr int E_SLOTS = 6;
 constexpr int OFF_K = 0;                               // 2 x 4 KiB   image R
 constexpr int OFF_V = OFF_K + 2 * TILE_BYTES;          // 2 x 4 KiB   image T
 constexpr int OFF_E = OFF_V + 2 * TILE_BYTES;          // 6 x 4 KiB   image R, ring indexed by chunk % 6
-constexpr int OFF_BAND = OFF_E + E_SLOTS * TILE_BYTES; // 4 x (32 x 64 fp32) = 32 KiB
-constexpr int LDS_BYTES = OFF_BAND + WAVES * 32 * 64 * 4;   // 73,728 B -> 2 workgroups per CU
+constexpr int OFF_BAND = OFF_E + E_SLOTS * TILE_BYTES; // 4 x (32 rows x 272 B) fp32 rotated band
+constexpr int LDS_BYTES = OFF_BAND + WAVES * BAND_BYTES;    // 75,776 B -> 2 workgroups per CU
 }  // namespace
 
 __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
@@ -39,8 +39,10 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
-    const int b = blockIdx.y / heads, hd = blockIdx.y % heads;
-    const int qb = gridDim.x - 1 - blockIdx.x;           // heaviest (latest) query blocks first
+    // grid: x = (batch, head) [fast], y = query-block rank [slow], heaviest (latest) blocks first, so the
+    // whole grid is dispatched longest-job-first; blocks of one (b,h) share an XCD when B*h % 8 == 0.
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int qb = gridDim.y - 1 - blockIdx.y;
     const int I0 = qb * 128, Q0 = I0 >> 5;
     const int i0 = I0 + w * 32;
     const int nchunk = L >> 5;                           // number of 32-row chunks / key tiles
@@ -83,17 +85,25 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
     }
     __syncthreads();
 
-    char* band = smem + OFF_BAND + w * (32 * 64 * 4);
-    // the wave's first "hi" chunk (delta in [i0, i0+31]) -> band columns ((Q0+w)&1)*32 + t
+    char* band = smem + OFF_BAND + w * BAND_BYTES;
+    // loop-invariant band addresses (see rel_attn_common.hpp "rotated band"):
+    //   write of QE[a_r][t]: wa0[r] for an even chunk, wa1[r] for an odd one (wave-uniform choice)
+    //   read of the 4 registers of group g4:   rbase + 32*g4 (+128 when D/32 is odd)
+    int wa0[16], wa1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        wa0[r] = band_off(crow(r, hh), (crow(r, hh) - a) & 63);
+        wa1[r] = band_off(crow(r, hh), (crow(r, hh) - a - 32) & 63);
+    }
+    const int rbase = a * BAND_STRIDE + 16 * hh;
+    // the wave's first "hi" chunk (delta in [i0, i0+31])
     if (wave_on) {
         const int q = Q0 + w;
         const char* et = smem + OFF_E + (q % E_SLOTS) * TILE_BYTES;
         f32x16 qe = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
-        const int cb = (q & 1) * 32 + a;                 // column = chunk parity * 32 + t (t = lane&31)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+        band_store(band, wa0, wa1, q & 1, qe);
     }
 
     f32x16 o0 = zero16(), o1 = zero16();
@@ -114,7 +124,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
 
         const int dq = Q0 + w - s;                       // D/32 for this wave; active iff dq >= 0
         if (wave_on && dq >= 0) {
-            const int D = dq * 32;
             // ---- new chunk dq-1 (delta in [D-32, D-1]); nothing to do on the diagonal -----------
             if (dq >= 1) {
                 const int q = dq - 1;
@@ -122,16 +131,19 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
                 f32x16 qe = zero16();
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
-                const int cb = (q & 1) * 32 + a;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+                band_store(band, wa0, wa1, q & 1, qe);
             }
             wave_lds_fence();
             // ---- S^T = K Q^T + Srel^T ------------------------------------------------------------
             f32x16 c;
+            {
+                const char* rb = band + rbase + ((dq & 1) << 7);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                c[r] = *(const float*)(band + (a * 64 + ((D + a - crow(r, hh)) & 63)) * 4);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = *(const f32x4*)(rb + 32 * g4);
+                    c[4 * g4] = v.x; c[4 * g4 + 1] = v.y; c[4 * g4 + 2] = v.z; c[4 * g4 + 3] = v.w;
+                }
+            }
             const char* kt = smem + OFF_K + cur * TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
@@ -209,13 +221,13 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
     MGX_REQUIRE(qkv && E && ctx && lse, MGX_ERR_NULL, "mgx_rel_attn_fwd: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
                 "mgx_rel_attn_fwd: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
-    MGX_REQUIRE((long)B * (d / 64) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_fwd: B*heads must be <= 65535");
+    MGX_REQUIRE((L + 127) / 128 <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_fwd: L too large");
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)rel_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    dim3 grid((L + 127) / 128, B * (d / 64));
+    dim3 grid(B * (d / 64), (L + 127) / 128);
     hipLaunchKernelGGL(rel_attn_fwd_kernel, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
                        E + (size_t)(M - L) * 64, padbits, ctx, lse, L, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");

@@ -96,13 +96,21 @@ class EncoderLayer(torch.nn.Module):
 class FlatStore:
     """Flat fp32 parameter / gradient buffers + bf16 shadow for an ordered list of parameters."""
 
-    def __init__(self, named: List[Tuple[str, torch.nn.Parameter]], device, buckets: List[Tuple[str, List[str]]]):
+    def __init__(self, named: List[Tuple[str, torch.nn.Parameter]], device, buckets: List[Tuple[str, List[str]]],
+                 padded: Optional[Dict[str, int]] = None):
+        """``padded[name]`` = number of elements to reserve for ``name`` (>= numel): the tail stays zero in
+        every buffer (parameters, gradients, moments, shadow) -- used to pad the vocabulary projection to a
+        multiple of 64 rows so all GEMM dimensions are tile-aligned."""
         self.names = [n for n, _ in named]
         self.offsets: Dict[str, Tuple[int, int]] = {}
+        self.reserved: Dict[str, int] = {}
+        padded = padded or {}
         off = 0
         for n, p in named:
             self.offsets[n] = (off, p.numel())
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            res = max(p.numel(), padded.get(n, 0))
+            self.reserved[n] = res
+            off += (res + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
         self.param = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
@@ -119,7 +127,7 @@ class FlatStore:
         self.buckets: List[Tuple[str, int, int]] = []
         for bname, members in buckets:
             lo = min(self.offsets[m][0] for m in members)
-            hi = max(self.offsets[m][0] + (self.offsets[m][1] + ALIGN - 1) // ALIGN * ALIGN for m in members)
+            hi = max(self.offsets[m][0] + (self.reserved[m] + ALIGN - 1) // ALIGN * ALIGN for m in members)
             self.buckets.append((bname, lo, hi))
         self._synced_version = -1
         self.sync_shadow(force=True)
@@ -132,6 +140,15 @@ class FlatStore:
     def g(self, name):          # fp32 gradient view
         o, k = self.offsets[name]
         return self.grad[o:o + k].view(self.params[name].shape)
+
+    def padded_view(self, name, rows, cols=None, what="shadow"):
+        """view over the reserved (zero-padded) region of ``name`` as [rows, cols] (or [rows])"""
+        o = self.offsets[name][0]
+        buf = {"shadow": self.shadow, "grad": self.grad, "param": self.param}[what]
+        n = rows * (cols or 1)
+        assert n <= self.reserved[name]
+        v = buf[o:o + n]
+        return v.view(rows, cols) if cols else v
 
     def fused(self, first, last, rows, cols, what="shadow"):
         """one view over adjacent parameters first..last (e.g. Wq|Wk|Wv -> [3d, d])"""

@@ -9,7 +9,7 @@ from typing import Dict
 import torch
 
 from . import ops
-from .criterion import SmoothCrossEntropyLoss
+from .criterion import SmoothCrossEntropyLoss, _rows_with_stride
 
 
 class _Metric(torch.nn.Module):
@@ -31,7 +31,7 @@ class MockAccuracy(Accuracy):
 def _fused_stats(input, target):
     V = input.shape[-1]
     x = input if input.dtype == torch.bfloat16 else input.to(torch.bfloat16)
-    return ops.smooth_ce_fwd(x.contiguous(), target.to(torch.int32).contiguous(), V, 0.0, -1)
+    return ops.smooth_ce_fwd(_rows_with_stride(x), target.to(torch.int32).contiguous(), V, 0.0, -1)
 
 
 class CategoricalAccuracy(Accuracy):

@@ -35,6 +35,7 @@ class MusicTransformer(torch.nn.Module):
         # the reference reads the pad id from the global config module (network.py:37); the default
         # is the same rule (pad = last vocabulary id), overridable per model
         self.pad_token = vocab_size - 1
+        self.vocab_padded = (vocab_size + 63) // 64 * 64     # rows of the vocabulary GEMM (zero rows beyond V)
         self.Decoder = Encoder(num_layers=self.num_layer, d_model=self.embedding_dim,
                                input_vocab_size=self.vocab_size, rate=dropout, max_len=max_seq)
         self.fc = torch.nn.Linear(self.embedding_dim, self.vocab_size)
@@ -57,7 +58,8 @@ class MusicTransformer(torch.nn.Module):
         order += ["fc.weight", "fc.bias"]
         buckets.append(("fc", ["fc.weight", "fc.bias"]))
         assert set(order) == set(named), "flat order must cover every parameter exactly once"
-        return [(n, named[n]) for n in order], buckets
+        padded = {"fc.weight": self.vocab_padded * self.embedding_dim, "fc.bias": self.vocab_padded}
+        return [(n, named[n]) for n in order], buckets, padded
 
     def store(self) -> FlatStore:
         dev = self.fc.weight.device
@@ -65,8 +67,8 @@ class MusicTransformer(torch.nn.Module):
             if dev.type != "cuda":
                 raise ops._lib.MgxError("MusicTransformer runs on the MI355X kernels only: move it to a HIP "
                                         "device first (model.to('cuda')); there is no CPU fallback")
-            named, buckets = self._flat_order()
-            self._store = FlatStore(named, dev, buckets)
+            named, buckets, padded = self._flat_order()
+            self._store = FlatStore(named, dev, buckets, padded)
         return self._store
 
     def _apply(self, fn, *a, **k):     # .to()/.cuda() re-materialise parameters: rebuild lazily
@@ -117,12 +119,15 @@ class MusicTransformer(torch.nn.Module):
             f = ops.linear(o1, P[pre + "FFN_pre.weight"], st.w(pre + "FFN_pre.weight"), P[pre + "FFN_pre.bias"].data,
                            1, st.g(pre + "FFN_pre.weight"), st.g(pre + "FFN_pre.bias"))
             f = ops.linear(f, P[pre + "FFN_suf.weight"], st.w(pre + "FFN_suf.weight"), P[pre + "FFN_suf.bias"].data,
-                           0, st.g(pre + "FFN_suf.weight"), st.g(pre + "FFN_suf.bias"))
+                           0, st.g(pre + "FFN_suf.weight"), st.g(pre + "FFN_suf.bias"), None, True)
             h = ops.add_ln(f, o1, P[pre + "layernorm2.weight"].data, P[pre + "layernorm2.bias"].data, 1e-6, p,
                            seed + 4 * i + 2, st.g(pre + "layernorm2.weight"), st.g(pre + "layernorm2.bias"))
-        logits = ops.linear(h, P["fc.weight"], st.w("fc.weight"), P["fc.bias"].data, 0, st.g("fc.weight"),
-                            st.g("fc.bias"), done("fc"))
-        return logits
+        Vp = self.vocab_padded
+        logits = ops.linear(h, P["fc.weight"], st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param"),
+                            0, st.padded_view("fc.weight", Vp, d, "grad"), st.padded_view("fc.bias", Vp, None, "grad"),
+                            done("fc"))
+        # [B, L, Vp] storage, [B, L, V] view: columns >= V are exact zeros (zero weight rows, zero bias)
+        return logits[..., : self.vocab_size]
 
     def forward(self, x, length=None, writer=None):
         if self.training or not self.infer:

@@ -151,6 +151,24 @@ def linear_fwd(a, w, bias, act=0):
     return out
 
 
+def linear_dx(dy, w, relu_y=None):
+    """dy bf16 [..,N], w bf16 [N,K] -> dx bf16 [..,K] = dy @ w (zeroed where relu_y <= 0)"""
+    _need_cuda(dy, w, relu_y)
+    N, K = w.shape
+    Mrows = dy.numel() // N
+    dx = torch.empty(*dy.shape[:-1], K, dtype=BF16, device=dy.device)
+    check(_lib.load().mgx_linear_dx(ptr(dy), ptr(w), ptr(relu_y), ptr(dx), Mrows, N, K, stream_ptr()), "mgx_linear_dx")
+    return dx
+
+
+def linear_dw(dy, x, gw, gb=None):
+    """gw f32 [N,K] += dy^T @ x ; gb f32 [N] += colsum(dy)"""
+    _need_cuda(dy, x, gw, gb)
+    N, K = gw.shape
+    Mrows = dy.numel() // N
+    check(_lib.load().mgx_linear_dw(ptr(dy), ptr(x), ptr(gw), ptr(gb), Mrows, N, K, stream_ptr()), "mgx_linear_dw")
+
+
 # --------------------------------------------------------------------------------------------------
 # autograd glue
 #
@@ -159,23 +177,6 @@ def linear_fwd(a, w, bias, act=0):
 # the model's flat gradient buffer (``g*`` arguments).  ``done`` is an optional callable invoked at
 # the end of backward (the data-parallel bucket hook, see dp.py).
 # --------------------------------------------------------------------------------------------------
-_MM_OUT_DTYPE = None
-
-
-def _mm_f32(a, b):
-    """a,b bf16 -> a @ b in fp32 (library GEMM; interim until the TN kernel lands in libmgx)."""
-    global _MM_OUT_DTYPE
-    if _MM_OUT_DTYPE is None:
-        try:
-            torch.mm(a[:1], b[:, :1], out_dtype=torch.float32)
-            _MM_OUT_DTYPE = True
-        except Exception:
-            _MM_OUT_DTYPE = False
-    if _MM_OUT_DTYPE:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    return torch.mm(a, b).float()
-
-
 class _EmbedPE(torch.autograd.Function):
     """K1: dropout(emb[x]*sqrt(d) + PE)                       layers.py:226-229"""
 
@@ -232,32 +233,29 @@ class _AddLN(torch.autograd.Function):
 
 
 class _Linear(torch.autograd.Function):
-    """K2/K5/K7/K8: y = act(x @ W^T + b).  Forward: libmgx MFMA GEMM with fused bias/ReLU epilogue.
-    Backward: dx = dy @ W, dW += dy^T @ x (fp32), db += colsum(dy)."""
+    """K2/K5/K7/K8: y = act(x @ W^T + b) and its backward, all libmgx MFMA kernels:
+    forward NT GEMM with fused bias/ReLU; dx = dy @ W (NN, transposed LDS reads); dW += dy^T @ x and
+    db += colsum(dy) accumulate in fp32 straight into the flat gradient buffer (TN, split-M atomics).
+    ``x_is_relu``: x is the output of a fused-ReLU layer, so dx is masked by (x > 0) in the dX
+    epilogue -- that producer (act=1) then receives an already-masked gradient."""
 
     @staticmethod
-    def forward(ctx, x, w_master, w_shadow, bias, act, gw, gb, done):
+    def forward(ctx, x, w_master, w_shadow, bias, act, gw, gb, done, x_is_relu):
         y = linear_fwd(x, w_shadow, bias, act)
-        ctx.save_for_backward(x, w_shadow, y if act else None)
-        ctx.cfg = (act, gw, gb, done)
+        ctx.save_for_backward(x, w_shadow)
+        ctx.cfg = (gw, gb, done, x_is_relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w_shadow, y = ctx.saved_tensors
-        act, gw, gb, done = ctx.cfg
-        if act:
-            dy = torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
-        N, K = w_shadow.shape
-        dy2 = dy.reshape(-1, N)
-        x2 = x.reshape(-1, K)
-        dx = torch.mm(dy2, w_shadow).view(x.shape)
-        gw.add_(_mm_f32(dy2.t(), x2))
-        if gb is not None:
-            gb.add_(dy2.sum(0, dtype=torch.float32))
+        x, w_shadow = ctx.saved_tensors
+        gw, gb, done, x_is_relu = ctx.cfg
+        dy = dy.contiguous()
+        dx = linear_dx(dy, w_shadow, x if x_is_relu else None)
+        linear_dw(dy, x, gw, gb)
         if done is not None:
             done()
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
 class _SmoothCE(torch.autograd.Function):
@@ -294,8 +292,8 @@ def add_ln(x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta):
     return _AddLN.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed), ggamma, gbeta)
 
 
-def linear(x, w_master, w_shadow, bias, act, gw, gb, done=None):
-    return _Linear.apply(x, w_master, w_shadow, bias, int(act), gw, gb, done)
+def linear(x, w_master, w_shadow, bias, act, gw, gb, done=None, x_is_relu=False):
+    return _Linear.apply(x, w_master, w_shadow, bias, int(act), gw, gb, done, bool(x_is_relu))
 
 
 def smooth_ce(logits, target, V, eps_ls, pad):

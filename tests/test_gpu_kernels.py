@@ -301,3 +301,34 @@ def test_linear_fwd(M, N, K, act):
     assert err <= 2 ** -7 * ref.abs().max().item() + 1e-3, err
     out2 = ops.linear_fwd(a.to(dev), w.to(dev), None, 0)
     assert _relerr(out2.cpu(), a.float() @ w.float().t()) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(128, 128, 128, 0), (300, 384, 512, 0), (1000, 1536, 512, 0),
+                                         (257, 512, 256, 1), (2048, 256, 512, 0), (96, 64, 64, 1)])
+def test_linear_backward_kernels(M, N, K, relu):
+    """dX = dY W (optionally masked by relu(x) > 0) and gW += dY^T X, gb += colsum(dY)."""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3 * M + N + K)
+    dy = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    if relu:
+        x = torch.relu(x)
+    ref_dx = dy.float() @ w.float()
+    if relu:
+        ref_dx = ref_dx * (x.float() > 0)
+    dx = ops.linear_dx(dy.to(dev), w.to(dev), x.to(dev) if relu else None)
+    torch.cuda.synchronize()
+    assert _relerr(dx.cpu(), ref_dx) < 5e-3
+    assert (dx.float().cpu() - ref_dx).abs().max().item() <= 2 ** -7 * ref_dx.abs().max().item() + 1e-3
+    gw0 = torch.randn(N, K, generator=g)
+    gb0 = torch.randn(N, generator=g)
+    gw, gb = gw0.clone().to(dev), gb0.clone().to(dev)
+    ops.linear_dw(dy.to(dev), x.to(dev), gw, gb)
+    ops.linear_dw(dy.to(dev), x.to(dev), gw, None)            # accumulates: called twice -> 2x
+    torch.cuda.synchronize()
+    ref_gw = gw0 + 2 * (dy.float().t() @ x.float())
+    ref_gb = gb0 + dy.float().sum(0)
+    assert _relerr(gw.cpu(), ref_gw) < 1e-4
+    assert _relerr(gb.cpu(), ref_gb) < 1e-4

@@ -1,0 +1,34 @@
+"""Micro-benchmark of the attention kernels at the cfg2 shape (for rocprofv3 / A-B timing)."""
+import argparse, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from musicgeneration_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=8); ap.add_argument("--L", type=int, default=2048)
+ap.add_argument("--d", type=int, default=512); ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--parts", type=int, default=31, help="bit0 fwd, bit1 delta, bit2 dq, bit3 dkv, bit4 de")
+a = ap.parse_args()
+dev = torch.device("cuda")
+g = torch.Generator().manual_seed(7)
+qkv = (torch.randn(a.B, a.L, 3 * a.d, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+E = (torch.randn(a.L, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+dctx = torch.randn(a.B, a.L, a.d, generator=g).to(torch.bfloat16).to(dev)
+dE = torch.zeros(a.L, 64, device=dev)
+ctx, lse = ops.rel_attn_fwd(qkv, E, None)
+dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
+ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, delta)
+torch.cuda.synchronize()
+unit = a.B * a.L * a.L * a.d
+def timed(fn, units, name):
+    fn(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
+    print(f"{name:8s} {ms:8.3f} ms   executed {units*unit/ms/1e9:8.1f} TF/s ({units} units)")
+if a.parts & 1: timed(lambda: ops.rel_attn_fwd(qkv, E, None), 3, "fwd")
+if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, delta), 0, "delta")
+if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2, dqkv, delta), 5, "dq")
+if a.parts & 8: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, delta), 6, "dkv")
+if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, delta), 6, "de")
