@@ -389,7 +389,10 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, M, N,
                        K, mchunk);
     if (gb) {
-        int ysplit = (M + 2047) / 2048;
+        // ~1024 blocks in flight: each block sums 64 columns over M / ysplit rows (32 row-lanes)
+        const int gx = (N + 63) / 64;
+        int ysplit = (1024 + gx - 1) / gx;
+        if (ysplit > (M + 31) / 32) ysplit = (M + 31) / 32;
         if (ysplit < 1) ysplit = 1;
         hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, ysplit), dim3(256), 0, (hipStream_t)stream, dY, gb, M, N);
     }

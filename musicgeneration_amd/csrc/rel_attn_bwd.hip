@@ -13,8 +13,8 @@
 // own kernel that keeps it in registers for the whole sweep and recomputes P (flash style):
 //   K1 dq_kernel  : workgroup = 128 query rows, sweeps key tiles    (20 MFMA / 32x32 tile)
 //   K2 dkv_kernel : workgroup = 128 keys,       sweeps query tiles  (24 MFMA / tile)
-//   K3 de_kernel  : workgroup = 4 chunks of 32 relative distances, sweeps query tiles along its
-//                   diagonal band (24 MFMA / tile); one float-atomic flush of 32 KB per workgroup.
+//   K3 de_kernel  : workgroup = 8 waves = 8 chunks of 32 relative distances, sweeps query tiles along
+//                   its diagonal band (24 MFMA / tile); one float-atomic flush of 64 KB per workgroup.
 // The skew / un-skew between (i,j) tiles and (i,delta) chunks is done through per-wave LDS band
 // buffers (see rel_attn_common.hpp); no L x L tensor ever exists.
 #include "rel_attn_common.hpp"
@@ -280,13 +280,15 @@ constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
 constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K  dO image R
 constexpr int OFF_OT = OFF_OR + 2 * TILE_BYTES;            // 2 x 4K  dO image T
-constexpr int OFF_ER = OFF_OT + 2 * TILE_BYTES;            // 6 x 4K  Er chunk image R
-constexpr int OFF_ST = OFF_ER + E_SLOTS * TILE_BYTES;      // 2 x 256 B: lse2[32], delta[32]
+constexpr int OFF_ST = OFF_OT + 2 * TILE_BYTES;            // 2 x 256 B: lse2[32], delta[32]
 constexpr int OFF_BAND = OFF_ST + 2 * 256;                 // 4 x 8K fp32 [32][64]
-constexpr int LDS_BYTES = OFF_BAND + WAVES * 8192;         // 90,624 B
+constexpr int LDS_BYTES = OFF_BAND + WAVES * 8192;         // 66,048 B -> 2 workgroups per CU
+// The Er chunks (B operand of Q.Er^T: column t = lane&31, 16 contiguous bytes of row L-1-32q-t) are
+// loaded straight from global/L2 into registers, one new chunk per step (the previous "hi" chunk is
+// the next "lo" chunk), so E needs no LDS here.
 }  // namespace k2
 
-__global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
+__global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
     uint16_t* __restrict__ dqkv, int L, int d) {
@@ -310,7 +312,10 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
     const uint16_t* qg = qkv_b + (size_t)(J0 + srow) * ld + hd * 64 + sch * 8;                  // + t*32*ld
     const uint16_t* og = dctx + ((size_t)b * L + J0 + srow) * d + hd * 64 + sch * 8;            // + t*32*d
-    auto e_src = [&](int q) { return Er + (size_t)(L - 1 - 32 * q - srow) * 64 + sch * 8; };
+    // fragment ks of Er chunk q for this lane
+    auto e_frag = [&](int q, int ks) {
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)(Er + (size_t)(L - 1 - 32 * q - bl) * 64 + hh * 8 + ks * 16));
+    };
     auto stat_src = [&](int t) {   // tid < 64: lse (0..31) / delta (32..63) of query tile t
         const int i = J0 + 32 * t + (tid & 31);
         return (tid < 32) ? lse[stat_base + i] * LOG2E : delta[stat_base + i];
@@ -323,12 +328,15 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
         *(u32x4*)(smem + OFF_QT + st_offT) = qq;
         *(u32x4*)(smem + OFF_OR + st_offR) = oo;
         *(u32x4*)(smem + OFF_OT + st_offT) = oo;
-        *(u32x4*)(smem + OFF_ER + st_offR) = *(const u32x4*)e_src(0);      // chunk 0 -> slot 0
         if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0);
     }
-    bf16x8 kf[4], vf[4];
+    bf16x8 kf[4], vf[4], ehi[4], elo[4];
     uint32_t padlane = 0;
     if (wave_on) {
+        if (w == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ehi[ks] = e_frag(0, ks);      // wave 0 starts on its diagonal (chunk 0)
+        }
         const uint16_t* kp = qkv_b + (size_t)(j0 + bl) * ld + d + hd * 64 + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -343,16 +351,21 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
 
     for (int t = 0; t < nT; ++t) {
         const int cur = t & 1;
-        u32x4 qreg, oreg, ereg;
+        u32x4 qreg, oreg;
         float streg = 0.f;
         const bool have_next = (t + 1 < nT);
         if (have_next) {
             qreg = *(const u32x4*)(qg + (size_t)(t + 1) * 32 * ld);
             oreg = *(const u32x4*)(og + (size_t)(t + 1) * 32 * d);
-            ereg = *(const u32x4*)e_src(t + 1);            // chunk t+1 <= nT-1 < nchunk
             if (tid < 64) streg = stat_src(t + 1);
         }
         const int dq = t - w;
+        bf16x8 enext[4];
+        const bool load_e = wave_on && have_next && (dq + 1 >= 0);     // chunk dq+1 <= nT-1 < nchunk
+        if (load_e) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) enext[ks] = e_frag(dq + 1, ks);
+        }
         if (wave_on && dq >= 0) {
             const int D = dq * 32;
             const char* qr = smem + OFF_QR + cur * TILE_BYTES;
@@ -360,18 +373,21 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_R(qr, bl, hh, ks);
             // QE for chunks dq (and dq-1): rows = query a, cols = t
+            {
+                f32x16 qe = zero16();
 #pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                const int q = dq - which;
-                if (q >= 0) {
-                    const char* et = smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES;
-                    f32x16 qe = zero16();
+                for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], ehi[ks], qe);
+                const int cb = (dq & 1) * 32 + bl;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], frag_R(et, bl, hh, ks), qe);
-                    const int cb = (q & 1) * 32 + bl;
+                for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+            }
+            if (dq >= 1) {
+                f32x16 qe = zero16();
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
-                }
+                for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], elo[ks], qe);
+                const int cb = ((dq - 1) & 1) * 32 + bl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
             }
             wave_lds_fence();
             f32x16 c;
@@ -425,8 +441,11 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
             *(u32x4*)(smem + OFF_QT + (cur ^ 1) * TILE_BYTES + st_offT) = qq;
             *(u32x4*)(smem + OFF_OR + (cur ^ 1) * TILE_BYTES + st_offR) = oreg;
             *(u32x4*)(smem + OFF_OT + (cur ^ 1) * TILE_BYTES + st_offT) = oreg;
-            *(u32x4*)(smem + OFF_ER + ((t + 1) % E_SLOTS) * TILE_BYTES + st_offR) = ereg;
             if (tid < 64) *(float*)(smem + OFF_ST + (cur ^ 1) * 256 + tid * 4) = streg;
+        }
+        if (load_e) {     // this step's "hi" chunk is the next step's "lo" chunk
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { elo[ks] = ehi[ks]; ehi[ks] = enext[ks]; }
         }
         __syncthreads();
     }
@@ -438,24 +457,25 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dkv_kernel(
 }
 
 // ================================================================================================
-// K3: dE.  workgroup = 4 consecutive chunks of 32 relative distances (wave = chunk c, Er chunk
+// K3: dE.  workgroup = 8 consecutive chunks of 32 relative distances (wave = chunk c, Er chunk
 // fragments + dEr[32][64] accumulators in registers).  For query tile i0 the band of chunk c
 // covers the lower triangle (b<=a) of key tile u = i0/32 - c and the upper triangle (b>a) of key
 // tile u-1: both tiles are computed and merged element-wise before exp/dS.
 // ================================================================================================
 namespace k3 {
-constexpr int KV_SLOTS = 6;
-constexpr int OFF_KR = 0;                                  // 6 x 4K K image R ring (slot = tile % 6)
-constexpr int OFF_VR = OFF_KR + KV_SLOTS * TILE_BYTES;     // 6 x 4K V image R ring
+constexpr int W3 = 8;                                      // waves (= distance chunks) per workgroup
+constexpr int KV_SLOTS = 10;                               // live key tiles [t-8, t] + the incoming one
+constexpr int OFF_KR = 0;                                  // 10 x 4K K image R ring (slot = tile % 10)
+constexpr int OFF_VR = OFF_KR + KV_SLOTS * TILE_BYTES;     // 10 x 4K V image R ring
 constexpr int OFF_QR = OFF_VR + KV_SLOTS * TILE_BYTES;     // 2 x 4K qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K qs image T
 constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K dO image R
 constexpr int OFF_ST = OFF_OR + 2 * TILE_BYTES;            // 2 x 256 B
-constexpr int OFF_BAND = OFF_ST + 2 * 256;                 // 4 x 4K fp32 [32][32] (QE, then dS)
-constexpr int LDS_BYTES = OFF_BAND + WAVES * 4096;         // 90,624 B
+constexpr int OFF_BAND = OFF_ST + 2 * 256;                 // 8 x 4K fp32 [32][32] (QE, then dS)
+constexpr int LDS_BYTES = OFF_BAND + W3 * 4096;            // 139,776 B: one 8-wave workgroup per CU
 }  // namespace k3
 
-__global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
+__global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
     float* __restrict__ dEr /* = dE + (M-L)*64 */, int L, int d) {
@@ -467,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
     const int heads = d >> 6;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int nchunk = L >> 5;
-    const int C0 = blockIdx.y * 4;                         // small C0 = longest sweep = dispatched first
+    const int C0 = blockIdx.y * W3;                        // small C0 = longest sweep = dispatched first
     const int cw = C0 + w;
     const bool wave_on = cw < nchunk;
     const int nT = nchunk - C0;
@@ -476,9 +496,11 @@ __global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
     const size_t stat_base = ((size_t)b * heads + hd) * L;
     const uint32_t* pb = padbits ? padbits + (size_t)b * nchunk : nullptr;
 
-    const int srow = tid >> 3, sch = tid & 7;
+    // staging roles: threads 0..255 stage the K and qs tiles, threads 256..511 the V and dO tiles
+    const int half = tid >> 8;
+    const int srow = (tid & 255) >> 3, sch = tid & 7;
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
-    const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;                      // + u*32*ld
+    const uint16_t* kg = qkv_b + (size_t)srow * ld + d + half * d + hd * 64 + sch * 8;           // K or V, + u*32*ld
     const uint16_t* qg = qkv_b + (size_t)(32 * C0 + srow) * ld + hd * 64 + sch * 8;              // + t*32*ld
     const uint16_t* og = dctx + ((size_t)b * L + 32 * C0 + srow) * d + hd * 64 + sch * 8;        // + t*32*d
     auto stat_src = [&](int t) {
@@ -486,12 +508,14 @@ __global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
         return (tid < 32) ? lse[stat_base + i] * LOG2E : delta[stat_base + i];
     };
     {
-        *(u32x4*)(smem + OFF_KR + st_offR) = *(const u32x4*)kg;             // key tile 0 -> slot 0
-        *(u32x4*)(smem + OFF_VR + st_offR) = *(const u32x4*)(kg + d);
-        const u32x4 qq = scale8(*(const u32x4*)qg, 0.125f);
-        *(u32x4*)(smem + OFF_QR + st_offR) = qq;
-        *(u32x4*)(smem + OFF_QT + st_offT) = qq;
-        *(u32x4*)(smem + OFF_OR + st_offR) = *(const u32x4*)og;
+        *(u32x4*)(smem + (half ? OFF_VR : OFF_KR) + st_offR) = *(const u32x4*)kg;      // key tile 0 -> slot 0
+        if (half == 0) {
+            const u32x4 qq = scale8(*(const u32x4*)qg, 0.125f);
+            *(u32x4*)(smem + OFF_QR + st_offR) = qq;
+            *(u32x4*)(smem + OFF_QT + st_offT) = qq;
+        } else {
+            *(u32x4*)(smem + OFF_OR + st_offR) = *(const u32x4*)og;
+        }
         if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0);
     }
     bf16x8 ef[4];
@@ -506,14 +530,12 @@ __global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
 
     for (int t = 0; t < nT; ++t) {
         const int cur = t & 1;
-        u32x4 kreg, vreg, qreg, oreg;
+        u32x4 kreg, qreg;      // K (or V) tile and qs (or dO) tile of the next step, by staging half
         float streg = 0.f;
         const bool have_next = (t + 1 < nT);
         if (have_next) {
             kreg = *(const u32x4*)(kg + (size_t)(t + 1) * 32 * ld);      // key tile t+1 <= nT-1 < nchunk
-            vreg = *(const u32x4*)(kg + d + (size_t)(t + 1) * 32 * ld);
-            qreg = *(const u32x4*)(qg + (size_t)(t + 1) * 32 * ld);
-            oreg = *(const u32x4*)(og + (size_t)(t + 1) * 32 * d);
+            qreg = half ? *(const u32x4*)(og + (size_t)(t + 1) * 32 * d) : *(const u32x4*)(qg + (size_t)(t + 1) * 32 * ld);
             if (tid < 64) streg = stat_src(t + 1);
         }
         const int u = t - w;                              // lower key tile; upper = u-1
@@ -600,12 +622,14 @@ __global__ __launch_bounds__(256, 1) void rel_attn_de_kernel(
             }
         }
         if (have_next) {
-            *(u32x4*)(smem + OFF_KR + ((t + 1) % KV_SLOTS) * TILE_BYTES + st_offR) = kreg;
-            *(u32x4*)(smem + OFF_VR + ((t + 1) % KV_SLOTS) * TILE_BYTES + st_offR) = vreg;
-            const u32x4 qq = scale8(qreg, 0.125f);
-            *(u32x4*)(smem + OFF_QR + (cur ^ 1) * TILE_BYTES + st_offR) = qq;
-            *(u32x4*)(smem + OFF_QT + (cur ^ 1) * TILE_BYTES + st_offT) = qq;
-            *(u32x4*)(smem + OFF_OR + (cur ^ 1) * TILE_BYTES + st_offR) = oreg;
+            *(u32x4*)(smem + (half ? OFF_VR : OFF_KR) + ((t + 1) % KV_SLOTS) * TILE_BYTES + st_offR) = kreg;
+            if (half == 0) {
+                const u32x4 qq = scale8(qreg, 0.125f);
+                *(u32x4*)(smem + OFF_QR + (cur ^ 1) * TILE_BYTES + st_offR) = qq;
+                *(u32x4*)(smem + OFF_QT + (cur ^ 1) * TILE_BYTES + st_offT) = qq;
+            } else {
+                *(u32x4*)(smem + OFF_OR + (cur ^ 1) * TILE_BYTES + st_offR) = qreg;
+            }
             if (tid < 64) *(float*)(smem + OFF_ST + (cur ^ 1) * 256 + tid * 4) = streg;
         }
         __syncthreads();
@@ -647,8 +671,8 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     const dim3 gq(B * heads, (L + 127) / 128);
     if (parts & 2) hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
     if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
-    const dim3 ge(B * heads, ((L >> 5) + 3) / 4);
-    if (parts & 8) hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(256), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
+    const dim3 ge(B * heads, ((L >> 5) + k3::W3 - 1) / k3::W3);
+    if (parts & 8) hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(64 * k3::W3), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
                        dE + (size_t)(M - L) * 64, L, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_bwd");
     return MGX_OK;
