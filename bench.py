@@ -78,8 +78,8 @@ def time_kernels(B, L, d, M, reps=10):
     dE = torch.zeros(M, 64, device=dev)
     ctx, lse = ops.rel_attn_fwd(qkv, E, None)
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty_like(lse)
-    ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, delta)
+    ws = torch.empty(ops._lib.load().mgx_rel_attn_bwd_workspace(*qkv.shape[:2], qkv.shape[2] // 3), dtype=torch.uint8, device=dev)
+    ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, ws)
     torch.cuda.synchronize()
 
     def timed(fn):
@@ -95,7 +95,7 @@ def time_kernels(B, L, d, M, reps=10):
     out = {"rel_attn_fwd_kernel": timed(lambda: ops.rel_attn_fwd(qkv, E, None))}
     for name, bit in (("attn_delta_kernel", 1), ("rel_attn_dq_kernel", 2), ("rel_attn_dkv_kernel", 4),
                       ("rel_attn_de_kernel", 8)):
-        out[name] = timed(lambda bit=bit: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, bit, dqkv, delta))
+        out[name] = timed(lambda bit=bit: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, bit, dqkv, ws))
     return out
 
 

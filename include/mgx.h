@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace */
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -68,16 +68,18 @@ int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* pad
                      uint16_t* ctx, float* lse, int B, int L, int d, int M, void* stream);
 /* backward of the above (autograd of layers.py:86-106).  dctx bf16 [B,L,d] -> dqkv bf16 [B,L,3d];
  * dE f32 [M,64] is ACCUMULATED into (caller zeroes it once per optimiser step).
- * delta f32 [B,h,L] is caller-provided scratch (rowsum(dctx*ctx)).                             */
+ * workspace: caller-provided scratch, 256-byte aligned, >= mgx_rel_attn_bwd_workspace(B,L,d) bytes
+ * (rowsum(dctx*ctx) [B,h,L] f32 + a transposed bf16 copy of E).                                   */
+size_t mgx_rel_attn_bwd_workspace(int B, int L, int d);
 int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                      const uint16_t* ctx, const uint16_t* dctx, const float* lse,
-                     uint16_t* dqkv, float* dE, float* delta,
+                     uint16_t* dqkv, float* dE, void* workspace, size_t ws_bytes,
                      int B, int L, int d, int M, void* stream);
-/* same, running only the selected sub-kernels (bit0 delta pre-pass, bit1 dQ, bit2 dK+dV, bit3 dE);
- * used by bench.py to time each kernel on its own.  parts == 15 is mgx_rel_attn_bwd.             */
+/* same, running only the selected sub-kernels (bit0 pre-pass: delta + E transpose, bit1 dQ, bit2 dK+dV,
+ * bit3 dE); used by bench.py to time each kernel on its own.  parts == 15 is mgx_rel_attn_bwd.    */
 int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                            const uint16_t* ctx, const uint16_t* dctx, const float* lse,
-                           uint16_t* dqkv, float* dE, float* delta,
+                           uint16_t* dqkv, float* dE, void* workspace, size_t ws_bytes,
                            int B, int L, int d, int M, int parts, void* stream);
 
 /* ---- K6: out = LayerNorm(dropout(x) + res) * gamma + beta, eps    layers.py:154-155,159-160 --

@@ -19,8 +19,9 @@ SIGNATURES = {
     "mgx_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_pad_bitmap": [_vp, _vp, _i, _i, _i, _vp],
     "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "mgx_rel_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "mgx_rel_attn_bwd_parts": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_bwd_workspace": [_i, _i, _i],          # returns size_t
+    "mgx_rel_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_bwd_parts": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
     "mgx_add_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _vp],
     "mgx_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _vp],
     "mgx_smooth_ce_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
@@ -57,7 +58,7 @@ def load() -> C.CDLL:
     lib.mgx_last_error.argtypes = []
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
-        fn.restype = C.c_int
+        fn.restype = C.c_size_t if name.endswith("_workspace") else C.c_int
         fn.argtypes = argt
     _lib = lib
     return lib

@@ -96,23 +96,40 @@ MGX_DEV void store_rowsT(uint16_t* dst_row, const f32x16& t0, const f32x16& t1, 
 // ================================================================================================
 // K1: dQ.  Same sweep as the forward (query-block owner, key tiles 0..diagonal).
 //   orientation: keys on registers, queries on lanes (S^T, P^T, dP^T, dS^T), dqs^T[c][a] accumulators.
+//   E never touches LDS here: the Er row fragments (B operand of Q.Er^T) and the fragments of the
+//   transposed copy ErT[c][delta] (A operand of dqs^T += ErT . dQE^T) are loaded from global/L2.
+//   K has ONE LDS image (R) that serves both the row reads (S^T) and the transposed reads (dq).
 // ================================================================================================
 namespace k1 {
-constexpr int OFF_KR = 0;                                  // 2 x 4K  K image R (row frags for S^T)
-constexpr int OFF_KT = OFF_KR + 2 * TILE_BYTES;            // 2 x 4K  K image T (K^T frags for dq)
-constexpr int OFF_VR = OFF_KT + 2 * TILE_BYTES;            // 2 x 4K  V image R (row frags for dP^T)
-constexpr int OFF_ER = OFF_VR + 2 * TILE_BYTES;            // 6 x 4K  Er chunk image R (QE)
-constexpr int OFF_ET = OFF_ER + E_SLOTS * TILE_BYTES;      // 6 x 4K  Er chunk image T (dq_rel)
-constexpr int OFF_BAND = OFF_ET + E_SLOTS * TILE_BYTES;    // 4 x 8K  fp32 [32][64] forward band
+constexpr int OFF_KR = 0;                                  // 2 x 4K  K image R (row + transposed reads)
+constexpr int OFF_VR = OFF_KR + 2 * TILE_BYTES;            // 2 x 4K  V image R (row frags for dP^T)
+constexpr int OFF_BAND = OFF_VR + 2 * TILE_BYTES;          // 4 x 8,704 B fp32 rotated band (see common.hpp)
 constexpr int DB_STRIDE = 144;                             // bytes per dband row (64 bf16 + pad)
-constexpr int OFF_DBAND = OFF_BAND + WAVES * 8192;         // 4 x 4608 bf16 [32][72]
-constexpr int LDS_BYTES = OFF_DBAND + WAVES * 32 * DB_STRIDE;   // 123,392 B -> 1 workgroup per CU
+constexpr int OFF_DBAND = OFF_BAND + WAVES * BAND_BYTES;   // 4 x 4,608 B bf16 [32][72]: dS by (query, delta&63)
+constexpr int LDS_BYTES = OFF_DBAND + WAVES * 32 * DB_STRIDE;   // 69,632 B -> 2 workgroups per CU
 }  // namespace k1
 
-__global__ __launch_bounds__(256, 1) void rel_attn_dq_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint32_t* __restrict__ padbits,
-    const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
-    uint16_t* __restrict__ dqkv, int L, int d) {
+// transposed fragment read from an image-R tile (2-way bank conflict, saves a second LDS image):
+// X[kappa(j)][32*ct + (lane&31)], kappa(j) = 16*s + 8*(j>>2) + 4*hh + (j&3)
+MGX_DEV bf16x8 frag_T_onR(const char* tile, int lane, int s, int ct) {
+    const int i = lane & 15, g = lane >> 4, hh = lane >> 5;
+    const int rq = i >> 2;
+    const int chunk = 4 * ct + 2 * (g & 1) + ((i & 3) >> 1);
+    const int byte_in = 8 * (i & 1);
+    bf16x8 out;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int row = 16 * s + 8 * jq + 4 * hh + rq;
+        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + imgR_off(row, chunk) + byte_in));
+        out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint16_t* __restrict__ ErT,
+    const uint32_t* __restrict__ padbits, const uint16_t* __restrict__ dctx, const float* __restrict__ lse,
+    const float* __restrict__ delta, uint16_t* __restrict__ dqkv, int L, int d) {
     using namespace k1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,29 +146,25 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dq_kernel(
     const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
 
     const int srow = tid >> 3, sch = tid & 7;
-    const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
+    const int st_offR = imgR_off(srow, sch);
     const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;
     const uint16_t* vg = kg + d;
-    auto e_src = [&](int q) { return Er + (size_t)(L - 1 - 32 * q - srow) * 64 + sch * 8; };
+    // Er row fragment ks of chunk q (row t = lane&31 of the chunk, i.e. delta = 32q + t)
+    auto e_frag = [&](int q, int ks) {
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)(Er + (size_t)(L - 1 - 32 * q - a) * 64 + hh * 8 + ks * 16));
+    };
+    // ErT fragment: row c = 32*ct + (lane&31), k = t = 16*ks + 8*hh + j of chunk q
+    auto et_frag = [&](int q, int ks, int ct) {
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)(ErT + (size_t)(32 * ct + a) * L + 32 * q + 16 * ks + 8 * hh));
+    };
 
     {   // prologue staging
-        const u32x4 kk = *(const u32x4*)kg;
-        *(u32x4*)(smem + OFF_KR + st_offR) = kk;
-        *(u32x4*)(smem + OFF_KT + st_offT) = kk;
+        *(u32x4*)(smem + OFF_KR + st_offR) = *(const u32x4*)kg;
         *(u32x4*)(smem + OFF_VR + st_offR) = *(const u32x4*)vg;
-#pragma unroll
-        for (int k = -1; k < 4; ++k) {
-            const int q = Q0 + k;
-            if (q >= 0 && q < nchunk) {
-                const u32x4 ee = *(const u32x4*)e_src(q);
-                *(u32x4*)(smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES + st_offR) = ee;
-                *(u32x4*)(smem + OFF_ET + (q % E_SLOTS) * TILE_BYTES + st_offT) = ee;
-            }
-        }
         // zero the dS band (its never-written half must read as 0 on the first step)
         for (int o = tid * 16; o < WAVES * 32 * DB_STRIDE; o += 256 * 16) *(u32x4*)(smem + OFF_DBAND + o) = u32x4{0, 0, 0, 0};
     }
-    bf16x8 qf[4], dof[4];
+    bf16x8 qf[4], dof[4], ecur[4];
     float lse2 = 0.f, dlt = 0.f;
     if (wave_on) {
         const uint16_t* qp = qkv_b + (size_t)(i0 + a) * ld + hd * 64 + hh * 8;
@@ -160,6 +173,7 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dq_kernel(
         for (int ks = 0; ks < 4; ++ks) {
             qf[ks] = __builtin_bit_cast(bf16x8, scale8(*(const u32x4*)(qp + ks * 16), 0.125f));
             dof[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(dp + ks * 16));
+            ecur[ks] = e_frag(Q0 + w, ks);                 // the wave's first "hi" chunk
         }
         const size_t si = ((size_t)b * heads + hd) * L + i0 + a;
         lse2 = lse[si] * LOG2E;
@@ -167,49 +181,72 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dq_kernel(
     }
     __syncthreads();
 
-    char* band = smem + OFF_BAND + w * 8192;
+    char* band = smem + OFF_BAND + w * BAND_BYTES;
     char* dband = smem + OFF_DBAND + w * (32 * DB_STRIDE);
-    if (wave_on) {
+    // band addressing (rotated band, rows placed so that the register index r is the row slot and the
+    // lane half hh selects a 256-byte-aligned region: XOR-ing byte-address bit 7 then flips chunk parity)
+    int wcl[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wcl[r] = hh * BAND_REGION + (((crow(r, hh) - a) & 63) << 2);
+    const int rbase = band_rowoff(a) + 16 * hh;
+    // dband (unrotated, [a][delta&63] bf16): write offsets for D/32 even; odd flips column bit 5
+    int dwa0[16], dwa1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        dwa0[r] = a * DB_STRIDE + (((a - crow(r, hh)) & 63) << 1);
+        dwa1[r] = a * DB_STRIDE + (((a - crow(r, hh) + 32) & 63) << 1);
+    }
+    if (wave_on) {      // first "hi" chunk -> band
         const int q = Q0 + w;
-        const char* et = smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES;
         f32x16 qe = zero16();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
-        const int cb = (q & 1) * 32 + a;
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], ecur[ks], qe);
+        const int tog = (q & 1) << 7;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+        for (int r = 0; r < 16; ++r) *(float*)(band + r * BAND_STRIDE + (wcl[r] ^ tog)) = qe[r];
+        if (q >= 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ecur[ks] = e_frag(q - 1, ks);    // new chunk of step 0
+        }
     }
     f32x16 dq0 = zero16(), dq1 = zero16();
 
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
-        u32x4 kreg, vreg, ereg;
+        u32x4 kreg, vreg;
         const bool have_next = (s + 1 < nsteps);
-        const int qnext = Q0 - s - 2;
-        const bool have_e = have_next && qnext >= 0;
         if (have_next) {
             kreg = *(const u32x4*)(kg + (size_t)(s + 1) * 32 * ld);
             vreg = *(const u32x4*)(vg + (size_t)(s + 1) * 32 * ld);
         }
-        if (have_e) ereg = *(const u32x4*)e_src(qnext);
-
         const int dq = Q0 + w - s;
         if (wave_on && dq >= 0) {
-            const int D = dq * 32;
+            // fragments of ErT for chunk dq (used at the end of this step) and Er for chunk dq-2 (next step)
+            bf16x8 et[4], enext[4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { et[2 * ks] = et_frag(dq, ks, 0); et[2 * ks + 1] = et_frag(dq, ks, 1); }
             if (dq >= 1) {
-                const int q = dq - 1;
-                const char* et = smem + OFF_ER + (q % E_SLOTS) * TILE_BYTES;
                 f32x16 qe = zero16();
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
-                const int cb = (q & 1) * 32 + a;
+                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], ecur[ks], qe);
+                const int tog = ((dq - 1) & 1) << 7;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
+                for (int r = 0; r < 16; ++r) *(float*)(band + r * BAND_STRIDE + (wcl[r] ^ tog)) = qe[r];
+            }
+            if (dq >= 2) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) enext[ks] = e_frag(dq - 2, ks);
             }
             wave_lds_fence();
             f32x16 c;
+            {
+                const char* rb = band + rbase + ((dq & 1) << 7);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = *(const float*)(band + (a * 64 + ((D + a - crow(r, hh)) & 63)) * 4);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = *(const f32x4*)(rb + 32 * g4);
+                    c[4 * g4] = v.x; c[4 * g4 + 1] = v.y; c[4 * g4 + 2] = v.z; c[4 * g4 + 3] = v.w;
+                }
+            }
             const char* kt = smem + OFF_KR + cur * TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
@@ -236,38 +273,51 @@ __global__ __launch_bounds__(256, 1) void rel_attn_dq_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[r] = c[r] * (dp[r] - dlt);
             // dqs^T += K^T dS^T
-            const char* ktt = smem + OFF_KT + cur * TILE_BYTES;
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 const bf16x8 df = acc_to_frag(c, ss);
-                dq0 = mfma(frag_T(ktt, lane, ss, 0), df, dq0);
-                dq1 = mfma(frag_T(ktt, lane, ss, 1), df, dq1);
+                dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df, dq0);
+                dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df, dq1);
             }
             // un-skew dS into the (query, delta) band, then the completed chunk dq feeds dq_rel
+            if (dq & 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                *(uint16_t*)(dband + a * DB_STRIDE + ((D + a - crow(r, hh)) & 63) * 2) = f32_to_bf16(c[r]);
+                for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa1[r]) = f32_to_bf16(c[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa0[r]) = f32_to_bf16(c[r]);
+            }
             wave_lds_fence();
-            const char* ett = smem + OFF_ET + (dq % E_SLOTS) * TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2);
-                dq0 = mfma(frag_Tn(ett, lane, ks, 0), gq, dq0);
-                dq1 = mfma(frag_Tn(ett, lane, ks, 1), gq, dq1);
+                dq0 = mfma(et[2 * ks], gq, dq0);
+                dq1 = mfma(et[2 * ks + 1], gq, dq1);
+            }
+            if (dq >= 2) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ecur[ks] = enext[ks];
             }
         }
         if (have_next) {
             *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
-            *(u32x4*)(smem + OFF_KT + (cur ^ 1) * TILE_BYTES + st_offT) = kreg;
             *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
-        }
-        if (have_e) {
-            *(u32x4*)(smem + OFF_ER + (qnext % E_SLOTS) * TILE_BYTES + st_offR) = ereg;
-            *(u32x4*)(smem + OFF_ET + (qnext % E_SLOTS) * TILE_BYTES + st_offT) = ereg;
         }
         __syncthreads();
     }
     if (wave_on) store_rowsT(dqkv + ((size_t)b * L + i0 + a) * ld + hd * 64, dq0, dq1, hh, 0.125f);
+}
+
+// ErT[c][delta] = Er[delta][c] = Er_rows[(L-1-delta)*64 + c]      (bf16 [64][L], 8 deltas per thread)
+__global__ __launch_bounds__(256) void er_transpose_kernel(const uint16_t* __restrict__ Er, uint16_t* __restrict__ ErT,
+                                                           int L) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = gid & 63, d8 = gid >> 6;
+    if (d8 * 8 >= L) return;
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = bf16_to_f32(Er[(size_t)(L - 1 - (d8 * 8 + k)) * 64 + c]);
+    *(u32x4*)(ErT + (size_t)c * L + d8 * 8) = pack8(f);
 }
 
 // ================================================================================================
@@ -647,13 +697,24 @@ __global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
     }
 }
 
+static size_t ws_delta_bytes(int B, int L, int d) { return (((size_t)B * (d / 64) * L * 4) + 255) / 256 * 256; }
+
+extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
+    if (B <= 0 || L <= 0 || d <= 0) return 0;
+    return ws_delta_bytes(B, L, d) + (size_t)64 * L * 2;
+}
+
 extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                                       const uint16_t* ctx, const uint16_t* dctx, const float* lse, uint16_t* dqkv,
-                                      float* dE, float* delta, int B, int L, int d, int M, int parts, void* stream) {
-    MGX_REQUIRE(qkv && E && ctx && dctx && lse && dqkv && dE && delta, MGX_ERR_NULL, "mgx_rel_attn_bwd: NULL pointer");
+                                      float* dE, void* workspace, size_t ws_bytes, int B, int L, int d, int M,
+                                      int parts, void* stream) {
+    MGX_REQUIRE(qkv && E && ctx && dctx && lse && dqkv && dE && workspace, MGX_ERR_NULL, "mgx_rel_attn_bwd: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
                 "mgx_rel_attn_bwd: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
     MGX_REQUIRE((L + 127) / 128 <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L too large");
+    MGX_REQUIRE(ws_bytes >= mgx_rel_attn_bwd_workspace(B, L, d) && ((uintptr_t)workspace & 255) == 0, MGX_ERR_SHAPE,
+                "mgx_rel_attn_bwd: workspace must be 256-byte aligned and >= mgx_rel_attn_bwd_workspace() = %zu bytes (got %zu)",
+                mgx_rel_attn_bwd_workspace(B, L, d), ws_bytes);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
@@ -664,12 +725,15 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     hipStream_t s = (hipStream_t)stream;
     const int heads = d / 64;
     const uint16_t* Er = E + (size_t)(M - L) * 64;
+    float* delta = (float*)workspace;
+    uint16_t* ErT = (uint16_t*)((char*)workspace + ws_delta_bytes(B, L, d));
     if (parts & 1) {
         const long total = (long)B * L * heads * 8;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
+        hipLaunchKernelGGL(er_transpose_kernel, dim3((64 * (L / 8) + 255) / 256), dim3(256), 0, s, Er, ErT, L);
     }
     const dim3 gq(B * heads, (L + 127) / 128);
-    if (parts & 2) hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
+    if (parts & 2) hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, padbits, dctx, lse, delta, dqkv, L, d);
     if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
     const dim3 ge(B * heads, ((L >> 5) + k3::W3 - 1) / k3::W3);
     if (parts & 8) hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(64 * k3::W3), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
@@ -679,7 +743,7 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
 }
 
 extern "C" int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const uint16_t* ctx,
-                                const uint16_t* dctx, const float* lse, uint16_t* dqkv, float* dE, float* delta,
-                                int B, int L, int d, int M, void* stream) {
-    return mgx_rel_attn_bwd_parts(qkv, E, padbits, ctx, dctx, lse, dqkv, dE, delta, B, L, d, M, 15, stream);
+                                const uint16_t* dctx, const float* lse, uint16_t* dqkv, float* dE, void* workspace,
+                                size_t ws_bytes, int B, int L, int d, int M, void* stream) {
+    return mgx_rel_attn_bwd_parts(qkv, E, padbits, ctx, dctx, lse, dqkv, dE, workspace, ws_bytes, B, L, d, M, 15, stream);
 }

@@ -93,6 +93,12 @@ MGX_DEV f32x16 zero16() {
 constexpr int BAND_STRIDE = 272;
 constexpr int BAND_BYTES = 32 * BAND_STRIDE;   // 8,704 B per wave
 MGX_DEV int band_off(int row, int col) { return row * BAND_STRIDE + col * 4; }
+// Row placement variant used by the dQ kernel: row a sits at slot ((a&3)|((a>>3)<<2)) of region (a>>2)&1.
+// For the row crow(r,hh) held by accumulator register r this is simply slot r of region hh, and the
+// region size (4,352 B = 17*256) keeps the low 8 address bits equal to the column byte offset, so ONE
+// precomputed per-register offset serves both chunk parities: XOR byte-address bit 7 flips column bit 5.
+constexpr int BAND_REGION = 16 * BAND_STRIDE;
+MGX_DEV int band_rowoff(int a) { return ((a & 3) | ((a >> 3) << 2)) * BAND_STRIDE + ((a >> 2) & 1) * BAND_REGION; }
 // store an accumulator tile through precomputed offsets; `odd` must be wave-uniform
 MGX_DEV void band_store(char* band, const int (&wa0)[16], const int (&wa1)[16], int odd, const f32x16& v) {
     if (odd) {

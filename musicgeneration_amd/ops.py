@@ -68,16 +68,19 @@ def rel_attn_fwd(qkv, E, padbits, M=None) -> Tuple[torch.Tensor, torch.Tensor]:
     return ctx, lse
 
 
-def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, delta=None) -> torch.Tensor:
+def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None) -> torch.Tensor:
     """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench)."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
     B, L, d3 = qkv.shape
     d = d3 // 3
+    lib = _lib.load()
     dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
-    delta = torch.empty_like(lse) if delta is None else delta
-    check(_lib.load().mgx_rel_attn_bwd_parts(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse),
-                                             ptr(dqkv), ptr(dE), ptr(delta), B, L, d, E.shape[0], int(parts),
-                                             stream_ptr()), "mgx_rel_attn_bwd")
+    need = lib.mgx_rel_attn_bwd_workspace(B, L, d)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+    check(lib.mgx_rel_attn_bwd_parts(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dE),
+                                     ptr(workspace), workspace.numel(), B, L, d, E.shape[0], int(parts), stream_ptr()),
+          "mgx_rel_attn_bwd")
     return dqkv
 
 

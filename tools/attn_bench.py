@@ -16,8 +16,8 @@ E = (torch.randn(a.L, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
 dctx = torch.randn(a.B, a.L, a.d, generator=g).to(torch.bfloat16).to(dev)
 dE = torch.zeros(a.L, 64, device=dev)
 ctx, lse = ops.rel_attn_fwd(qkv, E, None)
-dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
-ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, delta)
+dqkv = torch.empty_like(qkv); ws = torch.empty(ops._lib.load().mgx_rel_attn_bwd_workspace(*qkv.shape[:2], qkv.shape[2] // 3), dtype=torch.uint8, device=dev)
+ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, ws)
 torch.cuda.synchronize()
 unit = a.B * a.L * a.L * a.d
 def timed(fn, units, name):
@@ -28,7 +28,7 @@ def timed(fn, units, name):
     ms = e0.elapsed_time(e1) / a.reps
     print(f"{name:8s} {ms:8.3f} ms   executed {units*unit/ms/1e9:8.1f} TF/s ({units} units)")
 if a.parts & 1: timed(lambda: ops.rel_attn_fwd(qkv, E, None), 3, "fwd")
-if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, delta), 0, "delta")
-if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2, dqkv, delta), 5, "dq")
-if a.parts & 8: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, delta), 6, "dkv")
-if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, delta), 6, "de")
+if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, ws), 0, "delta")
+if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2, dqkv, ws), 5, "dq")
+if a.parts & 8: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
+if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 6, "de")
