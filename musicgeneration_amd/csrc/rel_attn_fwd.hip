@@ -21,15 +21,13 @@ using namespace relattn;
 
 namespace {
 constexpr int WAVES = 4;
-constexpr int E_SLOTS = 6;
 constexpr int OFF_K = 0;                               // 2 x 4 KiB   image R
 constexpr int OFF_V = OFF_K + 2 * TILE_BYTES;          // 2 x 4 KiB   image T
-constexpr int OFF_E = OFF_V + 2 * TILE_BYTES;          // 6 x 4 KiB   image R, ring indexed by chunk % 6
-constexpr int OFF_BAND = OFF_E + E_SLOTS * TILE_BYTES; // 4 x (32 rows x 272 B) fp32 rotated band
-constexpr int LDS_BYTES = OFF_BAND + WAVES * BAND_BYTES;    // 75,776 B -> 2 workgroups per CU
+constexpr int OFF_BAND = OFF_V + 2 * TILE_BYTES;       // 4 x (32 rows x 272 B) fp32 rotated band
+constexpr int LDS_BYTES = OFF_BAND + WAVES * BAND_BYTES;    // 51,200 B -> 3 workgroups per CU
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
+__global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er /* = E + (M-L)*64 */,
     const uint32_t* __restrict__ padbits, uint16_t* __restrict__ ctx, float* __restrict__ lse_out,
     int L, int d) {
@@ -56,21 +54,16 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
     const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;       // + j0*ld
     const uint16_t* vg = kg + d;
-    auto e_src = [&](int q) { return Er + (size_t)(L - 1 - 32 * q - srow) * 64 + sch * 8; };
+    // Er row fragment ks of chunk q (B operand of Q.Er^T: column t = lane&31, delta = 32q + t), from L2
+    auto e_frag = [&](int q, int ks) {
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)(Er + (size_t)(L - 1 - 32 * q - a) * 64 + hh * 8 + ks * 16));
+    };
 
-    // ---- prologue: K/V tile 0, E chunks Q0-1 .. Q0+3 --------------------------------------------
-    {
-        *(u32x4*)(smem + OFF_K + st_offR) = *(const u32x4*)kg;
-        *(u32x4*)(smem + OFF_V + st_offT) = *(const u32x4*)vg;
-#pragma unroll
-        for (int k = -1; k < 4; ++k) {
-            const int q = Q0 + k;
-            if (q >= 0 && q < nchunk)
-                *(u32x4*)(smem + OFF_E + (q % E_SLOTS) * TILE_BYTES + st_offR) = *(const u32x4*)e_src(q);
-        }
-    }
-    // Q fragments (A operand of QE, B operand of S^T), pre-scaled by 1/8
-    bf16x8 qf[4];
+    // ---- prologue: K/V tile 0 -------------------------------------------------------------------
+    *(u32x4*)(smem + OFF_K + st_offR) = *(const u32x4*)kg;
+    *(u32x4*)(smem + OFF_V + st_offT) = *(const u32x4*)vg;
+    // Q fragments (A operand of QE, B operand of S^T), pre-scaled by 1/8; first "hi" E chunk
+    bf16x8 qf[4], ecur[4];
     if (wave_on) {
         const uint16_t* qp = qkv_b + (size_t)(i0 + a) * ld + hd * 64 + hh * 8;
 #pragma unroll
@@ -81,29 +74,32 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
 #pragma unroll
             for (int k = 0; k < 8; ++k) f[k] *= 0.125f;
             qf[ks] = __builtin_bit_cast(bf16x8, pack8(f));
+            ecur[ks] = e_frag(Q0 + w, ks);
         }
     }
     __syncthreads();
 
     char* band = smem + OFF_BAND + w * BAND_BYTES;
-    // loop-invariant band addresses (see rel_attn_common.hpp "rotated band"):
-    //   write of QE[a_r][t]: wa0[r] for an even chunk, wa1[r] for an odd one (wave-uniform choice)
-    //   read of the 4 registers of group g4:   rbase + 32*g4 (+128 when D/32 is odd)
-    int wa0[16], wa1[16];
+    // band addressing (rel_attn_common.hpp): register r writes row slot r of region hh at the
+    // precomputed column offset wcl[r] (XOR bit 7 for odd chunks); a lane reads its own row with
+    // four ds_read_b128 at rbase + 32*g4 (+128 when D/32 is odd)
+    int wcl[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        wa0[r] = band_off(crow(r, hh), (crow(r, hh) - a) & 63);
-        wa1[r] = band_off(crow(r, hh), (crow(r, hh) - a - 32) & 63);
-    }
-    const int rbase = a * BAND_STRIDE + 16 * hh;
+    for (int r = 0; r < 16; ++r) wcl[r] = hh * BAND_REGION + (((crow(r, hh) - a) & 63) << 2);
+    const int rbase = band_rowoff(a) + 16 * hh;
     // the wave's first "hi" chunk (delta in [i0, i0+31])
     if (wave_on) {
         const int q = Q0 + w;
-        const char* et = smem + OFF_E + (q % E_SLOTS) * TILE_BYTES;
         f32x16 qe = zero16();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
-        band_store(band, wa0, wa1, q & 1, qe);
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], ecur[ks], qe);
+        const int tog = (q & 1) << 7;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) *(float*)(band + r * BAND_STRIDE + (wcl[r] ^ tog)) = qe[r];
+        if (q >= 1) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ecur[ks] = e_frag(q - 1, ks);      // new chunk of step 0
+        }
     }
 
     f32x16 o0 = zero16(), o1 = zero16();
@@ -112,26 +108,27 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
         // ---- prefetch next step's tiles into registers ------------------------------------------
-        u32x4 kreg, vreg, ereg;
+        u32x4 kreg, vreg;
         const bool have_next = (s + 1 < nsteps);
-        const int qnext = Q0 - s - 2;                    // new chunk of step s+1 for wave 0
-        const bool have_e = have_next && qnext >= 0;
         if (have_next) {
             kreg = *(const u32x4*)(kg + (size_t)(s + 1) * 32 * ld);
             vreg = *(const u32x4*)(vg + (size_t)(s + 1) * 32 * ld);
         }
-        if (have_e) ereg = *(const u32x4*)e_src(qnext);
 
         const int dq = Q0 + w - s;                       // D/32 for this wave; active iff dq >= 0
         if (wave_on && dq >= 0) {
             // ---- new chunk dq-1 (delta in [D-32, D-1]); nothing to do on the diagonal -----------
             if (dq >= 1) {
-                const int q = dq - 1;
-                const char* et = smem + OFF_E + (q % E_SLOTS) * TILE_BYTES;
                 f32x16 qe = zero16();
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], frag_R(et, a, hh, ks), qe);
-                band_store(band, wa0, wa1, q & 1, qe);
+                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], ecur[ks], qe);
+                const int tog = ((dq - 1) & 1) << 7;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(float*)(band + r * BAND_STRIDE + (wcl[r] ^ tog)) = qe[r];
+            }
+            if (dq >= 2) {                                // chunk of the next step: latency hidden by this step
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) ecur[ks] = e_frag(dq - 2, ks);
             }
             wave_lds_fence();
             // ---- S^T = K Q^T + Srel^T ------------------------------------------------------------
@@ -194,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_fwd_kernel(
             *(u32x4*)(smem + OFF_K + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
             *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
         }
-        if (have_e) *(u32x4*)(smem + OFF_E + (qnext % E_SLOTS) * TILE_BYTES + st_offR) = ereg;
         __syncthreads();
     }
 
