@@ -6,7 +6,8 @@ the hot path over one synthetic batch: forward + label-smoothed CE/accuracy + ba
 step (+ gradient all-reduce when N > 1), dropout 0.2 as in the reference config.  Inputs are
 device-resident before the timed region.  Workload = BASELINE.json configs[1] (cfg2):
 REMI vocabulary V=337 (336 + pad), 6 layers, d_model=512 (8 heads x 64), L = max_seq = 2048, bf16
-kernels with fp32 master weights / statistics / accumulation, per-GPU batch 8 (weak scaling).
+kernels with fp32 master weights / statistics / accumulation, per-GPU batch 16 (weak scaling; the
+reference's own default is 6, config.py:35 -- larger batches only help both sides).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
@@ -53,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
     ap.add_argument("--seq-len", type=int, default=CFG2["seq_len"])
     ap.add_argument("--d-model", type=int, default=CFG2["d_model"])
     ap.add_argument("--layers", type=int, default=CFG2["layers"])

@@ -88,11 +88,14 @@ int mgx_add_ln_fwd(const uint16_t* x, const uint16_t* res, const float* gamma, c
                    uint16_t* out, float* mean, float* rstd, int rows, int d, float eps,
                    float p_drop, uint64_t seed, void* stream);
 /* dout bf16 [rows,d] -> dx (grad of x, dropout applied), dres (grad of res) bf16 [rows,d];
- * dgamma,dbeta f32 [d] are ACCUMULATED into.  dx may alias dres when p_drop == 0.              */
+ * dgamma,dbeta f32 [d] are ACCUMULATED into; dxsum f32 [d] (or NULL) += column sums of dx, i.e. the bias
+ * gradient of the projection that produced x.  dx may alias dres when p_drop == 0.
+ * workspace: caller scratch >= mgx_add_ln_bwd_workspace(rows,d) bytes (per-block column partials).  */
+size_t mgx_add_ln_bwd_workspace(int rows, int d);
 int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,
                    const float* mean, const float* rstd, uint16_t* dx, uint16_t* dres,
-                   float* dgamma, float* dbeta, int rows, int d, float p_drop, uint64_t seed,
-                   void* stream);
+                   float* dgamma, float* dbeta, float* dxsum, void* workspace, size_t ws_bytes,
+                   int rows, int d, float p_drop, uint64_t seed, void* stream);
 
 /* ---- K9+K10: label-smoothed cross entropy + accuracy              criterion.py:43-67, metrics.py:22-60
  * logits bf16 [rows,ld] (row stride ld >= V elements; columns >= V are ignored), target int32 [rows].
@@ -117,7 +120,8 @@ int mgx_cast_bf16(const float* p, uint16_t* shadow, size_t n, void* stream);
 
 /* ---- K2/K5/K7/K8: C = act(A @ W^T + bias)                         layers.py:71-84,108,157-158; network.py:39
  * A bf16 [M,K] row-major, W bf16 [N,K] row-major (torch.nn.Linear layout), bias f32 [N] or NULL,
- * C bf16 [M,N].  act: 0 none, 1 ReLU.  K % 64 == 0; M, N arbitrary (edge tiles are masked).   */
+ * C bf16 [M,N].  act: 0 none, 1 ReLU.  K % 64 == 0, N % 4 == 0 (pad the weight rows, as the
+ * vocabulary projection does); M arbitrary (edge tiles are masked).   */
 int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C,
                    int M, int N, int K, int act, void* stream);
 

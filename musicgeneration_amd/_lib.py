@@ -23,7 +23,8 @@ SIGNATURES = {
     "mgx_rel_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_bwd_parts": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
     "mgx_add_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _u64, _vp],
-    "mgx_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _vp],
+    "mgx_add_ln_bwd_workspace": [_i, _i],                 # returns size_t
+    "mgx_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _f, _u64, _vp],
     "mgx_smooth_ce_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "mgx_smooth_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp],
     "mgx_adam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp],

@@ -12,6 +12,7 @@
 //                                        atomics (128-byte row segments) straight into the flat grad
 //                                        buffer -- gradient accumulation across micro-batches for free.
 //   colsum   gb += column sums of dY (bias gradients).
+#include <stdlib.h>
 #include "rel_attn_common.hpp"
 
 using namespace relattn;
@@ -40,6 +41,46 @@ MGX_DEV bf16x8 fragTn(const char* tile, int lane, int ks, int ct) {
         out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
     }
     return out;
+}
+
+// Epilogue of a wave's 64 x 64 output block held as C^T tiles: acc[rt][ct][r] = C[mb + 32*rt + lane&31]
+// [nb + 32*ct + crow(r,hh)].  Registers 4*g4 .. 4*g4+3 are 4 consecutive columns -> one 8-byte store.
+// Optional fused bias (per column), ReLU, and ReLU-backward mask (zero where relu_y <= 0).  N % 4 == 0.
+MGX_DEV void store_tileT(uint16_t* __restrict__ C, const uint16_t* __restrict__ relu_y, const f32x16 (&acc)[2][2],
+                         const float* __restrict__ bias, int act, int mb, int nb, int M, int N, int l31, int hh) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int m = mb + 32 * rt + l31;
+        if (m >= M) continue;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = nb + 32 * ct + 8 * g4 + 4 * hh;
+                if (n >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[rt][ct][4 * g4 + k];
+                if (bias) {
+                    const f32x4 bv = *(const f32x4*)(bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (act == 1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                }
+                if (relu_y) {
+                    const u32x2 y = *(const u32x2*)(relu_y + (size_t)m * N + n);
+                    if (!(bf16lo(y.x) > 0.f)) v[0] = 0.f;
+                    if (!(bf16hi(y.x) > 0.f)) v[1] = 0.f;
+                    if (!(bf16lo(y.y) > 0.f)) v[2] = 0.f;
+                    if (!(bf16hi(y.y) > 0.f)) v[3] = 0.f;
+                }
+                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2*)(C + (size_t)m * N + n) = o;
+            }
+        }
+    }
 }
 
 MGX_DEV void zero_acc(f32x16 (&acc)[2][2]) {
@@ -105,33 +146,17 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __re
             const bf16x8 a1 = frag_R(at, 64 * wm + 32 + l31, hh, ks);
             const bf16x8 b0 = frag_R(wt, 64 * wn + l31, hh, ks);
             const bf16x8 b1 = frag_R(wt, 64 * wn + 32 + l31, hh, ks);
-            acc[0][0] = mfma(a0, b0, acc[0][0]);
-            acc[0][1] = mfma(a0, b1, acc[0][1]);
-            acc[1][0] = mfma(a1, b0, acc[1][0]);
-            acc[1][1] = mfma(a1, b1, acc[1][1]);
+            // swapped operands: acc[rt][ct] holds C^T (rows = n on registers, column = m on the lane), so
+            // 4 consecutive registers are 4 consecutive n of one output row -> 8-byte stores
+            acc[0][0] = mfma(b0, a0, acc[0][0]);
+            acc[0][1] = mfma(b1, a0, acc[0][1]);
+            acc[1][0] = mfma(b0, a1, acc[1][0]);
+            acc[1][1] = mfma(b1, a1, acc[1][1]);
         }
         if (kt + 1 < nk) store_tiles(cur ^ 1);
         __syncthreads();
     }
-    // epilogue: D[i][j], column j on the lane (32 consecutive n = 64 contiguous bytes per half-wave)
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int n = n0 + 64 * wn + 32 * ct + l31;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 64 * wm + 32 * rt + crow(r, hh);
-                if (m < M) {
-                    float v = acc[rt][ct][r] + bv;
-                    if (act == 1) v = fmaxf(v, 0.f);
-                    C[(size_t)m * N + n] = f32_to_bf16(v);
-                }
-            }
-        }
-    }
+    store_tileT(C, nullptr, acc, bias, act, m0 + 64 * wm, n0 + 64 * wn, M, N, l31, hh);
 }
 
 // =================================================================================================
@@ -198,31 +223,15 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
             const char* sub = wt + ((ks >> 1) * 2 + wn) * TILE_BYTES;
             const bf16x8 b0 = fragTn(sub, lane, ks & 1, 0);
             const bf16x8 b1 = fragTn(sub, lane, ks & 1, 1);
-            acc[0][0] = mfma(a0, b0, acc[0][0]);
-            acc[0][1] = mfma(a0, b1, acc[0][1]);
-            acc[1][0] = mfma(a1, b0, acc[1][0]);
-            acc[1][1] = mfma(a1, b1, acc[1][1]);
+            acc[0][0] = mfma(b0, a0, acc[0][0]);      // C^T tiles (see the forward kernel)
+            acc[0][1] = mfma(b1, a0, acc[0][1]);
+            acc[1][0] = mfma(b0, a1, acc[1][0]);
+            acc[1][1] = mfma(b1, a1, acc[1][1]);
         }
         if (nt + 1 < nn) store_tiles(cur ^ 1);
         __syncthreads();
     }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int k = k0 + 64 * wn + 32 * ct + l31;
-        if (k >= K) continue;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 64 * wm + 32 * rt + crow(r, hh);
-                if (m < M) {
-                    float v = acc[rt][ct][r];
-                    if (relu_y && !(bf16_to_f32(relu_y[(size_t)m * K + k]) > 0.f)) v = 0.f;
-                    dX[(size_t)m * K + k] = f32_to_bf16(v);
-                }
-            }
-        }
-    }
+    store_tileT(dX, relu_y, acc, nullptr, 0, m0 + 64 * wm, k0 + 64 * wn, M, K, l31, hh);
 }
 
 // =================================================================================================
@@ -350,8 +359,8 @@ static void set_attrs() {
 extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C, int M, int N,
                               int K, int act, void* stream) {
     MGX_REQUIRE(A && W && C, MGX_ERR_NULL, "mgx_linear_fwd: NULL pointer");
-    MGX_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, MGX_ERR_SHAPE,
-                "mgx_linear_fwd: need K%%64==0 (got M=%d N=%d K=%d)", M, N, K);
+    MGX_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0, MGX_ERR_SHAPE,
+                "mgx_linear_fwd: need K%%64==0 and N%%4==0 (got M=%d N=%d K=%d)", M, N, K);
     MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
     set_attrs();
     const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -381,8 +390,18 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
                 "mgx_linear_dw: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
     set_attrs();
     const int tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-    // split M so that the grid has ~2 workgroups per CU; chunk is a multiple of 64 rows
-    int splits = (512 + tiles - 1) / tiles;
+    // split M so that the grid has ~target workgroups; chunk is a multiple of 64 rows.  Each split adds
+    // one 64 KiB partial tile with fp32 atomics (~1.3 TB/s chip-wide), so fewer, longer splits are better
+    // as long as the grid still covers the CUs.
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("MGX_DW_TARGET_WGS");
+        target = e ? atoi(e) : 0;
+    }
+    // measured on MI355X at M=16384 (tools/gemm_bench.py): ~384 workgroups for many-tile weights (QKV),
+    // ~256 for the small ones
+    const int tgt = target > 0 ? target : (tiles >= 32 ? 384 : 256);
+    int splits = (tgt + tiles - 1) / tiles;
     int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
     if (mchunk < 64) mchunk = 64;
     splits = (M + mchunk - 1) / mchunk;

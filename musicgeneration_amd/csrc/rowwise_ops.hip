@@ -195,25 +195,32 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(
 }
 
 // backward.  z recomputed from x,res; dz = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma.
-// dgamma/dbeta: per-wave register partials over the rows it owns -> LDS -> one atomic per column/block.
+// Column reductions (dgamma, dbeta and -- optionally -- the column sums of dx, i.e. the bias gradient of
+// the projection that produced x): per-wave register partials over the rows the wave owns -> LDS -> ONE
+// plain store per column per block into a [gridDim.x][3*d] partial buffer; ln_finish_kernel then adds the
+// partials to the gradients (no same-address atomics: 512 blocks x 1,024 atomics on the same 4 KB ran
+// 14x below the atomic rate and dominated this kernel).
 template <int NC>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
     const uint16_t* __restrict__ dout, const uint16_t* __restrict__ x, const uint16_t* __restrict__ res,
     const float* __restrict__ gamma, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-    uint16_t* __restrict__ dx, uint16_t* __restrict__ dres, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int rows, int d, DropCfg dc) {
+    uint16_t* __restrict__ dx, uint16_t* __restrict__ dres, float* __restrict__ partial, int rows, int d,
+    DropCfg dc, int want_dxsum) {
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     const int gpr = d >> 3;
     const float inv_d = 1.f / (float)d;
-    float ag[NC][8], ab[NC][8], gg[NC][8];
+    float ag[NC][8], ab[NC][8], ax[NC][8], gg[NC][8];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int col = c * 512 + lane * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { ag[c][k] = 0.f; ab[c][k] = 0.f; gg[c][k] = (col < d) ? gamma[col + k] : 0.f; }
+        for (int k = 0; k < 8; ++k) {
+            ag[c][k] = 0.f; ab[c][k] = 0.f; ax[c][k] = 0.f;
+            gg[c][k] = (col < d) ? gamma[col + k] : 0.f;
+        }
     }
     for (int r = wave; r < rows; r += nwave) {
         const float mean = mean_i[r], rstd = rstd_i[r];
@@ -258,29 +265,54 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
                     dz[k] = rstd * (g[c][k] - c1 - xh[c][k] * c2);
                     dxa[k] = dz[k] * mult[c][k];
                 }
-                *(u32x4*)(dres + (size_t)r * d + col) = pack8(dz);
-                if (dc.thr16 || dx != dres) *(u32x4*)(dx + (size_t)r * d + col) = pack8(dxa);
+                const u32x4 pz = pack8(dz), px = pack8(dxa);
+                *(u32x4*)(dres + (size_t)r * d + col) = pz;
+                if (dc.thr16 || dx != dres) *(u32x4*)(dx + (size_t)r * d + col) = px;
+                if (want_dxsum) {       // sum what the consumer will read: the bf16-rounded dx
+                    float q[8];
+                    unpack8(px, q);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ax[c][k] += q[k];
+                }
             }
         }
     }
-    // block reduce of the column partials over the 4 waves, then one atomic per column
+    // block reduce of the column partials over the 4 waves, one plain store per column
     __shared__ float red[4][512];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    float* prow = partial + (size_t)blockIdx.x * 3 * d;
+    const int npass = want_dxsum ? 3 : 2;
+    for (int pass = 0; pass < npass; ++pass) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) red[wid][lane * 8 + k] = pass ? ab[c][k] : ag[c][k];
+            for (int k = 0; k < 8; ++k) red[wid][lane * 8 + k] = pass == 0 ? ag[c][k] : (pass == 1 ? ab[c][k] : ax[c][k]);
             __syncthreads();
             for (int j = threadIdx.x; j < 512; j += 256) {
                 const int col = c * 512 + j;
-                if (col < d) {
-                    const float v = red[0][j] + red[1][j] + red[2][j] + red[3][j];
-                    atomicAdd((pass ? dbeta : dgamma) + col, v);
-                }
+                if (col < d) prow[pass * d + col] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
             }
         }
+    }
+}
+
+// out[k*d + col] += sum_b partial[b][k*d + col], k = 0 (dgamma), 1 (dbeta), 2 (dxsum)
+__global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                        float* __restrict__ dbeta, float* __restrict__ dxsum, int nblk,
+                                                        int d) {
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);      // column within [0, 3d)
+    const int part = threadIdx.x >> 6;                          // 4 row-groups of blocks
+    __shared__ float red[4][64];
+    float s = 0.f;
+    const int ncol = dxsum ? 3 * d : 2 * d;
+    if (idx < ncol)
+        for (int bb = part; bb < nblk; bb += 4) s += partial[(size_t)bb * 3 * d + idx];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && idx < ncol) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float* dst = idx < d ? dgamma + idx : (idx < 2 * d ? dbeta + (idx - d) : dxsum + (idx - 2 * d));
+        *dst += t;
     }
 }
 
@@ -293,14 +325,14 @@ static void launch_ln_fwd(const uint16_t* x, const uint16_t* res, const float* g
     hipLaunchKernelGGL(add_ln_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, x, res, gamma, beta, out, mean, rstd,
                        rows, d, eps, dc);
 }
+constexpr int LN_BWD_BLOCKS = 512;
+
 template <int NC>
 static void launch_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,
-                          const float* mean, const float* rstd, uint16_t* dx, uint16_t* dres, float* dgamma,
-                          float* dbeta, int rows, int d, DropCfg dc, hipStream_t s) {
-    int grid = (rows + 3) / 4;
-    if (grid > 512) grid = 512;   // fewer blocks -> fewer dgamma/dbeta atomics (512 cols x 512 blocks)
+                          const float* mean, const float* rstd, uint16_t* dx, uint16_t* dres, float* partial,
+                          int grid, int rows, int d, DropCfg dc, int want_dxsum, hipStream_t s) {
     hipLaunchKernelGGL(add_ln_bwd_kernel<NC>, dim3(grid), dim3(256), 0, s, dout, x, res, gamma, mean, rstd, dx,
-                       dres, dgamma, dbeta, rows, d, dc);
+                       dres, partial, rows, d, dc, want_dxsum);
 }
 
 extern "C" int mgx_add_ln_fwd(const uint16_t* x, const uint16_t* res, const float* gamma, const float* beta,
@@ -322,23 +354,37 @@ extern "C" int mgx_add_ln_fwd(const uint16_t* x, const uint16_t* res, const floa
     return MGX_OK;
 }
 
+extern "C" size_t mgx_add_ln_bwd_workspace(int rows, int d) {
+    (void)rows;
+    return d > 0 ? (size_t)LN_BWD_BLOCKS * 3 * d * sizeof(float) : 0;
+}
+
 extern "C" int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,
                               const float* mean, const float* rstd, uint16_t* dx, uint16_t* dres, float* dgamma,
-                              float* dbeta, int rows, int d, float p_drop, uint64_t seed, void* stream) {
-    MGX_REQUIRE(dout && x && res && gamma && mean && rstd && dx && dres && dgamma && dbeta, MGX_ERR_NULL,
+                              float* dbeta, float* dxsum, void* workspace, size_t ws_bytes, int rows, int d,
+                              float p_drop, uint64_t seed, void* stream) {
+    MGX_REQUIRE(dout && x && res && gamma && mean && rstd && dx && dres && dgamma && dbeta && workspace, MGX_ERR_NULL,
                 "mgx_add_ln_bwd: NULL pointer");
     MGX_REQUIRE(rows > 0 && d > 0 && d % 8 == 0 && d <= 512 * LN_MAXC, MGX_ERR_SHAPE,
                 "mgx_add_ln_bwd: need d%%8==0 and d<=%d (got rows=%d d=%d)", 512 * LN_MAXC, rows, d);
     MGX_REQUIRE(p_drop <= 0.f || dx != dres, MGX_ERR_SHAPE, "mgx_add_ln_bwd: dx may alias dres only when p_drop==0");
+    MGX_REQUIRE(ws_bytes >= mgx_add_ln_bwd_workspace(rows, d), MGX_ERR_SHAPE,
+                "mgx_add_ln_bwd: workspace must hold mgx_add_ln_bwd_workspace() = %zu bytes (got %zu)",
+                mgx_add_ln_bwd_workspace(rows, d), ws_bytes);
     const DropCfg dc = make_drop(p_drop, seed);
     const int nc = (d + 511) / 512;
     hipStream_t s = (hipStream_t)stream;
+    int grid = (rows + 3) / 4;
+    if (grid > LN_BWD_BLOCKS) grid = LN_BWD_BLOCKS;
+    float* partial = (float*)workspace;
+    const int wd = dxsum ? 1 : 0;
     switch (nc) {
-        case 1: launch_ln_bwd<1>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
-        case 2: launch_ln_bwd<2>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
-        case 3: launch_ln_bwd<3>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
-        default: launch_ln_bwd<4>(dout, x, res, gamma, mean, rstd, dx, dres, dgamma, dbeta, rows, d, dc, s); break;
+        case 1: launch_ln_bwd<1>(dout, x, res, gamma, mean, rstd, dx, dres, partial, grid, rows, d, dc, wd, s); break;
+        case 2: launch_ln_bwd<2>(dout, x, res, gamma, mean, rstd, dx, dres, partial, grid, rows, d, dc, wd, s); break;
+        case 3: launch_ln_bwd<3>(dout, x, res, gamma, mean, rstd, dx, dres, partial, grid, rows, d, dc, wd, s); break;
+        default: launch_ln_bwd<4>(dout, x, res, gamma, mean, rstd, dx, dres, partial, grid, rows, d, dc, wd, s); break;
     }
+    hipLaunchKernelGGL(ln_finish_kernel, dim3((3 * d + 63) / 64), dim3(256), 0, s, partial, dgamma, dbeta, dxsum, grid, d);
     MGX_CHECK_LAUNCH("mgx_add_ln_bwd");
     return MGX_OK;
 }

@@ -112,16 +112,20 @@ class MusicTransformer(torch.nn.Module):
             # the layer's bucket is complete when its first op (QKV projection) has run its backward
             qkv = ops.linear(h, P[pre + "rga.Wq.weight"], wqkv, bqkv, 0, gqkv, gbqkv, done(f"layer{i}"))
             ctx = ops.rel_attn(qkv, P[pre + "rga.E"], st.w(pre + "rga.E"), padbits, st.g(pre + "rga.E"))
+            # the bias gradients of `fc` and `FFN_suf` are column sums of the LayerNorm backward's dx: that kernel
+            # emits them (gb=None here)
             a = ops.linear(ctx, P[pre + "rga.fc.weight"], st.w(pre + "rga.fc.weight"), P[pre + "rga.fc.bias"].data,
-                           0, st.g(pre + "rga.fc.weight"), st.g(pre + "rga.fc.bias"))
+                           0, st.g(pre + "rga.fc.weight"), None)
             o1 = ops.add_ln(a, h, P[pre + "layernorm1.weight"].data, P[pre + "layernorm1.bias"].data, 1e-6, p,
-                            seed + 4 * i + 1, st.g(pre + "layernorm1.weight"), st.g(pre + "layernorm1.bias"))
+                            seed + 4 * i + 1, st.g(pre + "layernorm1.weight"), st.g(pre + "layernorm1.bias"),
+                            st.g(pre + "rga.fc.bias"))
             f = ops.linear(o1, P[pre + "FFN_pre.weight"], st.w(pre + "FFN_pre.weight"), P[pre + "FFN_pre.bias"].data,
                            1, st.g(pre + "FFN_pre.weight"), st.g(pre + "FFN_pre.bias"))
             f = ops.linear(f, P[pre + "FFN_suf.weight"], st.w(pre + "FFN_suf.weight"), P[pre + "FFN_suf.bias"].data,
-                           0, st.g(pre + "FFN_suf.weight"), st.g(pre + "FFN_suf.bias"), None, True)
+                           0, st.g(pre + "FFN_suf.weight"), None, None, True)
             h = ops.add_ln(f, o1, P[pre + "layernorm2.weight"].data, P[pre + "layernorm2.bias"].data, 1e-6, p,
-                           seed + 4 * i + 2, st.g(pre + "layernorm2.weight"), st.g(pre + "layernorm2.bias"))
+                           seed + 4 * i + 2, st.g(pre + "layernorm2.weight"), st.g(pre + "layernorm2.bias"),
+                           st.g(pre + "FFN_suf.bias"))
         Vp = self.vocab_padded
         logits = ops.linear(h, P["fc.weight"], st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param"),
                             0, st.padded_view("fc.weight", Vp, d, "grad"), st.padded_view("fc.bias", Vp, None, "grad"),

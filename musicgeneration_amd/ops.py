@@ -96,15 +96,24 @@ def add_ln_fwd(x, res, gamma, beta, eps=1e-6, p_drop=0.0, seed=0):
     return out, mean, rstd
 
 
-def add_ln_bwd(dout, x, res, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0):
-    _need_cuda(dout, x, res, gamma, mean, rstd, dgamma, dbeta)
+_LN_WS = {}
+
+
+def add_ln_bwd(dout, x, res, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=0, dxsum=None):
+    """-> (dx, dres); dgamma/dbeta (and dxsum = colsum(dx), if given) are accumulated in place."""
+    _need_cuda(dout, x, res, gamma, mean, rstd, dgamma, dbeta, dxsum)
     d = x.shape[-1]
     rows = x.numel() // d
     dres = torch.empty_like(x)
     dx = torch.empty_like(x) if p_drop > 0 else dres
-    check(_lib.load().mgx_add_ln_bwd(ptr(dout), ptr(x), ptr(res), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
-                                     ptr(dres), ptr(dgamma), ptr(dbeta), rows, d, float(p_drop), int(seed),
-                                     stream_ptr()), "mgx_add_ln_bwd")
+    lib = _lib.load()
+    key = (x.device, d)
+    ws = _LN_WS.get(key)          # per-device scratch, reused by every call on the (single) compute stream
+    if ws is None:
+        ws = _LN_WS[key] = torch.empty(lib.mgx_add_ln_bwd_workspace(rows, d), dtype=torch.uint8, device=x.device)
+    check(lib.mgx_add_ln_bwd(ptr(dout), ptr(x), ptr(res), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dres),
+                             ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(ws), ws.numel(), rows, d, float(p_drop), int(seed),
+                             stream_ptr()), "mgx_add_ln_bwd")
     return dx, dres
 
 
@@ -221,18 +230,18 @@ class _AddLN(torch.autograd.Function):
     """K6: LayerNorm(dropout(x) + res), eps 1e-6                 layers.py:154-155,159-160"""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta):
+    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta, gxbias):
         out, mean, rstd = add_ln_fwd(x, res, gamma, beta, eps, p_drop, seed)
         ctx.save_for_backward(x, res, gamma, mean, rstd)
-        ctx.cfg = (p_drop, seed, ggamma, gbeta)
+        ctx.cfg = (p_drop, seed, ggamma, gbeta, gxbias)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, res, gamma, mean, rstd = ctx.saved_tensors
-        p_drop, seed, ggamma, gbeta = ctx.cfg
-        dx, dres = add_ln_bwd(dout.contiguous(), x, res, gamma, mean, rstd, ggamma, gbeta, p_drop, seed)
-        return dx, dres, None, None, None, None, None, None, None
+        p_drop, seed, ggamma, gbeta, gxbias = ctx.cfg
+        dx, dres = add_ln_bwd(dout.contiguous(), x, res, gamma, mean, rstd, ggamma, gbeta, p_drop, seed, gxbias)
+        return dx, dres, None, None, None, None, None, None, None, None
 
 
 class _Linear(torch.autograd.Function):
@@ -291,8 +300,10 @@ def rel_attn(qkv, E_master, E_shadow, padbits, gE):
     return _RelAttn.apply(qkv, E_master, E_shadow, padbits, gE)
 
 
-def add_ln(x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta):
-    return _AddLN.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed), ggamma, gbeta)
+def add_ln(x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta, gxbias=None):
+    """gxbias: fp32 grad view of the bias of the projection that produced x; its gradient (= column sums of
+    dx) is then produced by the LayerNorm backward, and that projection is called with gb=None."""
+    return _AddLN.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed), ggamma, gbeta, gxbias)
 
 
 def linear(x, w_master, w_shadow, bias, act, gw, gb, done=None, x_is_relu=False):

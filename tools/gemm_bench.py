@@ -1,0 +1,29 @@
+"""Micro-benchmark of the GEMM kernels at the cfg2 shapes."""
+import sys, os, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from musicgeneration_amd import ops
+dev = torch.device("cuda")
+M = 16384
+shapes = [("qkv", 1536, 512), ("fc", 512, 512), ("ffn_pre", 256, 512), ("ffn_suf", 512, 256), ("vocab", 384, 512)]
+g = torch.Generator().manual_seed(0)
+def timed(fn, reps=20):
+    fn(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+tot = {"fwd": 0, "dx": 0, "dw": 0}
+for name, N, K in shapes:
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    gw = torch.zeros(N, K, device=dev); gb = torch.zeros(N, device=dev)
+    fl = 2.0 * M * N * K
+    t1 = timed(lambda: ops.linear_fwd(x, w, b, 0)); t2 = timed(lambda: ops.linear_dx(dy, w, None)); t3 = timed(lambda: ops.linear_dw(dy, x, gw, None))
+    t4 = timed(lambda: torch.mm(x, w.t()))
+    mult = 6 if name != "vocab" else 1
+    tot["fwd"] += t1 * mult; tot["dx"] += t2 * mult; tot["dw"] += t3 * mult
+    print(f"{name:8s} N={N:5d} K={K:4d}  fwd {t1*1e3:6.1f} us {fl/t1/1e9:6.0f} TF/s | dx {t2*1e3:6.1f} us {fl/t2/1e9:6.0f} | dw {t3*1e3:6.1f} us {fl/t3/1e9:6.0f} | lib mm {t4*1e3:6.1f} us {fl/t4/1e9:6.0f}")
+print("per-step totals (ms):", {k: round(v, 3) for k, v in tot.items()})
