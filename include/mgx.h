@@ -136,6 +136,26 @@ int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y,
 int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, float* gb,
                   int M, int N, int K, void* stream);
 
+/* ---- K12: autoregressive decode with a KV cache (replaces the per-token full-window recompute of
+ * network.py:52-77; causal semantics).  The current position t lives in device memory
+ * (pos_dev[0]) so that one captured graph of a whole step can be replayed for every token.
+ * mgx_decode_embed: out bf16 [B,d] = table[tok]*sqrt(d) + pe[t]            (layers.py:226-229)          */
+int mgx_decode_embed(const int32_t* tok, const float* table, const float* pe, const int32_t* pos_dev,
+                     uint16_t* out, int B, int d, int V, void* stream);
+/* qkv_new bf16 [B,3d] (projection of the token at position t): k_t, v_t are appended to
+ * kcache/vcache bf16 [B,Lmax,d] at row t, then ctx bf16 [B,d] = softmax_j((q.k_j + q.E[M-1-(t-j)])/8) v_j
+ * over j = 0..t.  t < Lmax <= M.                                                                      */
+int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, uint16_t* vcache, const uint16_t* E,
+                        const int32_t* pos_dev, uint16_t* ctx, int B, int Lmax, int d, int M, void* stream);
+/* logits bf16 [B,ld] -> next_tok int32 [B] drawn from softmax(logits/temperature) restricted to the top_k
+ * most likely ids (0 = all) and then to the smallest set whose mass reaches top_p (1 = all).
+ * out_tokens int32 [B,out_ld] (or NULL): column t+1 receives the token; probs_out f32 [B,V] (or NULL)
+ * receives the unfiltered softmax.  The draw is a pure function of (seed, t, row).
+ * advance != 0: pos_dev[0] += 1 after sampling.  V <= 1024.                                           */
+int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
+                         uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
+                         float* probs_out, int B, int advance, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

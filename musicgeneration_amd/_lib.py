@@ -30,6 +30,9 @@ SIGNATURES = {
     "mgx_adam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp],
     "mgx_cast_bf16": [_vp, _vp, _sz, _vp],
     "mgx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_decode_embed": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mgx_rel_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_sample_topk_topp": [_vp, _i, _i, _f, _i, _f, _u64, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "mgx_linear_dx": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_linear_dw": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }

@@ -180,6 +180,100 @@ class MusicTransformer(torch.nn.Module):
             result_array = torch.cat((result_array, nxt), dim=-1)
         return result_array
 
+    # ------------------------------------------------------------------------------------------
+    # KV-cache decode (cfg5): O(t) per token instead of the reference's O(W^2) recompute
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate_cached(self, prior: torch.Tensor, length: int, temperature: float = 1.0, top_k: int = 0,
+                        top_p: float = 1.0, seed: int = 0, use_graph: bool = True, return_probs: bool = False):
+        """Sample ``length`` events after ``prior`` [B,P] with per-layer K/V caches and absolute positions
+        0..P+length-1 (requires P+length <= max_seq; no sliding window).  Every step runs
+        embed -> N x (QKV GEMM, cached relative attention, fc, LN, FFN, LN) -> vocabulary GEMM -> fused
+        sampler; the position lives on the device, so after a warm-up step the whole step is captured in
+        one graph and replayed per token.  Returns int32 [B, P+length] (and, if ``return_probs``, the
+        f32 [B, P+length, V] next-token distributions, position p = distribution after token p)."""
+        st = self.store()
+        st.sync_shadow()
+        was_training = self.training
+        self.eval()
+        B, P = prior.shape
+        total = P + length
+        if total > self.max_seq or P < 1:
+            raise ValueError(f"prior ({P}) + length ({length}) must be <= max_seq ({self.max_seq}) and prior non-empty")
+        dev = st.param.device
+        d, V, Vp, nl = self.embedding_dim, self.vocab_size, self.vocab_padded, self.num_layer
+        bf = torch.bfloat16
+        kc = [torch.zeros(B, total, d, dtype=bf, device=dev) for _ in range(nl)]
+        vc = [torch.zeros(B, total, d, dtype=bf, device=dev) for _ in range(nl)]
+        pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        tok = prior[:, 0].to(torch.int32).contiguous().to(dev)
+        prior_i = prior.to(torch.int32).to(dev)
+        out_tokens = torch.zeros(B, total, dtype=torch.int32, device=dev)
+        out_tokens[:, :P] = prior_i
+        probs_all = torch.zeros(B, total, V, dtype=torch.float32, device=dev) if return_probs else None
+        probs_step = torch.zeros(B, V, dtype=torch.float32, device=dev) if return_probs else None
+        hbuf = torch.empty(B, d, dtype=bf, device=dev)
+        ctxbuf = torch.empty(B, d, dtype=bf, device=dev)
+        pe = self.Decoder.pos_encoding.table()
+        Pm = st.params
+        layers = []
+        for i in range(nl):
+            pre = f"Decoder.enc_layers.{i}."
+            layers.append(dict(
+                wqkv=st.fused(pre + "rga.Wq.weight", pre + "rga.Wv.weight", 3 * d, d),
+                bqkv=st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "param").view(3 * d),
+                E=st.w(pre + "rga.E"), wfc=st.w(pre + "rga.fc.weight"), bfc=Pm[pre + "rga.fc.bias"].data,
+                g1=Pm[pre + "layernorm1.weight"].data, b1=Pm[pre + "layernorm1.bias"].data,
+                w1=st.w(pre + "FFN_pre.weight"), bb1=Pm[pre + "FFN_pre.bias"].data,
+                w2=st.w(pre + "FFN_suf.weight"), bb2=Pm[pre + "FFN_suf.bias"].data,
+                g2=Pm[pre + "layernorm2.weight"].data, b2=Pm[pre + "layernorm2.bias"].data))
+        wv, bv = st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param")
+
+        def step(sample_into_out: bool):
+            h = ops.decode_embed(tok, Pm["Decoder.embedding.weight"].data, pe, pos, hbuf)
+            for i, ly in enumerate(layers):
+                qkv = ops.linear_fwd(h, ly["wqkv"], ly["bqkv"], 0)
+                ops.rel_attn_decode(qkv, kc[i], vc[i], ly["E"], pos, ctxbuf)
+                a = ops.linear_fwd(ctxbuf, ly["wfc"], ly["bfc"], 0)
+                o1 = ops.add_ln_fwd(a, h, ly["g1"], ly["b1"], 1e-6)[0]
+                f = ops.linear_fwd(o1, ly["w1"], ly["bb1"], 1)
+                f = ops.linear_fwd(f, ly["w2"], ly["bb2"], 0)
+                h = ops.add_ln_fwd(f, o1, ly["g2"], ly["b2"], 1e-6)[0]
+            logits = ops.linear_fwd(h, wv, bv, 0)
+            ops.sample_topk_topp(logits, V, pos, tok, out_tokens if sample_into_out else None, probs_step, temperature,
+                                 top_k, top_p, seed, advance=True)
+
+        # prefill: the prior is teacher-forced token by token (it also warms every kernel up before capture)
+        for p in range(P):
+            step(sample_into_out=(p == P - 1) and length > 0)
+            if return_probs:
+                probs_all[:, p] = probs_step
+            if p + 1 < P:
+                tok.copy_(prior_i[:, p + 1])
+        remaining = length - 1 if length > 0 else 0
+        if remaining > 0:
+            graph = None
+            if use_graph and not return_probs and remaining > 2:
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side):
+                        step(True)
+                torch.cuda.current_stream().wait_stream(side)
+                remaining -= 1                      # the capture itself does not execute; replay below
+                remaining += 1
+            for p in range(remaining):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    step(True)
+                    if return_probs:
+                        probs_all[:, P + p] = probs_step
+        self.train(was_training)
+        return (out_tokens, probs_all) if return_probs else out_tokens
+
     def test(self):
         self.eval()
         self.infer = True

@@ -181,6 +181,35 @@ def linear_dw(dy, x, gw, gb=None):
     check(_lib.load().mgx_linear_dw(ptr(dy), ptr(x), ptr(gw), ptr(gb), Mrows, N, K, stream_ptr()), "mgx_linear_dw")
 
 
+# ---- decode path (no autograd) ----------------------------------------------------------------------
+def decode_embed(tok, table, pe, pos_dev, out):
+    _need_cuda(tok, table, pe, pos_dev, out)
+    V, d = table.shape
+    check(_lib.load().mgx_decode_embed(ptr(tok), ptr(table), ptr(pe), ptr(pos_dev), ptr(out), tok.numel(), d, V,
+                                       stream_ptr()), "mgx_decode_embed")
+    return out
+
+
+def rel_attn_decode(qkv_new, kcache, vcache, E, pos_dev, ctx):
+    _need_cuda(qkv_new, kcache, vcache, E, pos_dev, ctx)
+    B, Lmax, d = kcache.shape
+    check(_lib.load().mgx_rel_attn_decode(ptr(qkv_new), ptr(kcache), ptr(vcache), ptr(E), ptr(pos_dev), ptr(ctx), B, Lmax,
+                                          d, E.shape[0], stream_ptr()), "mgx_rel_attn_decode")
+    return ctx
+
+
+def sample_topk_topp(logits, V, pos_dev, next_tok, out_tokens=None, probs_out=None, temperature=1.0, top_k=0, top_p=1.0,
+                     seed=0, advance=True):
+    _need_cuda(logits, pos_dev, next_tok, out_tokens, probs_out)
+    ld = logits.shape[-1]
+    B = logits.numel() // ld
+    check(_lib.load().mgx_sample_topk_topp(ptr(logits), int(V), ld, float(temperature), int(top_k), float(top_p), int(seed),
+                                           ptr(pos_dev), ptr(next_tok), ptr(out_tokens),
+                                           0 if out_tokens is None else out_tokens.shape[-1], ptr(probs_out), B,
+                                           1 if advance else 0, stream_ptr()), "mgx_sample_topk_topp")
+    return next_tok
+
+
 # --------------------------------------------------------------------------------------------------
 # autograd glue
 #

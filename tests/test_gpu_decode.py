@@ -1,0 +1,92 @@
+"""Decode path (A12): cached single-query relative attention + fused sampler vs the causal training forward."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(d=128, nl=2, L=96, V=337, seed=0):
+    from musicgeneration_amd.network import MusicTransformer
+    from oracle import ref_cpu as R
+    p0 = R.init_params(V, d, nl, L, seed=seed)
+    # tame the random-init logits (N(0,1)*sqrt(d) embeddings give near one-hot attention, the worst case for
+    # bf16): decode-vs-forward parity is about the kernels, not about that fixture
+    p0["Decoder.embedding.weight"] = p0["Decoder.embedding.weight"] * 0.1
+    for k in list(p0):
+        if k.endswith("rga.E"):
+            p0[k] = p0[k] * 0.2
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0)
+    mt.load_state_dict(p0)
+    return mt.cuda().eval(), p0
+
+
+def test_cached_decode_matches_causal_forward_and_oracle():
+    from oracle import ref_cpu as R
+    mt, p0 = _model()
+    V, L, B = 337, 96, 3
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, V - 1, (B, L), generator=g)
+    toks, probs = mt.generate_cached(x.cuda(), 0, return_probs=True)
+    torch.cuda.synchronize()
+    assert (toks.cpu() == x).all()
+    with torch.no_grad():
+        fwd = torch.softmax(mt(x.to(torch.int32).cuda())[0].float(), -1).cpu()
+        ref = torch.softmax(R.model_forward(p0, x, V - 1)[0], -1)
+    assert (probs.cpu() - fwd).abs().max().item() < 1e-2          # same kernels' arithmetic, different order
+    assert (probs.cpu() - ref).abs().max().item() < 2e-2          # vs the fp32 oracle (causal semantics)
+    assert abs(probs.sum(-1).cpu() - 1).max().item() < 1e-4
+
+
+def test_sampler_distribution_and_filters():
+    from musicgeneration_amd import ops
+    dev = torch.device("cuda")
+    V, B = 337, 4096
+    g = torch.Generator().manual_seed(3)
+    row = torch.randn(V, generator=g) * 2
+    logits = row.to(torch.bfloat16).repeat(B, 1).contiguous().to(dev)
+    p_ref = torch.softmax(row.to(torch.bfloat16).float(), -1)
+    pos = torch.zeros(1, dtype=torch.int32, device=dev)
+    nxt = torch.empty(B, dtype=torch.int32, device=dev)
+    probs = torch.empty(B, V, device=dev)
+    ops.sample_topk_topp(logits, V, pos, nxt, None, probs, seed=7, advance=True)
+    torch.cuda.synchronize()
+    assert pos.item() == 1
+    assert (probs[0].cpu() - p_ref).abs().max().item() < 1e-6
+    cnt = torch.bincount(nxt.cpu().long(), minlength=V).float() / B
+    assert (cnt - p_ref).abs().max().item() < 4 * math.sqrt(p_ref.max().item() / B) + 2e-3   # ~4 sigma
+    # same (seed, step, row) -> same draw; another step -> another stream
+    nxt2 = torch.empty_like(nxt)
+    pos.zero_()
+    ops.sample_topk_topp(logits, V, pos, nxt2, None, None, seed=7, advance=False)
+    assert (nxt2 == nxt).all()
+    # top-k: only the k most likely ids appear; top-p: the smallest prefix reaching p
+    k = 5
+    ops.sample_topk_topp(logits, V, pos, nxt, None, None, top_k=k, seed=9, advance=False)
+    topk_ids = set(p_ref.topk(k).indices.tolist())
+    assert set(nxt.cpu().tolist()) <= topk_ids and len(set(nxt.cpu().tolist())) == k
+    sp, si = p_ref.sort(descending=True)
+    n_keep = int((sp.cumsum(0) < 0.9).sum().item()) + 1
+    ops.sample_topk_topp(logits, V, pos, nxt, None, None, top_p=0.9, seed=10, advance=False)
+    assert set(nxt.cpu().tolist()) <= set(si[:n_keep].tolist())
+    assert len(set(nxt.cpu().tolist())) >= n_keep - 2
+    # temperature -> 0 is greedy
+    ops.sample_topk_topp(logits, V, pos, nxt, None, None, temperature=1e-3, seed=11, advance=False)
+    best = set((p_ref == p_ref.max()).nonzero().flatten().tolist())     # bf16 logits may tie at the top
+    assert set(nxt.cpu().tolist()) <= best
+
+
+def test_graph_replay_equals_eager_decode():
+    mt, _ = _model(L=64)
+    prior = torch.tensor([[24, 28, 31], [5, 6, 7]], device="cuda")
+    a = mt.generate_cached(prior, 40, top_p=0.9, seed=123, use_graph=True).cpu()
+    b = mt.generate_cached(prior, 40, top_p=0.9, seed=123, use_graph=False).cpu()
+    assert a.shape == (2, 43) and (a[:, :3] == prior.cpu()).all()
+    assert (a == b).all()                       # sampling is a pure function of (seed, position, row)
+    c = mt.generate_cached(prior, 40, top_p=0.9, seed=124, use_graph=True).cpu()
+    assert not (a == c).all()
+    assert int(a.max()) < 337 and int(a.min()) >= 0
+    with pytest.raises(ValueError):
+        mt.generate_cached(prior, 100)          # beyond max_seq: no silent sliding window
