@@ -156,6 +156,14 @@ int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float temperatur
                          uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
                          float* probs_out, int B, int advance, void* stream);
 
+/* ---- K13: Event_Melody_RNN step (Event_MelodyRNN/network.py:51-61): the GRU projections run on
+ * mgx_linear_fwd; these two kernels are the rest of a step.
+ * out bf16 [B,ld] = table bf16 [V,ld][tok] (ld = embedding width padded to a multiple of 64).          */
+int mgx_gather_rows(const int32_t* tok, const uint16_t* table, uint16_t* out, int B, int ld, int V, void* stream);
+/* torch.nn.GRU cell, gate order (r,z,n): gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh bf16 [B,3H];
+ * h f32 [B,H] is updated in place, h_bf16 [B,H] receives its bf16 copy (input of the next projection). */
+int mgx_gru_gates(const uint16_t* gi, const uint16_t* gh, float* h, uint16_t* h_bf16, int B, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

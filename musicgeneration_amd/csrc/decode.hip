@@ -266,3 +266,52 @@ extern "C" int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float
     MGX_CHECK_LAUNCH("mgx_sample_topk_topp");
     return MGX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// K13: Event_Melody_RNN step pieces (Event_MelodyRNN/network.py:51-61): row gather + fused GRU gates
+// ---------------------------------------------------------------------------------------------------
+// out bf16 [B, ld] = table bf16 [V, ld][tok]        (ld = embedding width padded to the GEMM's K % 64)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int32_t* __restrict__ tok, const uint16_t* __restrict__ table,
+                                                          uint16_t* __restrict__ out, int B, int ld, int V) {
+    const int gpr = ld >> 3;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= B * gpr) return;
+    const int r = g / gpr, c = (g % gpr) * 8;
+    int t = tok[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    *(u32x4*)(out + (size_t)r * ld + c) = *(const u32x4*)(table + (size_t)t * ld + c);
+}
+// torch.nn.GRU cell (gate order r,z,n):  r = s(gi_r+gh_r), z = s(gi_z+gh_z), n = tanh(gi_n + r*gh_n),
+// h' = (1-z)*n + z*h.   gi, gh bf16 [B,3H] (biases already added by the GEMM epilogue), h f32 [B,H] in/out,
+// h_bf16 [B,H] = bf16(h') for the next GEMM.
+__global__ __launch_bounds__(256) void gru_gates_kernel(const uint16_t* __restrict__ gi, const uint16_t* __restrict__ gh,
+                                                        float* __restrict__ h, uint16_t* __restrict__ h_bf16, int B, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H) return;
+    const int b = i / H, k = i % H;
+    const size_t o = (size_t)b * 3 * H + k;
+    const float ir = bf16_to_f32(gi[o]), iz = bf16_to_f32(gi[o + H]), in_ = bf16_to_f32(gi[o + 2 * H]);
+    const float hr = bf16_to_f32(gh[o]), hz = bf16_to_f32(gh[o + H]), hn = bf16_to_f32(gh[o + 2 * H]);
+    const float r = 1.f / (1.f + __expf(-(ir + hr)));
+    const float z = 1.f / (1.f + __expf(-(iz + hz)));
+    const float n = tanhf(in_ + r * hn);
+    const float hv = (1.f - z) * n + z * h[i];
+    h[i] = hv;
+    h_bf16[i] = f32_to_bf16(hv);
+}
+
+extern "C" int mgx_gather_rows(const int32_t* tok, const uint16_t* table, uint16_t* out, int B, int ld, int V, void* stream) {
+    MGX_REQUIRE(tok && table && out, MGX_ERR_NULL, "mgx_gather_rows: NULL pointer");
+    MGX_REQUIRE(B > 0 && V > 0 && ld > 0 && ld % 8 == 0, MGX_ERR_SHAPE, "mgx_gather_rows: need ld%%8==0 (ld=%d)", ld);
+    const int total = B * (ld / 8);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, table, out, B, ld, V);
+    MGX_CHECK_LAUNCH("mgx_gather_rows");
+    return MGX_OK;
+}
+extern "C" int mgx_gru_gates(const uint16_t* gi, const uint16_t* gh, float* h, uint16_t* h_bf16, int B, int H, void* stream) {
+    MGX_REQUIRE(gi && gh && h && h_bf16, MGX_ERR_NULL, "mgx_gru_gates: NULL pointer");
+    MGX_REQUIRE(B > 0 && H > 0, MGX_ERR_SHAPE, "mgx_gru_gates: bad shape");
+    hipLaunchKernelGGL(gru_gates_kernel, dim3((B * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, gi, gh, h, h_bf16, B, H);
+    MGX_CHECK_LAUNCH("mgx_gru_gates");
+    return MGX_OK;
+}

@@ -1,0 +1,192 @@
+"""Mirror of mg/model/Event_MelodyRNN/network.py:11-164: ``Event_Melody_RNN`` (embedding -> multi-layer GRU
+-> linear) with the reference's constructor, ``state_dict`` keys and ``generate`` / ``gen_forward`` /
+``init_to_hidden`` / ``get_primary_event`` signatures, running each step on libmgx kernels:
+row gather, two bf16 MFMA projections per layer (bias fused), one fused gate kernel per layer, the output
+projection and the fused sampler; the whole step is captured in a graph when it is replayed many times.
+
+Scope: sampling (the north-star's cfg5 alternative reading).  ``Train`` is forward-only here (teacher-forced
+logits, used for parity); the GRU training backward and beam search (broken in the reference)
+are not built."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import check, ptr, stream_ptr, load as _load
+
+BF16 = torch.bfloat16
+
+
+def _pad_cols(w: torch.Tensor, k: int) -> torch.Tensor:
+    out = torch.zeros(w.shape[0], k, dtype=BF16, device=w.device)
+    out[:, : w.shape[1]] = w.to(BF16)
+    return out.contiguous()
+
+
+class Event_Melody_RNN(nn.Module):
+    def __init__(self, init_dim, event_dim, hidden_dim, rnn_layers=2, dropout=0.5):
+        super().__init__()
+        self.event_dim = event_dim
+        self.init_dim = init_dim
+        self.hidden_dim = hidden_dim
+        self.rnn_layers = rnn_layers
+        self.output_dim = event_dim
+        self.primary_event = self.event_dim - 1
+        self.inithid_fc = nn.Linear(init_dim, rnn_layers * hidden_dim)
+        self.inithid_fc_activation = nn.Tanh()
+        self.event_embedding = nn.Embedding(event_dim, event_dim)
+        self.rnn = nn.GRU(self.event_dim, self.hidden_dim, num_layers=rnn_layers, dropout=dropout)
+        self.output_fc = nn.Linear(hidden_dim, self.output_dim)
+        self.output_fc_activation = nn.Softmax(dim=-1)
+        if hidden_dim % 64:
+            raise ValueError("hidden_dim must be a multiple of 64 for the MFMA projections")
+        self._packed = None
+
+    # ---- bf16 operand pack (rebuilt when parameters change) -----------------------------------------
+    def _pack(self):
+        ver = tuple(p._version for p in self.parameters())
+        dev = self.output_fc.weight.device
+        if self._packed is not None and self._packed["ver"] == ver and self._packed["dev"] == dev:
+            return self._packed
+        if dev.type != "cuda":
+            raise ops._lib.MgxError("Event_Melody_RNN runs on the MI355X kernels only: move it to a HIP device")
+        Ep = (self.event_dim + 63) // 64 * 64            # embedding width padded to the GEMM's K % 64
+        Vp = (self.event_dim + 3) // 4 * 4               # output rows padded to N % 4
+        pk = {"ver": ver, "dev": dev, "Ep": Ep, "Vp": Vp,
+              "emb": _pad_cols(self.event_embedding.weight.data, Ep), "layers": []}
+        for l in range(self.rnn_layers):
+            wih = getattr(self.rnn, f"weight_ih_l{l}").data
+            pk["layers"].append(dict(
+                wih=_pad_cols(wih, Ep) if l == 0 else wih.to(BF16).contiguous(),
+                whh=getattr(self.rnn, f"weight_hh_l{l}").data.to(BF16).contiguous(),
+                bih=getattr(self.rnn, f"bias_ih_l{l}").data.float().contiguous(),
+                bhh=getattr(self.rnn, f"bias_hh_l{l}").data.float().contiguous()))
+        wo = torch.zeros(Vp, self.hidden_dim, dtype=BF16, device=dev)
+        wo[: self.event_dim] = self.output_fc.weight.data.to(BF16)
+        bo = torch.zeros(Vp, dtype=torch.float32, device=dev)
+        bo[: self.event_dim] = self.output_fc.bias.data.float()
+        pk["wo"], pk["bo"] = wo, bo
+        self._packed = pk
+        return pk
+
+    # ---- reference API ------------------------------------------------------------------------------
+    def get_primary_event(self, batch_size):
+        return torch.full((1, batch_size), self.primary_event, dtype=torch.long, device=self.output_fc.weight.device)
+
+    def init_to_hidden(self, init):
+        """network.py:98-104 (one tiny projection, once per sequence; library op)"""
+        batch_size = init.shape[0]
+        out = self.inithid_fc_activation(self.inithid_fc(init))
+        return out.view(self.rnn_layers, batch_size, self.hidden_dim)
+
+    @torch.no_grad()
+    def _step(self, pk, tok_i32, h32, hbf, xbuf):
+        """event int32 [B] -> logits bf16 [B,Vp]; h32 f32 [layers,B,H] and hbf bf16 [layers,B,H] updated in place"""
+        lib = _load()
+        B, H = tok_i32.numel(), self.hidden_dim
+        check(lib.mgx_gather_rows(ptr(tok_i32), ptr(pk["emb"]), ptr(xbuf), B, pk["Ep"], self.event_dim, stream_ptr()),
+              "mgx_gather_rows")
+        x = xbuf
+        for l, ly in enumerate(pk["layers"]):
+            gi = ops.linear_fwd(x, ly["wih"], ly["bih"], 0)
+            gh = ops.linear_fwd(hbf[l], ly["whh"], ly["bhh"], 0)
+            check(lib.mgx_gru_gates(ptr(gi), ptr(gh), ptr(h32[l]), ptr(hbf[l]), B, H, stream_ptr()), "mgx_gru_gates")
+            x = hbf[l]
+        return ops.linear_fwd(x, pk["wo"], pk["bo"], 0)
+
+    @torch.no_grad()
+    def gen_forward(self, event, hidden=None):
+        """One step (network.py:51-61): event int64 [1,B], hidden [layers,B,H] -> (logits [1,B,V] f32, hidden')"""
+        assert len(event.shape) == 2 and event.shape[0] == 1
+        pk = self._pack()
+        B = event.shape[1]
+        dev = pk["dev"]
+        h32 = (torch.zeros(self.rnn_layers, B, self.hidden_dim, device=dev) if hidden is None
+               else hidden.detach().float().clone().contiguous())
+        hbf = h32.to(BF16).contiguous()
+        xbuf = torch.empty(B, pk["Ep"], dtype=BF16, device=dev)
+        logits = self._step(pk, event[0].to(torch.int32).contiguous(), h32, hbf, xbuf)
+        return logits[:, : self.event_dim].float().unsqueeze(0), h32
+
+    def forward(self, event, hidden=None):
+        return self.gen_forward(event, hidden)
+
+    @torch.no_grad()
+    def Train(self, init, events, lengths=None):
+        """Teacher-forced logits [T+1,B,V] (network.py:63-84,109-116), forward only."""
+        if lengths is not None:
+            raise NotImplementedError("packed variable-length batches are not built")
+        hidden = self.init_to_hidden(init)
+        outs = []
+        ev = self.get_primary_event(init.shape[0])
+        o, hidden = self.gen_forward(ev, hidden)
+        outs.append(o)
+        for t in range(events.shape[0]):
+            o, hidden = self.gen_forward(events[t:t + 1], hidden)
+            outs.append(o)
+        return torch.cat(outs, 0)
+
+    @torch.no_grad()
+    def generate(self, init, steps, events=None, greedy=1.0, temperature=1.0, teacher_forcing_ratio=1.0,
+                 output_type='index', verbose=False, seed=0, use_graph=True):
+        """network.py:119-164.  ``greedy`` is the probability of an arg-max step (host coin per step, as in the
+        reference); otherwise the event is drawn from softmax(logits / temperature) by the fused sampler."""
+        batch_size = init.shape[0]
+        assert init.shape[1] == self.init_dim and steps > 0
+        use_teacher_forcing = events is not None
+        if use_teacher_forcing:
+            assert len(events.shape) == 2 and events.shape[0] >= steps - 1
+            events = events[:steps - 1]
+        pk = self._pack()
+        dev, V = pk["dev"], self.event_dim
+        h32 = self.init_to_hidden(init).detach().float().contiguous().clone()
+        hbf = h32.to(BF16).contiguous()
+        xbuf = torch.empty(batch_size, pk["Ep"], dtype=BF16, device=dev)
+        tok = torch.full((batch_size,), self.primary_event, dtype=torch.int32, device=dev)
+        pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        probs = torch.empty(batch_size, V, device=dev) if output_type == 'softmax' else None
+        rng = np.random.RandomState(seed)
+        coins = rng.random_sample(steps) < greedy
+        tf_coins = rng.random_sample(steps) <= teacher_forcing_ratio
+        outputs = []
+        plain = output_type == 'index' and not use_teacher_forcing
+        out_tokens = torch.zeros(batch_size, steps + 1, dtype=torch.int32, device=dev) if plain else None
+
+        def one(step_greedy):
+            logits = self._step(pk, tok, h32, hbf, xbuf)
+            ops.sample_topk_topp(logits, V, pos, tok, out_tokens, probs, temperature, 1 if step_greedy else 0, 1.0, seed,
+                                 advance=True)
+            return logits
+
+        graphs = {}
+        for step in range(steps):
+            g = bool(coins[step])
+            if plain and use_graph and steps > 8 and step >= 2:
+                if g not in graphs:
+                    torch.cuda.synchronize()
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        gr = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gr, stream=side):
+                            one(g)
+                    torch.cuda.current_stream().wait_stream(side)
+                    graphs[g] = gr
+                graphs[g].replay()
+                continue
+            logits = one(g)
+            if output_type == 'index':
+                outputs.append(tok.clone().long().unsqueeze(0))
+            elif output_type == 'softmax':
+                outputs.append(probs.clone().unsqueeze(0))
+            elif output_type == 'logit':
+                outputs.append(logits[:, :V].float().unsqueeze(0))
+            else:
+                assert False
+            if use_teacher_forcing and step < steps - 1 and tf_coins[step]:
+                tok.copy_(events[step].to(torch.int32))
+        if plain:
+            return out_tokens[:, 1:].t().contiguous().long()
+        return torch.cat(outputs, 0)

@@ -90,3 +90,35 @@ def test_graph_replay_equals_eager_decode():
     assert int(a.max()) < 337 and int(a.min()) >= 0
     with pytest.raises(ValueError):
         mt.generate_cached(prior, 100)          # beyond max_seq: no silent sliding window
+
+
+def test_gru_step_matches_reference_golden(golden_dir):
+    """Event_Melody_RNN (A13): gen_forward chain, init_to_hidden and teacher-forced logits vs golden G8."""
+    import os
+    from musicgeneration_amd.melody_rnn import Event_Melody_RNN
+    g = dict(np.load(os.path.join(golden_dir, "g8_gru.npz")))
+    net = Event_Melody_RNN(init_dim=8, event_dim=40, hidden_dim=64, rnn_layers=2, dropout=0.0)
+    net.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")})   # reference keys
+    net = net.cuda().eval()
+    init = torch.from_numpy(g["init"]).cuda()
+    hid = net.init_to_hidden(init)
+    np.testing.assert_allclose(hid.detach().cpu().numpy(), g["hid0"], rtol=1e-4, atol=1e-5)
+    for s in range(3):
+        o, hid = net.gen_forward(torch.from_numpy(g[f"step{s}_event"]).cuda(), hid)
+        assert np.abs(o.cpu().numpy() - g[f"step{s}_logits"]).max() < 2e-2
+        assert np.abs(hid.cpu().numpy() - g[f"step{s}_hidden"]).max() < 2e-2
+    tl = net.Train(init, torch.from_numpy(g["train_events"]).cuda())
+    assert tl.shape == g["train_logits"].shape
+    assert np.abs(tl.cpu().numpy() - g["train_logits"]).max() < 3e-2
+
+
+def test_gru_generate_graph_equals_eager():
+    from musicgeneration_amd.melody_rnn import Event_Melody_RNN
+    torch.manual_seed(0)
+    net = Event_Melody_RNN(init_dim=32, event_dim=308, hidden_dim=512, rnn_layers=3, dropout=0.3).cuda().eval()
+    init = torch.randn(4, 32, device="cuda")
+    a = net.generate(init, 40, greedy=0.5, temperature=1.2, seed=5, use_graph=True)
+    b = net.generate(init, 40, greedy=0.5, temperature=1.2, seed=5, use_graph=False)
+    assert a.shape == (40, 4) and (a == b).all() and int(a.max()) < 308
+    sm = net.generate(init, 3, greedy=0.0, output_type='softmax')
+    assert sm.shape == (3, 4, 308) and abs(sm.sum(-1) - 1).max().item() < 1e-4
