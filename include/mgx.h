@@ -66,6 +66,11 @@ int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, int B, int L, int pad, vo
  * artefact of -1e9+x in fp32 and is outside the parity contract).                             */
 int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                      uint16_t* ctx, float* lse, int B, int L, int d, int M, void* stream);
+/* eval/debug output of the reference (`attention_weights`, layers.py:102,109): weights f32 [B,h,L,L] =
+ * softmax rows recomputed from qkv and the lse of mgx_rel_attn_fwd.  The caller zero-fills `weights`
+ * first (tiles above the diagonal are not visited); masked entries inside visited tiles are written as 0. */
+int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const float* lse,
+                         float* weights, int B, int L, int d, int M, void* stream);
 /* backward of the above (autograd of layers.py:86-106).  dctx bf16 [B,L,d] -> dqkv bf16 [B,L,3d];
  * dE f32 [M,64] is ACCUMULATED into (caller zeroes it once per optimiser step).
  * workspace: caller-provided scratch, 256-byte aligned, >= mgx_rel_attn_bwd_workspace(B,L,d) bytes

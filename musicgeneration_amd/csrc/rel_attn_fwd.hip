@@ -27,10 +27,14 @@ constexpr int OFF_BAND = OFF_V + 2 * TILE_BYTES;       // 4 x (32 rows x 272 B) 
 constexpr int LDS_BYTES = OFF_BAND + WAVES * BAND_BYTES;    // 51,200 B -> 3 workgroups per CU
 }  // namespace
 
+// WRITE_W = false: the training/inference forward (ctx + lse).
+// WRITE_W = true : debug/eval output of the reference (layers.py:102,109): the same sweep recomputes S and
+//                  writes weights[b,h,i,j] = exp(S - lse_i) (fp32, caller pre-zeroes the future triangle).
+template <bool WRITE_W>
 __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er /* = E + (M-L)*64 */,
     const uint32_t* __restrict__ padbits, uint16_t* __restrict__ ctx, float* __restrict__ lse_out,
-    int L, int d) {
+    const float* __restrict__ lse_in, float* __restrict__ weights, int L, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,6 +108,8 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
 
     f32x16 o0 = zero16(), o1 = zero16();
     float m_run = -INFINITY, l_run = 0.f;
+    float lse2w = 0.f;
+    if (WRITE_W && wave_on) lse2w = lse_in[((size_t)b * heads + hd) * L + i0 + a] * LOG2E;
 
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
@@ -157,6 +163,20 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
                         c[r] = ((pw >> crow(r, hh)) & 1u) ? ((c[r] == -INFINITY) ? c[r] : PAD_NEG) : c[r];
                 }
             }
+            if (WRITE_W) {
+                // weights[b,h,i0+a, j0 + 8*g4 + 4*hh + k] = exp(S - lse); masked entries are exactly 0
+                float* wrow = weights + (((size_t)b * heads + hd) * L + i0 + a) * L + 32 * s + 4 * hh;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sv = c[4 * g4 + k];
+                        v[k] = (sv <= PAD_NEG) ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sv, LOG2E, -lse2w));
+                    }
+                    *(f32x4*)(wrow + 8 * g4) = v;
+                }
+            } else {
             // ---- online softmax (keys on registers + lane half, queries on lanes) ----------------
             float tmax = c[0];
 #pragma unroll
@@ -185,6 +205,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
                 o0 = mfma(frag_T(vt, lane, ss, 0), pf, o0);
                 o1 = mfma(frag_T(vt, lane, ss, 1), pf, o1);
             }
+            }   // !WRITE_W
         }
         // ---- publish the prefetched tiles into the other buffers ---------------------------------
         if (have_next) {
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     }
 
     // ---- epilogue: ctx[b, i0+a, hd*64 + c] = O^T[c][a] / l ; lse = m + ln l ---------------------
-    if (wave_on) {
+    if (!WRITE_W && wave_on) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.f / l_tot;
         uint16_t* op = ctx + ((size_t)b * L + i0 + a) * d + hd * 64 + 4 * hh;
@@ -212,20 +233,37 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     }
 }
 
+static void set_fwd_attrs() {
+    static bool attr_set = false;
+    if (attr_set) return;
+    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+}
+
 extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
                                 float* lse, int B, int L, int d, int M, void* stream) {
     MGX_REQUIRE(qkv && E && ctx && lse, MGX_ERR_NULL, "mgx_rel_attn_fwd: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
                 "mgx_rel_attn_fwd: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
     MGX_REQUIRE((L + 127) / 128 <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_fwd: L too large");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)rel_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    set_fwd_attrs();
     dim3 grid(B * (d / 64), (L + 127) / 128);
-    hipLaunchKernelGGL(rel_attn_fwd_kernel, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
-                       E + (size_t)(M - L) * 64, padbits, ctx, lse, L, d);
+    hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
+                       E + (size_t)(M - L) * 64, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");
+    return MGX_OK;
+}
+
+extern "C" int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const float* lse,
+                                    float* weights, int B, int L, int d, int M, void* stream) {
+    MGX_REQUIRE(qkv && E && lse && weights, MGX_ERR_NULL, "mgx_rel_attn_weights: NULL pointer");
+    MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
+                "mgx_rel_attn_weights: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
+    set_fwd_attrs();
+    dim3 grid(B * (d / 64), (L + 127) / 128);
+    hipLaunchKernelGGL(rel_attn_fwd_kernel<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
+                       E + (size_t)(M - L) * 64, padbits, (uint16_t*)nullptr, (float*)nullptr, lse, weights, L, d);
+    MGX_CHECK_LAUNCH("mgx_rel_attn_weights");
     return MGX_OK;
 }

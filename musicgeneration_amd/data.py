@@ -87,3 +87,66 @@ class Data:
     def slide_seq2seq_batch(self, batch_size, length, mode='train'):
         data = self.batch(batch_size, length + 1, mode)
         return data[:, :-1], data[:, 1:]
+
+
+# --------------------------------------------------------------------------------------------------
+# GRU feeder: mirror of mg/model/utils/data.py:23-47 (SeqBatchify, MyDataset) and :49-123 (Event_Dataset)
+# --------------------------------------------------------------------------------------------------
+def SeqBatchify(inputs):
+    """sort by length (desc), zero-pad to the longest -> (X int16 [B,Tmax], Y = concat of X[i,1:len_i], lengths)"""
+    inputs = sorted(inputs, key=lambda i: len(i), reverse=True)
+    lengths = np.array([len(item) for item in inputs])
+    mx_length = np.max(lengths)
+    X = np.zeros((len(inputs), mx_length), dtype=np.int16)
+    for i in range(len(inputs)):
+        X[i, :lengths[i]] = np.array(inputs[i])
+    Y = np.concatenate([np.array(X[i])[1:lengths[i]] for i in range(len(inputs))])
+    return X, Y, lengths
+
+
+class MyDataset(torch.utils.data.Dataset):
+    def __init__(self, seqs):
+        self.seqs = seqs
+
+    def __getitem__(self, index):
+        return self.seqs[index]
+
+    def __len__(self):
+        return len(self.seqs)
+
+
+class Event_Dataset:
+    """All ``*.data`` arrays with len >= limlen, held in RAM; window index + time-major collate."""
+
+    def __init__(self, root, limlen=None, verbose=False):
+        import os
+        assert os.path.isdir(root), root
+        self.root = root
+        self.samples = []
+        self.seqlens = []
+        for path in utils.find_files_by_extensions(root, ['.data']):
+            eventseq, n = _load_array(path)
+            if eventseq is not None and n >= (limlen or 0):
+                self.samples.append(eventseq)
+                self.seqlens.append(n)
+        self.avglen = np.mean(self.seqlens) if self.seqlens else 0.0
+
+    def count(self, v):
+        a = sorted(self.seqlens)
+        x = int(np.searchsorted(a, v, side='left'))
+        return 100 * x / len(a)
+
+    def batches(self, batch_size, window_size, stride_size):
+        """list of (file index, (start, end)) windows            utils/data.py:74-78"""
+        return [(i, (j, j + window_size))
+                for i, seqlen in enumerate(self.seqlens)
+                for j in range(0, seqlen - window_size, stride_size)]
+
+    def SegBatchify(self, data):
+        """collate -> np [T, B] (time-major)                      utils/data.py:104-114"""
+        return np.stack([self.samples[i][start:end] for i, (start, end) in data], axis=1)
+
+    Batchify = SegBatchify
+
+    def __repr__(self):
+        return (f'Dataset(root="{self.root}", samples={len(self.samples)}, avglen={self.avglen})')

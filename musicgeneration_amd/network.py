@@ -82,7 +82,7 @@ class MusicTransformer(torch.nn.Module):
     # ------------------------------------------------------------------------------------------
     # the hot path: tokens -> logits                 network.py:37-39 + layers.py:223-233,152-161
     # ------------------------------------------------------------------------------------------
-    def _logits(self, x: torch.Tensor) -> torch.Tensor:
+    def _logits(self, x: torch.Tensor, wsink: Optional[list] = None) -> torch.Tensor:
         st = self.store()
         st.sync_shadow()
         training = self.training and torch.is_grad_enabled()
@@ -111,7 +111,7 @@ class MusicTransformer(torch.nn.Module):
             gbqkv = st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "grad").view(3 * d)
             # the layer's bucket is complete when its first op (QKV projection) has run its backward
             qkv = ops.linear(h, P[pre + "rga.Wq.weight"], wqkv, bqkv, 0, gqkv, gbqkv, done(f"layer{i}"))
-            ctx = ops.rel_attn(qkv, P[pre + "rga.E"], st.w(pre + "rga.E"), padbits, st.g(pre + "rga.E"))
+            ctx = ops.rel_attn(qkv, P[pre + "rga.E"], st.w(pre + "rga.E"), padbits, st.g(pre + "rga.E"), wsink)
             # the bias gradients of `fc` and `FFN_suf` are column sums of the LayerNorm backward's dx: that kernel
             # emits them (gb=None here)
             a = ops.linear(ctx, P[pre + "rga.fc.weight"], st.w(pre + "rga.fc.weight"), P[pre + "rga.fc.bias"].data,
@@ -135,12 +135,13 @@ class MusicTransformer(torch.nn.Module):
 
     def forward(self, x, length=None, writer=None):
         if self.training or not self.infer:
-            logits = self._logits(x)
             if self.training:
-                return logits
-            if self.return_attention_weights:
-                raise NotImplementedError("materialised [B,h,L,L] attention weights are not built yet")
-            return logits, []
+                return self._logits(x)
+            # eval: (logits, [attention_weights per layer]) as network.py:40.  The [B,h,L,L] fp32 weights are a
+            # debug output (268 MB per layer at cfg2, B=2): they are materialised only on request.
+            ws = [] if self.return_attention_weights else None
+            logits = self._logits(x, ws)
+            return logits, (ws if ws is not None else [])
         return self.generate(x, length, None).contiguous().tolist()
 
     # ------------------------------------------------------------------------------------------

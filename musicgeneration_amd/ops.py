@@ -68,6 +68,17 @@ def rel_attn_fwd(qkv, E, padbits, M=None) -> Tuple[torch.Tensor, torch.Tensor]:
     return ctx, lse
 
 
+def rel_attn_weights(qkv, E, padbits, lse) -> torch.Tensor:
+    """materialised attention weights f32 [B,h,L,L] (eval/debug output of the reference)"""
+    _need_cuda(qkv, E, padbits, lse)
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    w = torch.zeros(B, d // 64, L, L, dtype=torch.float32, device=qkv.device)
+    check(_lib.load().mgx_rel_attn_weights(ptr(qkv), ptr(E), ptr(padbits), ptr(lse), ptr(w), B, L, d, E.shape[0],
+                                           stream_ptr()), "mgx_rel_attn_weights")
+    return w
+
+
 def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None) -> torch.Tensor:
     """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench)."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
@@ -241,10 +252,12 @@ class _RelAttn(torch.autograd.Function):
     """K3+K4 (+K4b): fused relative attention over a fused qkv projection.   layers.py:86-106"""
 
     @staticmethod
-    def forward(ctx, qkv, E_master, E_shadow, padbits, gE):
+    def forward(ctx, qkv, E_master, E_shadow, padbits, gE, wsink):
         out, lse = rel_attn_fwd(qkv, E_shadow, padbits)
         ctx.save_for_backward(qkv, E_shadow, out, lse)
         ctx.cfg = (padbits, gE)
+        if wsink is not None:        # eval-mode debug output: materialise this layer's [B,h,L,L] weights
+            wsink.append(rel_attn_weights(qkv, E_shadow, padbits, lse))
         return out
 
     @staticmethod
@@ -252,7 +265,7 @@ class _RelAttn(torch.autograd.Function):
         qkv, E_shadow, out, lse = ctx.saved_tensors
         padbits, gE = ctx.cfg
         dqkv = rel_attn_bwd(qkv, E_shadow, padbits, out, dctx.contiguous(), lse, gE)
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class _AddLN(torch.autograd.Function):
@@ -325,8 +338,8 @@ def embed_pe(tok, table, pe, p_drop=0.0, seed=0, gtable=None, done=None):
     return _EmbedPE.apply(tok, table, pe, float(p_drop), int(seed), gtable, done)
 
 
-def rel_attn(qkv, E_master, E_shadow, padbits, gE):
-    return _RelAttn.apply(qkv, E_master, E_shadow, padbits, gE)
+def rel_attn(qkv, E_master, E_shadow, padbits, gE, wsink=None):
+    return _RelAttn.apply(qkv, E_master, E_shadow, padbits, gE, wsink)
 
 
 def add_ln(x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta, gxbias=None):

@@ -106,3 +106,19 @@ def test_mask_helper_matches_golden(golden_dir):
     assert (m.numpy() == g["mask"]).all()
     from musicgeneration_amd.layers import sinusoid
     np.testing.assert_allclose(sinusoid(8, 16), g["pe"], rtol=0, atol=1e-12)
+
+
+def test_event_dataset_and_seqbatchify(tmp_path):
+    from musicgeneration_amd.data import Event_Dataset, MyDataset, SeqBatchify
+    _make_dataset(str(tmp_path))
+    ds = Event_Dataset(str(tmp_path), limlen=40)
+    assert len(ds.samples) == 7 and min(ds.seqlens) == 40           # the dict file and the short files are skipped
+    idx = ds.batches(4, 16, 8)
+    assert all(e - s == 16 for _, (s, e) in idx) and len(idx) == 4 * 3 + 3 * 8
+    batch = ds.SegBatchify(idx[:5])
+    assert batch.shape == (16, 5)
+    assert (batch[:, 0] == ds.samples[idx[0][0]][idx[0][1][0]:idx[0][1][1]]).all()
+    assert len(MyDataset(idx)) == len(idx) and MyDataset(idx)[3] == idx[3]
+    X, Y, lengths = SeqBatchify([[1, 2, 3], [4, 5, 6, 7, 8], [9]])
+    assert lengths.tolist() == [5, 3, 1] and X.shape == (3, 5) and X.dtype == np.int16
+    assert Y.tolist() == [5, 6, 7, 8, 2, 3]
