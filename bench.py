@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "rehearsing the data-parallel path with several ranks on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="all ranks use cuda:0 (rehearsal with --backend gloo)")
     return ap.parse_args()
 
 
@@ -135,12 +138,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
     from musicgeneration_amd.dp import DataParallel
@@ -206,6 +214,9 @@ def main():
                    "final_loss": loss_val},
         "model_mfma_frac": value * train_flops_per_event(nl, d, L, V) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
+    if world > 1:
+        out["dp"] = {"backend": args.backend, "buckets": len(mt.store().buckets),
+                     "allreduce_bytes_per_step": dp.bytes_reduced // max(1, args.warmup + args.steps)}
     if rank == 0 and not args.no_kernel_timing:
         kt = time_kernels(B, L, d, L)
         units = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 2.5, "rel_attn_dkv_kernel": 2.5,

@@ -297,20 +297,32 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
 }
 
 // out[k*d + col] += sum_b partial[b][k*d + col], k = 0 (dgamma), 1 (dbeta), 2 (dxsum)
+// block = 16 columns x 16 block-groups; every thread keeps 8 independent loads in flight.
 __global__ __launch_bounds__(256) void ln_finish_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, float* __restrict__ dxsum, int nblk,
                                                         int d) {
-    const int idx = blockIdx.x * 64 + (threadIdx.x & 63);      // column within [0, 3d)
-    const int part = threadIdx.x >> 6;                          // 4 row-groups of blocks
-    __shared__ float red[4][64];
-    float s = 0.f;
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + cl;                       // column within [0, 3d)
     const int ncol = dxsum ? 3 * d : 2 * d;
-    if (idx < ncol)
-        for (int bb = part; bb < nblk; bb += 4) s += partial[(size_t)bb * 3 * d + idx];
-    red[part][threadIdx.x & 63] = s;
+    __shared__ float red[16][17];
+    float s = 0.f;
+    if (idx < ncol) {
+        int bb = part;
+        for (; bb + 7 * 16 < nblk; bb += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(bb + 16 * u) * 3 * d + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; bb < nblk; bb += 16) s += partial[(size_t)bb * 3 * d + idx];
+    }
+    red[part][cl] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && idx < ncol) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (threadIdx.x < 16 && idx < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
         float* dst = idx < d ? dgamma + idx : (idx < 2 * d ? dbeta + (idx - d) : dxsum + (idx - 2 * d));
         *dst += t;
     }
@@ -384,7 +396,7 @@ extern "C" int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uin
         case 3: launch_ln_bwd<3>(dout, x, res, gamma, mean, rstd, dx, dres, partial, grid, rows, d, dc, wd, s); break;
         default: launch_ln_bwd<4>(dout, x, res, gamma, mean, rstd, dx, dres, partial, grid, rows, d, dc, wd, s); break;
     }
-    hipLaunchKernelGGL(ln_finish_kernel, dim3((3 * d + 63) / 64), dim3(256), 0, s, partial, dgamma, dbeta, dxsum, grid, d);
+    hipLaunchKernelGGL(ln_finish_kernel, dim3((3 * d + 15) / 16), dim3(256), 0, s, partial, dgamma, dbeta, dxsum, grid, d);
     MGX_CHECK_LAUNCH("mgx_add_ln_bwd");
     return MGX_OK;
 }
