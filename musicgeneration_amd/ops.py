@@ -79,8 +79,21 @@ def rel_attn_weights(qkv, E, padbits, lse) -> torch.Tensor:
     return w
 
 
-def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None) -> torch.Tensor:
-    """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench)."""
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev):
+    ss = _SIDE_STREAMS.get(dev)
+    if ss is None:
+        ss = _SIDE_STREAMS[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return ss
+
+
+def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None, concurrent=None) -> torch.Tensor:
+    """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench).
+    concurrent (default: on for the full backward): the three owner kernels (dQ / dK+dV / dE) are independent
+    once the pre-pass (delta, E transpose) has run, so they are launched on three streams -- their tails
+    overlap and one block of each fits a CU's LDS together."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
     B, L, d3 = qkv.shape
     d = d3 // 3
@@ -89,9 +102,25 @@ def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, works
     need = lib.mgx_rel_attn_bwd_workspace(B, L, d)
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=qkv.device)
-    check(lib.mgx_rel_attn_bwd_parts(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dE),
-                                     ptr(workspace), workspace.numel(), B, L, d, E.shape[0], int(parts), stream_ptr()),
-          "mgx_rel_attn_bwd")
+    args = (ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dE), ptr(workspace),
+            workspace.numel(), B, L, d, E.shape[0])
+    if concurrent is None:
+        concurrent = (parts == 15) and not torch.cuda.is_current_stream_capturing()
+    if not concurrent:
+        check(lib.mgx_rel_attn_bwd_parts(*args, int(parts), stream_ptr()), "mgx_rel_attn_bwd")
+        return dqkv
+    main = torch.cuda.current_stream()
+    s1, s2 = _side_streams(qkv.device)
+    check(lib.mgx_rel_attn_bwd_parts(*args, 1, main.cuda_stream), "mgx_rel_attn_bwd(pre)")
+    ready = torch.cuda.Event()
+    ready.record(main)
+    s1.wait_event(ready)
+    s2.wait_event(ready)
+    check(lib.mgx_rel_attn_bwd_parts(*args, 8, s2.cuda_stream), "mgx_rel_attn_bwd(dE)")      # longest first
+    check(lib.mgx_rel_attn_bwd_parts(*args, 4, s1.cuda_stream), "mgx_rel_attn_bwd(dKV)")
+    check(lib.mgx_rel_attn_bwd_parts(*args, 2, main.cuda_stream), "mgx_rel_attn_bwd(dQ)")
+    main.wait_stream(s1)
+    main.wait_stream(s2)
     return dqkv
 
 
