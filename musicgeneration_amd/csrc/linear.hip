@@ -94,7 +94,8 @@ MGX_DEV void zero_acc(f32x16 (&acc)[2][2]) {
 // =================================================================================================
 // forward (NT)
 // =================================================================================================
-__global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __restrict__ A,
+template <bool DBUF>
+__global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uint16_t* __restrict__ A,
                                                             const uint16_t* __restrict__ W,
                                                             const float* __restrict__ bias,
                                                             uint16_t* __restrict__ C, int M, int N, int K, int act) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __re
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = DBUF ? (kt & 1) : 0;
         if (kt + 1 < nk) load_tiles((kt + 1) * BK);
         const char* at = smem + cur * 2 * IMG;
         const char* wt = at + IMG;
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(const uint16_t* __re
             acc[1][0] = mfma(b0, a1, acc[1][0]);
             acc[1][1] = mfma(b1, a1, acc[1][1]);
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        if (!DBUF) __syncthreads();                 // single buffer: everyone has read the tile before it is replaced
+        if (kt + 1 < nk) store_tiles(DBUF ? (cur ^ 1) : 0);
         __syncthreads();
     }
     store_tileT(C, nullptr, acc, bias, act, m0 + 64 * wm, n0 + 64 * wn, M, N, l31, hh);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict_
 static bool g_attr_set = false;
 static void set_attrs() {
     if (g_attr_set) return;
-    hipFuncSetAttribute((const void*)linear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     g_attr_set = true;
@@ -364,8 +366,17 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
     MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
     set_attrs();
     const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, A, W, bias, C, M, N,
-                       K, act);
+    // Large grids (>= 3 workgroups per CU) run the single-LDS-buffer variant: 32 KiB -> 3 workgroups/CU
+    // (+8 % on the QKV projection); small grids keep the double-buffered one (one barrier per step).
+    static int sbuf_env = -2;
+    if (sbuf_env == -2) { const char* e = getenv("MGX_GEMM_SINGLE_BUF"); sbuf_env = e ? atoi(e) : -1; }
+    const bool sbuf = sbuf_env >= 0 ? (sbuf_env != 0) : (nwg >= 768);
+    if (sbuf)
+        hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3(nwg), dim3(256), LDS_BYTES / 2, (hipStream_t)stream, A, W, bias, C,
+                           M, N, K, act);
+    else
+        hipLaunchKernelGGL(linear_fwd_kernel<true>, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, A, W, bias, C, M,
+                           N, K, act);
     MGX_CHECK_LAUNCH("mgx_linear_fwd");
     return MGX_OK;
 }
