@@ -321,6 +321,57 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
     }
 }
 
+// =================================================================================================
+// skinny forward (M <= 32: the decode path's projections).  The weights are streamed exactly once:
+// workgroup = 32 output columns, its 4 waves split K; W rows and x rows go straight from global/L2 into
+// MFMA fragments (no LDS staging, no barriers in the loop); the four partial tiles are combined in LDS.
+//   D[n][m] = sum_k W[n][k] x[m][k]   (A = W rows, B = x^T)
+// =================================================================================================
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                            const float* __restrict__ bias, uint16_t* __restrict__ C,
+                                                            int M, int N, int K, int act) {
+    __shared__ float part[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int kq = K >> 2;                                   // K per wave (multiple of 16)
+    const int nrow = n0 + l31, mrow = l31;
+    const bool nv = nrow < N, mv = mrow < M;
+    const uint16_t* wp = W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    const uint16_t* xp = A + (size_t)(mv ? mrow : 0) * K + w * kq + hh * 8;
+    f32x16 acc = zero16();
+    for (int k0 = 0; k0 < kq; k0 += 64) {                    // 4 k-steps per iteration, 8 loads in flight
+        u32x4 wf[4], xf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bool in = k0 + 16 * ks < kq;
+            wf[ks] = (nv && in) ? *(const u32x4*)(wp + k0 + 16 * ks) : u32x4{0, 0, 0, 0};
+            xf[ks] = (mv && in) ? *(const u32x4*)(xp + k0 + 16 * ks) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            acc = mfma(__builtin_bit_cast(bf16x8, wf[ks]), __builtin_bit_cast(bf16x8, xf[ks]), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[w][crow(r, hh)][l31] = acc[r];      // [n][m]
+    __syncthreads();
+    // thread -> (n = tid >> 3, 4 consecutive m)
+    const int n = tid >> 3, m4 = (tid & 7) * 4;
+    if (n0 + n < N) {
+        const float bv = bias ? bias[n0 + n] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m4 + k;
+            if (m < M) {
+                float v = part[0][n][m] + part[1][n][m] + part[2][n][m] + part[3][n][m] + bv;
+                if (act == 1) v = fmaxf(v, 0.f);
+                C[(size_t)m * N + n0 + n] = f32_to_bf16(v);
+            }
+        }
+    }
+}
+
 // gb[n] += sum_m dY[m][n]      thread = 8 columns, rows strided over gridDim.y * 32 row-lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ dY, float* __restrict__ gb, int M,
                                                      int N) {
@@ -365,6 +416,12 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
                 "mgx_linear_fwd: need K%%64==0 and N%%4==0 (got M=%d N=%d K=%d)", M, N, K);
     MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
     set_attrs();
+    if (M <= 32) {      // decode-size batches: weight-streaming skinny kernel
+        hipLaunchKernelGGL(linear_skinny_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, W, bias, C, M, N,
+                           K, act);
+        MGX_CHECK_LAUNCH("mgx_linear_fwd");
+        return MGX_OK;
+    }
     const int nwg = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     // Large grids (>= 3 workgroups per CU) run the single-LDS-buffer variant: 32 KiB -> 3 workgroups/CU
     // (+8 % on the QKV projection); small grids keep the double-buffered one (one barrier per step).
