@@ -219,17 +219,32 @@ def main():
                      "allreduce_bytes_per_step": dp.bytes_reduced // max(1, args.warmup + args.steps)}
     if rank == 0 and not args.no_kernel_timing:
         kt = time_kernels(B, L, d, L)
-        units = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 2.5, "rel_attn_dkv_kernel": 2.5,
-                 "rel_attn_de_kernel": 1.0}
-        dom = max(units, key=lambda k: kt[k])
-        ach = attn_flops_per_launch(B, L, d, units[dom]) / (kt[dom] * 1e-3) / 1e12
+        # credited (algorithmic) and executed product-units per kernel; 1 unit = B*L^2*d FLOPs
+        credited = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 2.5, "rel_attn_dkv_kernel": 2.5,
+                    "rel_attn_de_kernel": 1.0}
+        executed = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 5.0, "rel_attn_dkv_kernel": 6.0,
+                    "rel_attn_de_kernel": 6.0}
+        per_kernel = {k: {"ms": kt[k], "credited_tflops": attn_flops_per_launch(B, L, d, credited[k]) / (kt[k] * 1e-3) / 1e12,
+                          "executed_tflops": attn_flops_per_launch(B, L, d, executed[k]) / (kt[k] * 1e-3) / 1e12}
+                      for k in credited}
+        # the dominant launch of the step is the attention backward (ONE C-ABI call, mgx_rel_attn_bwd =
+        # delta/transposed-E pre-pass + dQ + dK/dV + dE kernels): 6 credited units per launch
+        bwd_ms = kt["attn_delta_kernel"] + kt["rel_attn_dq_kernel"] + kt["rel_attn_dkv_kernel"] + kt["rel_attn_de_kernel"]
+        fwd_ms = kt["rel_attn_fwd_kernel"]
+        dom, dom_ms, dom_units, dom_exec = (("mgx_rel_attn_bwd (pre-pass + dq + dkv + de kernels)", bwd_ms, 6.0, 17.0)
+                                            if bwd_ms >= fwd_ms else ("rel_attn_fwd_kernel", fwd_ms, 3.0, 3.0))
+        ach = attn_flops_per_launch(B, L, d, dom_units) / (dom_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                           "launch_ms": kt[dom], "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, units[dom])}
+                           "launch_ms": dom_ms, "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, dom_units),
+                           "executed_tflops": attn_flops_per_launch(B, L, d, dom_exec) / (dom_ms * 1e-3) / 1e12,
+                           "executed_frac": attn_flops_per_launch(B, L, d, dom_exec) / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
         out["kernel_ms"] = kt
+        out["attention_kernels"] = per_kernel
         out["attention_all_kernels"] = {
             "ms_per_layer": sum(kt.values()),
-            "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12}
+            "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12,
+            "executed_tflops": attn_flops_per_launch(B, L, d, 20.0) / (sum(kt.values()) * 1e-3) / 1e12}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
