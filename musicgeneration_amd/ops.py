@@ -80,6 +80,7 @@ def rel_attn_weights(qkv, E, padbits, lse) -> torch.Tensor:
 
 
 _SIDE_STREAMS = {}
+_CONCURRENT_BWD = __import__("os").environ.get("MGX_CONCURRENT_BWD", "0") == "1"
 
 
 def _side_streams(dev):
@@ -91,9 +92,9 @@ def _side_streams(dev):
 
 def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None, concurrent=None) -> torch.Tensor:
     """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench).
-    concurrent (default: on for the full backward): the three owner kernels (dQ / dK+dV / dE) are independent
-    once the pre-pass (delta, E transpose) has run, so they are launched on three streams -- their tails
-    overlap and one block of each fits a CU's LDS together."""
+    concurrent (opt-in, MGX_CONCURRENT_BWD=1): the three owner kernels (dQ / dK+dV / dE) are independent once
+    the pre-pass (delta, E transpose) has run, so they can be launched on three streams (their tails overlap;
+    measured +1 % end to end).  Default is one stream, which keeps per-kernel profiles comparable."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
     B, L, d3 = qkv.shape
     d = d3 // 3
@@ -105,7 +106,7 @@ def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, works
     args = (ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(dctx), ptr(lse), ptr(dqkv), ptr(dE), ptr(workspace),
             workspace.numel(), B, L, d, E.shape[0])
     if concurrent is None:
-        concurrent = (parts == 15) and not torch.cuda.is_current_stream_capturing()
+        concurrent = (_CONCURRENT_BWD and parts == 15 and not torch.cuda.is_current_stream_capturing())
     if not concurrent:
         check(lib.mgx_rel_attn_bwd_parts(*args, int(parts), stream_ptr()), "mgx_rel_attn_bwd")
         return dqkv
