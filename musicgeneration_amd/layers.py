@@ -161,11 +161,16 @@ class FlatStore:
     # ---- shadow / grad maintenance ------------------------------------------------------------------
     def sync_shadow(self, force=False):
         """Re-round the bf16 shadow if the fp32 parameters were modified by anything but our Adam kernel
-        (torch in-place ops bump the version counter shared by all views of ``param``)."""
-        v = self.param._version
+        (torch in-place ops bump the version counter of the parameter they touch)."""
+        v = self._versions()
         if force or v != self._synced_version:
             ops.cast_bf16(self.param, self.shadow)
-            self._synced_version = self.param._version
+            self._synced_version = self._versions()
+
+    def _versions(self):
+        # ``p.data = view`` keeps the Parameter's OWN version counter (it is not shared with the flat base),
+        # so in-place updates by torch optimizers / load_state_dict show up per parameter.
+        return self.param._version + sum(p._version for p in self.params.values())
 
     def attach_grads(self):
         """``optimizer.zero_grad(set_to_none=True)`` drops our views: re-attach (and zero) them."""
