@@ -131,6 +131,25 @@ def cpu_baseline(args):
                       f"(oracle/ref_cpu.py CpuTrainer, eager PyTorch fp32, {ncores} threads, {t_used:.1f} s)"}
 
 
+def pmc_traffic(dom, B, L, d):
+    """HBM bytes per launch of the dominant op from the committed PMC passes (tools/traffic.sh: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
+    Only reported when this run has the shape the counters were collected on (cfg2, per-GPU batch 16)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_cfg2_b16.json")
+    if not os.path.exists(path) or (B, L, d) != (16, 2048, 512):
+        return {"traffic": None}
+    k = json.load(open(path))["kernels"]
+    names = (["attn_delta_kernel", "er_transpose_kernel", "rel_attn_dq_kernel", "rel_attn_dkv_kernel", "rel_attn_de_kernel"]
+             if dom.startswith("mgx_rel_attn_bwd") else ["void rel_attn_fwd_kernel<false>"])
+    if any(n not in k for n in names):
+        return {"traffic": None}
+    tr = sum(k[n]["hbm_bytes_per_launch"] for n in names)
+    # algorithmic bytes: bf16 Q,K,V,O(,dO) in + O (or dQ,dK,dV) out, E and dE are 256 KiB and ignored
+    nbuf = 8 if dom.startswith("mgx_rel_attn_bwd") else 4
+    return {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b16.json)",
+            "algorithmic_bytes_per_launch": nbuf * B * L * d * 2}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,6 +258,7 @@ def main():
                            "launch_ms": dom_ms, "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, dom_units),
                            "executed_tflops": attn_flops_per_launch(B, L, d, dom_exec) / (dom_ms * 1e-3) / 1e12,
                            "executed_frac": attn_flops_per_launch(B, L, d, dom_exec) / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+        out["roofline"].update(pmc_traffic(dom, B, L, d))
         out["kernel_ms"] = kt
         out["attention_kernels"] = per_kernel
         out["attention_all_kernels"] = {

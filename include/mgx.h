@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend */
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -132,10 +132,12 @@ int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint
 
 /* backward of the above (autograd of the same reference lines):
  * dX bf16 [M,K] = dY bf16 [M,N] @ W bf16 [N,K]; if relu_y (bf16 [M,K]) is given, dX is zeroed where
- * relu_y <= 0 (the backward of a ReLU fused into the producer of this layer's input).
+ * relu_y <= 0 (the backward of a ReLU fused into the producer of this layer's input); if addend
+ * (bf16 [M,K]) is given it is added last -- the gradient arriving over the residual connection
+ * (layers.py:155,160: out = LN(x + branch(x))) joins the branch's input gradient without a separate pass.
  * N % 8 == 0, K % 8 == 0.                                                                         */
-int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y, uint16_t* dX,
-                  int M, int N, int K, void* stream);
+int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y, const uint16_t* addend,
+                  uint16_t* dX, int M, int N, int K, void* stream);
 /* gW f32 [N,K] += dY^T @ X (dY bf16 [M,N], X bf16 [M,K]); gb f32 [N] += column sums of dY (or NULL).
  * Both ACCUMULATE (fp32 atomics), so gradient accumulation over micro-batches needs no extra pass. */
 int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, float* gb,

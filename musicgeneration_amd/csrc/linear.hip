@@ -47,7 +47,8 @@ MGX_DEV bf16x8 fragTn(const char* tile, int lane, int ks, int ct) {
 // [nb + 32*ct + crow(r,hh)].  Registers 4*g4 .. 4*g4+3 are 4 consecutive columns -> one 8-byte store.
 // Optional fused bias (per column), ReLU, and ReLU-backward mask (zero where relu_y <= 0).  N % 4 == 0.
 MGX_DEV void store_tileT(uint16_t* __restrict__ C, const uint16_t* __restrict__ relu_y, const f32x16 (&acc)[2][2],
-                         const float* __restrict__ bias, int act, int mb, int nb, int M, int N, int l31, int hh) {
+                         const float* __restrict__ bias, int act, int mb, int nb, int M, int N, int l31, int hh,
+                         const uint16_t* __restrict__ addend = nullptr) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int m = mb + 32 * rt + l31;
@@ -75,6 +76,10 @@ MGX_DEV void store_tileT(uint16_t* __restrict__ C, const uint16_t* __restrict__ 
                     if (!(bf16hi(y.x) > 0.f)) v[1] = 0.f;
                     if (!(bf16lo(y.y) > 0.f)) v[2] = 0.f;
                     if (!(bf16hi(y.y) > 0.f)) v[3] = 0.f;
+                }
+                if (addend) {                  // residual-branch gradient joins here (saves an elementwise pass)
+                    const u32x2 a = *(const u32x2*)(addend + (size_t)m * N + n);
+                    v[0] += bf16lo(a.x); v[1] += bf16hi(a.x); v[2] += bf16lo(a.y); v[3] += bf16hi(a.y);
                 }
                 u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2*)(C + (size_t)m * N + n) = o;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
 }
 
 // =================================================================================================
-// dX = dY W   (NN; optional epilogue mask: dX *= (relu_y > 0), the backward of a fused ReLU)
+// dX = dY W   (NN; optional epilogue: dX *= (relu_y > 0), the backward of a fused ReLU; then dX += addend)
 //   tile: 128 rows m x 128 cols k', reduction over n in steps of 64
 //   LDS:  dY tile [128 m][64 n] image R;  W tile [64 n][128 k'] as 4 sub-tiles (2 n-blocks x 2 col halves)
 //         of [32][64] image T
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
 __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __restrict__ dY,
                                                            const uint16_t* __restrict__ W,
                                                            const uint16_t* __restrict__ relu_y,
+                                                           const uint16_t* __restrict__ addend,
                                                            uint16_t* __restrict__ dX, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
         if (nt + 1 < nn) store_tiles(cur ^ 1);
         __syncthreads();
     }
-    store_tileT(dX, relu_y, acc, nullptr, 0, m0 + 64 * wm, k0 + 64 * wn, M, K, l31, hh);
+    store_tileT(dX, relu_y, acc, nullptr, 0, m0 + 64 * wm, k0 + 64 * wn, M, K, l31, hh, addend);
 }
 
 // =================================================================================================
@@ -438,15 +444,15 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
     return MGX_OK;
 }
 
-extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y, uint16_t* dX, int M, int N,
-                             int K, void* stream) {
+extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y, const uint16_t* addend,
+                             uint16_t* dX, int M, int N, int K, void* stream) {
     MGX_REQUIRE(dY && W && dX, MGX_ERR_NULL, "mgx_linear_dx: NULL pointer");
     MGX_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, MGX_ERR_SHAPE,
                 "mgx_linear_dx: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
     set_attrs();
     const int nwg = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
-    hipLaunchKernelGGL(linear_dx_kernel, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, W, relu_y, dX, M, N,
-                       K);
+    hipLaunchKernelGGL(linear_dx_kernel, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, W, relu_y, addend, dX,
+                       M, N, K);
     MGX_CHECK_LAUNCH("mgx_linear_dx");
     return MGX_OK;
 }

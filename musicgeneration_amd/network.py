@@ -103,35 +103,45 @@ class MusicTransformer(torch.nn.Module):
         P = st.params
         h = ops.embed_pe(tok, P["Decoder.embedding.weight"], pe, p, seed, st.g("Decoder.embedding.weight"),
                          done("embedding"))
-        for i in range(self.num_layer):
-            pre = f"Decoder.enc_layers.{i}."
-            wqkv = st.fused(pre + "rga.Wq.weight", pre + "rga.Wv.weight", 3 * d, d)
-            gqkv = st.fused(pre + "rga.Wq.weight", pre + "rga.Wv.weight", 3 * d, d, "grad")
-            bqkv = st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "param").view(3 * d)
-            gbqkv = st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "grad").view(3 * d)
-            # the layer's bucket is complete when its first op (QKV projection) has run its backward
-            qkv = ops.linear(h, P[pre + "rga.Wq.weight"], wqkv, bqkv, 0, gqkv, gbqkv, done(f"layer{i}"))
-            ctx = ops.rel_attn(qkv, P[pre + "rga.E"], st.w(pre + "rga.E"), padbits, st.g(pre + "rga.E"), wsink)
-            # the bias gradients of `fc` and `FFN_suf` are column sums of the LayerNorm backward's dx: that kernel
-            # emits them (gb=None here)
-            a = ops.linear(ctx, P[pre + "rga.fc.weight"], st.w(pre + "rga.fc.weight"), P[pre + "rga.fc.bias"].data,
-                           0, st.g(pre + "rga.fc.weight"), None)
-            o1 = ops.add_ln(a, h, P[pre + "layernorm1.weight"].data, P[pre + "layernorm1.bias"].data, 1e-6, p,
-                            seed + 4 * i + 1, st.g(pre + "layernorm1.weight"), st.g(pre + "layernorm1.bias"),
-                            st.g(pre + "rga.fc.bias"))
-            f = ops.linear(o1, P[pre + "FFN_pre.weight"], st.w(pre + "FFN_pre.weight"), P[pre + "FFN_pre.bias"].data,
-                           1, st.g(pre + "FFN_pre.weight"), st.g(pre + "FFN_pre.bias"))
-            f = ops.linear(f, P[pre + "FFN_suf.weight"], st.w(pre + "FFN_suf.weight"), P[pre + "FFN_suf.bias"].data,
-                           0, st.g(pre + "FFN_suf.weight"), None, None, True)
-            h = ops.add_ln(f, o1, P[pre + "layernorm2.weight"].data, P[pre + "layernorm2.bias"].data, 1e-6, p,
-                           seed + 4 * i + 2, st.g(pre + "layernorm2.weight"), st.g(pre + "layernorm2.bias"),
-                           st.g(pre + "FFN_suf.bias"))
+        for i, lp in enumerate(self._layer_params()):
+            # the layer's gradient bucket is complete when the block's backward (ending in the QKV projection) has run
+            h = ops.encoder_layer(h, lp, padbits, p, seed + 4 * i, done(f"layer{i}"), wsink)
         Vp = self.vocab_padded
         logits = ops.linear(h, P["fc.weight"], st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param"),
                             0, st.padded_view("fc.weight", Vp, d, "grad"), st.padded_view("fc.bias", Vp, None, "grad"),
                             done("fc"))
         # [B, L, Vp] storage, [B, L, V] view: columns >= V are exact zeros (zero weight rows, zero bias)
         return logits[..., : self.vocab_size]
+
+    def _layer_params(self):
+        """per-layer kernel operands as views of the flat buffers (rebuilt when the store is)"""
+        st = self.store()
+        if getattr(self, "_lp_store", None) is st:
+            return self._lp
+        d, P, out = self.embedding_dim, st.params, []
+        for i in range(self.num_layer):
+            pre = f"Decoder.enc_layers.{i}."
+            lp = ops.LayerParams()
+            lp.wqkv = st.fused(pre + "rga.Wq.weight", pre + "rga.Wv.weight", 3 * d, d)
+            lp.gqkv = st.fused(pre + "rga.Wq.weight", pre + "rga.Wv.weight", 3 * d, d, "grad")
+            lp.bqkv = st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "param").view(3 * d)
+            lp.gbqkv = st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "grad").view(3 * d)
+            lp.E, lp.gE = st.w(pre + "rga.E"), st.g(pre + "rga.E")
+            # the bias gradients of `fc` and `FFN_suf` are column sums of the LayerNorm backward's dx: that
+            # kernel emits them
+            lp.wfc, lp.bfc = st.w(pre + "rga.fc.weight"), P[pre + "rga.fc.bias"].data
+            lp.gwfc, lp.gbfc = st.g(pre + "rga.fc.weight"), st.g(pre + "rga.fc.bias")
+            lp.g1, lp.b1 = P[pre + "layernorm1.weight"].data, P[pre + "layernorm1.bias"].data
+            lp.gg1, lp.gb1 = st.g(pre + "layernorm1.weight"), st.g(pre + "layernorm1.bias")
+            lp.wpre, lp.bpre = st.w(pre + "FFN_pre.weight"), P[pre + "FFN_pre.bias"].data
+            lp.gwpre, lp.gbpre = st.g(pre + "FFN_pre.weight"), st.g(pre + "FFN_pre.bias")
+            lp.wsuf, lp.bsuf = st.w(pre + "FFN_suf.weight"), P[pre + "FFN_suf.bias"].data
+            lp.gwsuf, lp.gbsuf = st.g(pre + "FFN_suf.weight"), st.g(pre + "FFN_suf.bias")
+            lp.g2, lp.b2 = P[pre + "layernorm2.weight"].data, P[pre + "layernorm2.bias"].data
+            lp.gg2, lp.gb2 = st.g(pre + "layernorm2.weight"), st.g(pre + "layernorm2.bias")
+            out.append(lp)
+        self._lp_store, self._lp = st, out
+        return out
 
     def forward(self, x, length=None, writer=None):
         if self.training or not self.infer:

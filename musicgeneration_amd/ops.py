@@ -150,8 +150,9 @@ def add_ln_bwd(dout, x, res, gamma, mean, rstd, dgamma, dbeta, p_drop=0.0, seed=
     lib = _lib.load()
     key = (x.device, d)
     ws = _LN_WS.get(key)          # per-device scratch, reused by every call on the (single) compute stream
-    if ws is None:
-        ws = _LN_WS[key] = torch.empty(lib.mgx_add_ln_bwd_workspace(rows, d), dtype=torch.uint8, device=x.device)
+    need = lib.mgx_add_ln_bwd_workspace(rows, d)
+    if ws is None or ws.numel() < need:
+        ws = _LN_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
     check(lib.mgx_add_ln_bwd(ptr(dout), ptr(x), ptr(res), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dres),
                              ptr(dgamma), ptr(dbeta), ptr(dxsum), ptr(ws), ws.numel(), rows, d, float(p_drop), int(seed),
                              stream_ptr()), "mgx_add_ln_bwd")
@@ -204,13 +205,16 @@ def linear_fwd(a, w, bias, act=0):
     return out
 
 
-def linear_dx(dy, w, relu_y=None):
-    """dy bf16 [..,N], w bf16 [N,K] -> dx bf16 [..,K] = dy @ w (zeroed where relu_y <= 0)"""
-    _need_cuda(dy, w, relu_y)
+def linear_dx(dy, w, relu_y=None, addend=None):
+    """dy bf16 [..,N], w bf16 [N,K] -> dx bf16 [..,K] = dy @ w (zeroed where relu_y <= 0) (+ addend)"""
+    _need_cuda(dy, w, relu_y, addend)
     N, K = w.shape
     Mrows = dy.numel() // N
     dx = torch.empty(*dy.shape[:-1], K, dtype=BF16, device=dy.device)
-    check(_lib.load().mgx_linear_dx(ptr(dy), ptr(w), ptr(relu_y), ptr(dx), Mrows, N, K, stream_ptr()), "mgx_linear_dx")
+    if addend is not None and (addend.dtype != BF16 or addend.numel() != dx.numel() or not addend.is_contiguous()):
+        raise ValueError("linear_dx: addend must be a contiguous bf16 tensor of dx's shape")
+    check(_lib.load().mgx_linear_dx(ptr(dy), ptr(w), ptr(relu_y), ptr(addend), ptr(dx), Mrows, N, K, stream_ptr()),
+          "mgx_linear_dx")
     return dx
 
 
@@ -340,6 +344,65 @@ class _Linear(torch.autograd.Function):
         if done is not None:
             done()
         return dx, None, None, None, None, None, None, None, None
+
+
+class LayerParams:
+    """Views one encoder layer's kernels need (bf16 shadow weights, fp32 biases / LayerNorm parameters and
+    the fp32 gradient slots they accumulate into); built once per model by network.MusicTransformer."""
+    __slots__ = ("wqkv", "bqkv", "gqkv", "gbqkv", "E", "gE", "wfc", "bfc", "gwfc", "gbfc", "g1", "b1", "gg1", "gb1",
+                 "wpre", "bpre", "gwpre", "gbpre", "wsuf", "bsuf", "gwsuf", "gbsuf", "g2", "b2", "gg2", "gb2")
+
+
+class _EncoderLayer(torch.autograd.Function):
+    """One whole post-LN block (layers.py:152-161) as a single autograd node: 7 kernels forward, 14 backward.
+    Doing the block in one node lets the gradient that arrives over each residual connection join the
+    branch's input gradient inside the dX GEMM epilogue (``addend``) instead of a separate elementwise pass,
+    and frees each intermediate as soon as its last consumer has run."""
+
+    @staticmethod
+    def forward(ctx, h, lp, padbits, p_drop, seed, done, wsink):
+        qkv = linear_fwd(h, lp.wqkv, lp.bqkv, 0)
+        att, lse = rel_attn_fwd(qkv, lp.E, padbits)
+        if wsink is not None:
+            wsink.append(rel_attn_weights(qkv, lp.E, padbits, lse))
+        a = linear_fwd(att, lp.wfc, lp.bfc, 0)
+        o1, mean1, rstd1 = add_ln_fwd(a, h, lp.g1, lp.b1, 1e-6, p_drop, seed + 1)
+        f1 = linear_fwd(o1, lp.wpre, lp.bpre, 1)
+        f2 = linear_fwd(f1, lp.wsuf, lp.bsuf, 0)
+        out, mean2, rstd2 = add_ln_fwd(f2, o1, lp.g2, lp.b2, 1e-6, p_drop, seed + 2)
+        ctx.save_for_backward(h, qkv, att, lse, a, o1, f1, f2, mean1, rstd1, mean2, rstd2)
+        ctx.cfg = (lp, padbits, p_drop, seed, done)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, qkv, att, lse, a, o1, f1, f2, mean1, rstd1, mean2, rstd2 = ctx.saved_tensors
+        lp, padbits, p_drop, seed, done = ctx.cfg
+        # LN2 <- FFN_suf <- ReLU <- FFN_pre, residual o1
+        df2, dres2 = add_ln_bwd(dout.contiguous(), f2, o1, lp.g2, mean2, rstd2, lp.gg2, lp.gb2, p_drop, seed + 2, lp.gbsuf)
+        df1 = linear_dx(df2, lp.wsuf, f1)
+        linear_dw(df2, f1, lp.gwsuf, None)
+        del df2
+        do1 = linear_dx(df1, lp.wpre, None, dres2)
+        linear_dw(df1, o1, lp.gwpre, lp.gbpre)
+        del df1, dres2
+        # LN1 <- fc <- attention <- QKV, residual h
+        da, dres1 = add_ln_bwd(do1, a, h, lp.g1, mean1, rstd1, lp.gg1, lp.gb1, p_drop, seed + 1, lp.gbfc)
+        del do1
+        datt = linear_dx(da, lp.wfc)
+        linear_dw(da, att, lp.gwfc, None)
+        del da
+        dqkv = rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE)
+        del datt
+        dh = linear_dx(dqkv, lp.wqkv, None, dres1)
+        linear_dw(dqkv, h, lp.gqkv, lp.gbqkv)
+        if done is not None:
+            done()
+        return dh, None, None, None, None, None, None
+
+
+def encoder_layer(h, lp, padbits, p_drop, seed, done=None, wsink=None):
+    return _EncoderLayer.apply(h, lp, padbits, p_drop, seed, done, wsink)
 
 
 class _SmoothCE(torch.autograd.Function):

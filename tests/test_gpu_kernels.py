@@ -325,6 +325,13 @@ def test_linear_backward_kernels(M, N, K, relu):
     torch.cuda.synchronize()
     assert _relerr(dx.cpu(), ref_dx) < 5e-3
     assert (dx.float().cpu() - ref_dx).abs().max().item() <= 2 ** -7 * ref_dx.abs().max().item() + 1e-3
+    # residual-gradient addend joins after the mask
+    add = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    dx2 = ops.linear_dx(dy.to(dev), w.to(dev), x.to(dev) if relu else None, add.to(dev))
+    ref2 = ref_dx + add.float()
+    assert (dx2.float().cpu() - ref2).abs().max().item() <= 2 ** -7 * ref2.abs().max().item() + 1e-3
+    with pytest.raises(ValueError):
+        ops.linear_dx(dy.to(dev), w.to(dev), None, add.to(dev).float())
     gw0 = torch.randn(N, K, generator=g)
     gb0 = torch.randn(N, generator=g)
     gw, gb = gw0.clone().to(dev), gb0.clone().to(dev)
