@@ -74,14 +74,17 @@ int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t*
 /* backward of the above (autograd of layers.py:86-106).  dctx bf16 [B,L,d] -> dqkv bf16 [B,L,3d];
  * dE f32 [M,64] is ACCUMULATED into (caller zeroes it once per optimiser step).
  * workspace: caller-provided scratch, 256-byte aligned, >= mgx_rel_attn_bwd_workspace(B,L,d) bytes
- * (rowsum(dctx*ctx) [B,h,L] f32 + a transposed bf16 copy of E).                                   */
+ * (rowsum(dctx*ctx) [B,h,L] f32, a transposed bf16 copy of E, and dS by (query, relative distance)
+ * bf16 [B,h,L,L] that the dQ kernel leaves for the dE kernel -- 2*B*h*L*L bytes, 1.07 GB at cfg2/B=16). */
 size_t mgx_rel_attn_bwd_workspace(int B, int L, int d);
 int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                      const uint16_t* ctx, const uint16_t* dctx, const float* lse,
                      uint16_t* dqkv, float* dE, void* workspace, size_t ws_bytes,
                      int B, int L, int d, int M, void* stream);
 /* same, running only the selected sub-kernels (bit0 pre-pass: delta + E transpose, bit1 dQ, bit2 dK+dV,
- * bit3 dE); used by bench.py to time each kernel on its own.  parts == 15 is mgx_rel_attn_bwd.    */
+ * bit3 dE streamed from the dS that a bit1 run left in the SAME workspace, bit4 dE by full recomputation:
+ * independent of bit1, used as a cross-check); bench.py times each kernel on its own this way.
+ * parts == 15 is mgx_rel_attn_bwd.                                                                */
 int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                            const uint16_t* ctx, const uint16_t* dctx, const float* lse,
                            uint16_t* dqkv, float* dE, void* workspace, size_t ws_bytes,

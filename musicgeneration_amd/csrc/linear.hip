@@ -188,9 +188,9 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
     const int m0 = tm * BM, k0 = tk * BN;
 
     // staging: dY tile as in the forward (row = srow + 32 i, 16-byte chunk sch of 64 n);
-    //          W tile: 64 rows n x 256 B; thread -> (n row = tid >> 2 [0..63], chunks 4*(tid&3) .. +3 of 16)
+    //          W tile: 64 rows n x 256 B; thread -> (n rows (tid >> 4) + 16 i, chunk tid & 15 of 16)
     const int srow = tid >> 3, sch = tid & 7;
-    const int wrow = tid >> 2, wc0 = (tid & 3) * 4;
+    const int wrow = tid >> 4, wch = tid & 15;           // W rows wrow + 16 i, 16 lanes per 256-byte row (see dW)
     u32x4 areg[4], wreg[4];
     auto load_tiles = [&](int n0) {
 #pragma unroll
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
             const int gm = m0 + srow + 32 * i;
             const int gn = n0 + sch * 8;                                  // N % 8 == 0 (host-checked)
             areg[i] = (gm < M && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
-            const int wn_ = n0 + wrow, wk = k0 + (wc0 + i) * 8;
+            const int wn_ = n0 + wrow + 16 * i, wk = k0 + wch * 8;
             wreg[i] = (wn_ < N && wk < K) ? *(const u32x4*)(W + (size_t)wn_ * K + wk) : u32x4{0, 0, 0, 0};
         }
     };
@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             *(u32x4*)(at + imgR_off(srow + 32 * i, sch)) = areg[i];
-            const int ch = wc0 + i;                                       // 16-byte chunk 0..15 of the 128 columns
-            const int sub = (wrow >> 5) * 2 + (ch >> 3);                  // (n block, column half)
-            *(u32x4*)(wt + sub * TILE_BYTES + imgT_off(wrow & 31, ch & 7)) = wreg[i];
+            const int row = wrow + 16 * i;
+            const int sub = (row >> 5) * 2 + (wch >> 3);                  // (n block, column half)
+            *(u32x4*)(wt + sub * TILE_BYTES + imgT_off(row & 31, wch & 7)) = wreg[i];
         }
     };
     f32x16 acc[2][2];
@@ -260,13 +260,16 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
     const int n0 = tn * BM, k0 = tk * BN;
     const int mbeg = blockIdx.y * mchunk, mend = min(M, mbeg + mchunk);
 
-    const int wrow = tid >> 2, wc0 = (tid & 3) * 4;      // 64 rows m x 16 chunks
+    // staging: 16 consecutive lanes cover one 256-byte row (16 chunks) -> the 8 lanes of a ds_write_b128 group hit
+    // 8 distinct 16-byte slots of one sub-tile row (conflict-free), and global reads are 256-byte segments
+    const int wrow = tid >> 4, ch = tid & 15;            // rows wrow + 16 i
+    const int sub_c = ch >> 3, slot = ch & 7;
     u32x4 areg[4], breg[4];
     auto load_tiles = [&](int mm) {
-        const int gm = mm + wrow;
+        const int gn = n0 + ch * 8, gk = k0 + ch * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int gn = n0 + (wc0 + i) * 8, gk = k0 + (wc0 + i) * 8;
+            const int gm = mm + wrow + 16 * i;
             areg[i] = (gm < mend && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
             breg[i] = (gm < mend && gk < K) ? *(const u32x4*)(X + (size_t)gm * K + gk) : u32x4{0, 0, 0, 0};
         }
@@ -276,8 +279,8 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
         char* bt = at + IMG;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ch = wc0 + i;
-            const int off = ((wrow >> 5) * 2 + (ch >> 3)) * TILE_BYTES + imgT_off(wrow & 31, ch & 7);
+            const int row = wrow + 16 * i;
+            const int off = ((row >> 5) * 2 + sub_c) * TILE_BYTES + imgT_off(row & 31, slot);
             *(u32x4*)(at + off) = areg[i];
             *(u32x4*)(bt + off) = breg[i];
         }

@@ -126,10 +126,11 @@ MGX_DEV bf16x8 frag_T_onR(const char* tile, int lane, int s, int ct) {
     return out;
 }
 
+template <bool EXPORT_DS>
 __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint16_t* __restrict__ ErT,
     const uint32_t* __restrict__ padbits, const uint16_t* __restrict__ dctx, const float* __restrict__ lse,
-    const float* __restrict__ delta, uint16_t* __restrict__ dqkv, int L, int d) {
+    const float* __restrict__ delta, uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel, int L, int d) {
     using namespace k1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -210,6 +211,17 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         }
     }
     f32x16 dq0 = zero16(), dq1 = zero16();
+    // dS by (query, relative distance) for the dE kernel, tile-blocked: tile (b,h, query block i0/32, chunk q) is 2 KB at
+    // ((bh*nchunk + i0/32)*nchunk + q)*1024 elements; inside, the 16-byte unit of (row a, columns 16ks+8hh..+7) sits at
+    // ks*512 + a*16 + hh*8 elements -- each wave store instruction below writes 1 KB contiguously.
+    uint16_t* dsp = nullptr;
+    if (EXPORT_DS && wave_on) {   // chunks above the diagonal chunk inside this 128-row block read as zeros downstream
+        dsp = dsrel + (((size_t)b * heads + hd) * nchunk + (i0 >> 5)) * nchunk * 1024 + a * 16 + hh * 8;
+        for (int q = Q0 + w + 1; q < min(Q0 + 4, nchunk); ++q) {
+            *(u32x4*)(dsp + (size_t)q * 1024) = u32x4{0, 0, 0, 0};
+            *(u32x4*)(dsp + (size_t)q * 1024 + 512) = u32x4{0, 0, 0, 0};
+        }
+    }
 
     for (int s = 0; s < nsteps; ++s) {
         const int cur = s & 1;
@@ -302,6 +314,14 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         if (have_next) {
             *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
             *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
+        }
+        if (EXPORT_DS && wave_on && dq >= 0) {
+            // completed chunk dq of dS[i][delta] -> workspace.  Last in the step: VMEM operations retire in order, so
+            // the wait for the NEXT step's K/V tiles then only covers stores that have had a whole step to drain.
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                *(bf16x8*)(dsp + (size_t)dq * 1024 + 512 * ks) =
+                    *(const bf16x8*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2);
         }
         __syncthreads();
     }
@@ -697,13 +717,142 @@ __global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
     }
 }
 
+// ================================================================================================
+// K3s: dE from the stored dS.  The dQ kernel leaves dsrel[b,h][i][delta] = dS[i][i-delta] (bf16, the
+// exact operand it multiplied with Er itself), so
+//     dEr[delta][c] = 1/8 sum_{b,h} sum_{i >= delta} dsrel[b,h][i][delta] q[b,i,h,c]
+// is a plain "TN" product streamed from HBM: no recomputation of S / P / dP (the recompute kernel above
+// executes 6 product units for this 1).  Workgroup = 128 distances x 64 columns, a fixed number of
+// 64-row steps of the flattened (b, h, i-block) sweep; partial sums are flushed with fp32 atomics in
+// 128-byte row segments.  HBM-bound: 24 KB per step against 8 MFMAs per wave.
+// ================================================================================================
+namespace k3s {
+constexpr int DT = 128;                                    // distances per workgroup
+constexpr int RS = 64;                                     // query rows per step
+constexpr int STEPS = 32;                                  // steps per workgroup (768 KB streamed, 32 KB flushed)
+constexpr int OFF_A = 0;                                   // 2 x 16K  dS tile [64 i][128 delta]: 4 sub-tiles image T
+constexpr int OFF_Q = 2 * 4 * TILE_BYTES;                  // 2 x 8K   q tile  [64 i][64 c]:      2 sub-tiles image T
+constexpr int LDS_BYTES = OFF_Q + 2 * 2 * TILE_BYTES;      // 49,152 B -> 3 workgroups per CU
+}  // namespace k3s
+
+__global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dsrel, float* __restrict__ dEr /* = dE + (M-L)*64 */,
+    int B, int L, int d) {
+    using namespace k3s;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int heads = d >> 6, nbh = B * heads;
+    const size_t ld = (size_t)3 * d;
+    // which distance tile, which slice of its flattened (bh, row-block) sweep: tiles are laid out heaviest first
+    int t = 0, first = 0, ns = 0;
+    {
+        int rest = blockIdx.x;
+        const int ntile = (L + DT - 1) / DT;
+        for (t = 0; t < ntile; ++t) {
+            ns = (L - t * DT + RS - 1) / RS;               // row blocks i0 = t*DT, +64, ... < L
+            const int nwg = (nbh * ns + STEPS - 1) / STEPS;
+            if (rest < nwg) break;
+            rest -= nwg;
+        }
+        if (t == ntile) return;
+        first = rest * STEPS;
+    }
+    const int total = nbh * ns;
+    const int last = min(total, first + STEPS);
+    const int d0 = t * DT;
+
+    // staging.  dS: a step's [64 i][128 delta] block = 2 query blocks x 4 chunks = 8 stored tiles of 2 KB (the 4 chunk
+    // tiles of one query block are adjacent: 8 KB runs); thread -> 16-byte units u = tid + 256 i: tile u>>7, unit u&127
+    // = (ks, row a, half hh) as the dQ kernel wrote them.  q: rows of 128 B (8 lanes x 16 B).
+    const int nchunk = L >> 5;
+    const int qrow = tid >> 3, qch = tid & 7;              // rows qrow + 32 i
+    int a_src[4], a_dst[4];
+    bool a_colok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = tid + 256 * i;
+        const int tt = u >> 7, v = u & 127;
+        const int rb = tt >> 2, qq = tt & 3;               // query block (of 2), chunk (of 4) inside the step
+        const int ks = v >> 6, ar = (v >> 1) & 31, h2 = v & 1;
+        a_src[i] = (rb * nchunk + qq) * 1024 + v * 8;      // elements, relative to tile (bh, i0/32, d0/32)
+        const int ch16 = 4 * qq + 2 * ks + h2;             // 16-byte column chunk 0..15 of the 128 distances
+        a_dst[i] = (rb * 2 + (ch16 >> 3)) * TILE_BYTES + imgT_off(ar, ch16 & 7);
+        a_colok[i] = (d0 >> 5) + qq < nchunk;
+    }
+    u32x4 areg[4], qreg[2];
+    auto load_tiles = [&](int g) {
+        const int bh = g / ns, i0 = d0 + (g - bh * ns) * RS;
+        const int bb = bh / heads, hd = bh - bb * heads;
+        const uint16_t* ap = dsrel + (((size_t)bh * nchunk + (i0 >> 5)) * nchunk + (d0 >> 5)) * 1024;
+        const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + qch * 8;
+        const bool second = i0 + 32 < L;                   // L % 64 may be 32: the step's second query block is absent
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            areg[i] = (a_colok[i] && (i < 2 || second)) ? *(const u32x4*)(ap + a_src[i]) : u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = qrow + 32 * i;
+            qreg[i] = (i0 + r < L) ? *(const u32x4*)(qp + (size_t)r * ld) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* at = smem + OFF_A + buf * 4 * TILE_BYTES;
+        char* qt = smem + OFF_Q + buf * 2 * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(at + a_dst[i]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = qrow + 32 * i;
+            *(u32x4*)(qt + (r >> 5) * TILE_BYTES + imgT_off(r & 31, qch)) = qreg[i];
+        }
+    };
+    f32x16 de0 = zero16(), de1 = zero16();
+    if (first < last) {
+        load_tiles(first);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int g = first; g < last; ++g) {
+        const int cur = (g - first) & 1;
+        if (g + 1 < last) load_tiles(g + 1);
+        const char* at = smem + OFF_A + cur * 4 * TILE_BYTES;
+        const char* qt = smem + OFF_Q + cur * 2 * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 af = frag_Tn(at + ((ks >> 1) * 2 + (w >> 1)) * TILE_BYTES, lane, ks & 1, w & 1);
+            const char* qs = qt + (ks >> 1) * TILE_BYTES;
+            de0 = mfma(af, frag_Tn(qs, lane, ks & 1, 0), de0);
+            de1 = mfma(af, frag_Tn(qs, lane, ks & 1, 1), de1);
+        }
+        if (g + 1 < last) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+    // flush: rows = distances 32w + crow(r,hh) of the tile, columns on lanes; q was not pre-scaled -> 1/8 here
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dl = d0 + 32 * w + crow(r, hh);
+        if (dl < L) {
+            float* row = dEr + (size_t)(L - 1 - dl) * 64;
+            atomicAdd(row + l31, 0.125f * de0[r]);
+            atomicAdd(row + 32 + l31, 0.125f * de1[r]);
+        }
+    }
+}
+
 static size_t ws_delta_bytes(int B, int L, int d) { return (((size_t)B * (d / 64) * L * 4) + 255) / 256 * 256; }
+
+static size_t ws_ert_bytes(int L) { return (((size_t)64 * L * 2) + 255) / 256 * 256; }
 
 extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
     if (B <= 0 || L <= 0 || d <= 0) return 0;
-    return ws_delta_bytes(B, L, d) + (size_t)64 * L * 2;
+    // delta f32 [B,h,L] | ErT bf16 [64][L] | dS by (query, distance) bf16 [B,h,L,L]
+    return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * L * L * 2;
 }
 
+// parts: 1 pre-pass (delta, E transpose) | 2 dQ (also leaves dS for 8) | 4 dK/dV | 8 dE streamed from the dS the dQ
+// kernel left in the workspace | 16 dE by the recompute kernel (independent of 2; cross-check / A-B timing).
 extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                                       const uint16_t* ctx, const uint16_t* dctx, const float* lse, uint16_t* dqkv,
                                       float* dE, void* workspace, size_t ws_bytes, int B, int L, int d, int M,
@@ -717,9 +866,11 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
                 mgx_rel_attn_bwd_workspace(B, L, d), ws_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)rel_attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_de_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3s::LDS_BYTES);
         attr_set = true;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -727,17 +878,36 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     const uint16_t* Er = E + (size_t)(M - L) * 64;
     float* delta = (float*)workspace;
     uint16_t* ErT = (uint16_t*)((char*)workspace + ws_delta_bytes(B, L, d));
+    uint16_t* dsrel = (uint16_t*)((char*)ErT + ws_ert_bytes(L));
     if (parts & 1) {
         const long total = (long)B * L * heads * 8;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
         hipLaunchKernelGGL(er_transpose_kernel, dim3((64 * (L / 8) + 255) / 256), dim3(256), 0, s, Er, ErT, L);
     }
     const dim3 gq(B * heads, (L + 127) / 128);
-    if (parts & 2) hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, padbits, dctx, lse, delta, dqkv, L, d);
+    const bool export_ds = (parts & 8) || !(parts & 16);
+    if (parts & 2) {
+        if (export_ds)
+            hipLaunchKernelGGL(rel_attn_dq_kernel<true>, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, padbits, dctx, lse, delta,
+                               dqkv, dsrel, L, d);
+        else
+            hipLaunchKernelGGL(rel_attn_dq_kernel<false>, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, padbits, dctx, lse, delta,
+                               dqkv, dsrel, L, d);
+    }
     if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
-    const dim3 ge(B * heads, ((L >> 5) + k3::W3 - 1) / k3::W3);
-    if (parts & 8) hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(64 * k3::W3), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
-                       dE + (size_t)(M - L) * 64, L, d);
+    if (parts & 8) {
+        long nwg = 0;
+        for (int t = 0; t < (L + k3s::DT - 1) / k3s::DT; ++t)
+            nwg += ((long)B * heads * ((L - t * k3s::DT + k3s::RS - 1) / k3s::RS) + k3s::STEPS - 1) / k3s::STEPS;
+        MGX_REQUIRE(nwg < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
+        hipLaunchKernelGGL(rel_attn_de_stream_kernel, dim3((unsigned)nwg), dim3(256), k3s::LDS_BYTES, s, qkv, dsrel,
+                           dE + (size_t)(M - L) * 64, B, L, d);
+    }
+    if (parts & 16) {
+        const dim3 ge(B * heads, ((L >> 5) + k3::W3 - 1) / k3::W3);
+        hipLaunchKernelGGL(rel_attn_de_kernel, ge, dim3(64 * k3::W3), k3::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta,
+                           dE + (size_t)(M - L) * 64, L, d);
+    }
     MGX_CHECK_LAUNCH("mgx_rel_attn_bwd");
     return MGX_OK;
 }

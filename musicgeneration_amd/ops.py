@@ -92,9 +92,9 @@ def _side_streams(dev):
 
 def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None, concurrent=None) -> torch.Tensor:
     """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench).
-    concurrent (opt-in, MGX_CONCURRENT_BWD=1): the three owner kernels (dQ / dK+dV / dE) are independent once
-    the pre-pass (delta, E transpose) has run, so they can be launched on three streams (their tails overlap;
-    measured +1 % end to end).  Default is one stream, which keeps per-kernel profiles comparable."""
+    parts: 1 pre-pass | 2 dQ (leaves dS in the workspace) | 4 dK/dV | 8 dE streamed from that dS | 16 dE by recompute.
+    concurrent (opt-in, MGX_CONCURRENT_BWD=1): dK/dV is independent of dQ -> dE once the pre-pass has run, so it
+    can go on a second stream (tails overlap).  Default is one stream, which keeps per-kernel profiles comparable."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
     B, L, d3 = qkv.shape
     d = d3 // 3
@@ -111,17 +111,14 @@ def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, works
         check(lib.mgx_rel_attn_bwd_parts(*args, int(parts), stream_ptr()), "mgx_rel_attn_bwd")
         return dqkv
     main = torch.cuda.current_stream()
-    s1, s2 = _side_streams(qkv.device)
+    s1, _ = _side_streams(qkv.device)
     check(lib.mgx_rel_attn_bwd_parts(*args, 1, main.cuda_stream), "mgx_rel_attn_bwd(pre)")
     ready = torch.cuda.Event()
     ready.record(main)
     s1.wait_event(ready)
-    s2.wait_event(ready)
-    check(lib.mgx_rel_attn_bwd_parts(*args, 8, s2.cuda_stream), "mgx_rel_attn_bwd(dE)")      # longest first
     check(lib.mgx_rel_attn_bwd_parts(*args, 4, s1.cuda_stream), "mgx_rel_attn_bwd(dKV)")
-    check(lib.mgx_rel_attn_bwd_parts(*args, 2, main.cuda_stream), "mgx_rel_attn_bwd(dQ)")
+    check(lib.mgx_rel_attn_bwd_parts(*args, 2 | 8, main.cuda_stream), "mgx_rel_attn_bwd(dQ, dE)")   # dE consumes dQ's dS
     main.wait_stream(s1)
-    main.wait_stream(s2)
     return dqkv
 
 

@@ -7,7 +7,7 @@ from musicgeneration_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=8); ap.add_argument("--L", type=int, default=2048)
 ap.add_argument("--d", type=int, default=512); ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--parts", type=int, default=31, help="bit0 fwd, bit1 delta, bit2 dq, bit3 dkv, bit4 de")
+ap.add_argument("--parts", type=int, default=63, help="bit0 fwd, bit1 delta, bit2 dq, bit3 dkv, bit4 de (streamed), bit5 de (recompute)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(7)
@@ -31,4 +31,6 @@ if a.parts & 1: timed(lambda: ops.rel_attn_fwd(qkv, E, None), 3, "fwd")
 if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, ws), 0, "delta")
 if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2, dqkv, ws), 5, "dq")
 if a.parts & 8: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
-if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 6, "de")
+if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de")
+if a.parts & 32: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 16, dqkv, ws), 6, "de_rec")
+if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2 | 16, dqkv, ws), 5, "dq_noexp")

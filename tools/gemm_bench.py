@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from musicgeneration_amd import ops
 dev = torch.device("cuda")
-M = 16384
+M = int(os.environ.get("GEMM_M", 32768))
 shapes = [("qkv", 1536, 512), ("fc", 512, 512), ("ffn_pre", 256, 512), ("ffn_suf", 512, 256), ("vocab", 384, 512)]
 g = torch.Generator().manual_seed(0)
 def timed(fn, reps=20):
@@ -23,7 +23,9 @@ for name, N, K in shapes:
     fl = 2.0 * M * N * K
     t1 = timed(lambda: ops.linear_fwd(x, w, b, 0)); t2 = timed(lambda: ops.linear_dx(dy, w, None)); t3 = timed(lambda: ops.linear_dw(dy, x, gw, None))
     t4 = timed(lambda: torch.mm(x, w.t()))
+    t5 = timed(lambda: torch.mm(dy, w)); t6 = timed(lambda: torch.mm(dy.t(), x))
+    byt = 2.0 * (M * K + M * N)
     mult = 6 if name != "vocab" else 1
     tot["fwd"] += t1 * mult; tot["dx"] += t2 * mult; tot["dw"] += t3 * mult
-    print(f"{name:8s} N={N:5d} K={K:4d}  fwd {t1*1e3:6.1f} us {fl/t1/1e9:6.0f} TF/s | dx {t2*1e3:6.1f} us {fl/t2/1e9:6.0f} | dw {t3*1e3:6.1f} us {fl/t3/1e9:6.0f} | lib mm {t4*1e3:6.1f} us {fl/t4/1e9:6.0f}")
+    print(f"{name:8s} N={N:5d} K={K:4d}  fwd {t1*1e3:6.1f} us {fl/t1/1e9:6.0f} TF/s | dx {t2*1e3:6.1f} us {fl/t2/1e9:6.0f} | dw {t3*1e3:6.1f} us {fl/t3/1e9:6.0f} | lib fwd {t4*1e3:6.1f} dx {t5*1e3:6.1f} dw {t6*1e3:6.1f} | floor hbm {byt/8e12*1e6:5.1f} mfma {fl/2.5e15*1e6:5.1f} us")
 print("per-step totals (ms):", {k: round(v, 3) for k, v in tot.items()})
