@@ -11,7 +11,7 @@
 //                                        split over workgroups and partial tiles are added with fp32
 //                                        atomics (128-byte row segments) straight into the flat grad
 //                                        buffer -- gradient accumulation across micro-batches for free.
-//   colsum   gb += column sums of dY (bias gradients).
+//   bias     gb += column sums of dY, folded into the dW kernel (its first k-tile column stages those rows anyway).
 #include <stdlib.h>
 #include "rel_attn_common.hpp"
 
@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
 // =================================================================================================
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __restrict__ dY,
                                                            const uint16_t* __restrict__ X,
-                                                           float* __restrict__ gW, int M, int N, int K, int mchunk) {
+                                                           float* __restrict__ gW, float* __restrict__ gb, int M, int N,
+                                                           int K, int mchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -274,6 +275,9 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
             breg[i] = (gm < mend && gk < K) ? *(const u32x4*)(X + (size_t)gm * K + gk) : u32x4{0, 0, 0, 0};
         }
     };
+    // bias gradient gb[n] += sum_m dY[m][n]: the workgroups of the first k-tile column add up the dY rows they stage anyway
+    const bool do_bias = (gb != nullptr) && (tk == 0);
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto store_tiles = [&](int buf) {
         char* at = smem + buf * 2 * IMG;
         char* bt = at + IMG;
@@ -283,6 +287,15 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
             const int off = ((row >> 5) * 2 + sub_c) * TILE_BYTES + imgT_off(row & 31, slot);
             *(u32x4*)(at + off) = areg[i];
             *(u32x4*)(bt + off) = breg[i];
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float f[8];
+                unpack8(areg[i], f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bsum[k] += f[k];
+            }
         }
     };
     f32x16 acc[2][2];
@@ -313,6 +326,17 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
         }
         if (mt + 1 < nm) store_tiles(cur ^ 1);
         __syncthreads();
+    }
+    if (do_bias) {      // lanes with equal (tid & 15) hold the same 8 columns: fold lane bits 4,5, then one atomic per wave
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bsum[k] += __shfl_xor(bsum[k], 16, 64);
+            bsum[k] += __shfl_xor(bsum[k], 32, 64);
+        }
+        if (lane < 16 && n0 + ch * 8 < N) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) atomicAdd(gb + n0 + ch * 8 + k, bsum[k]);
+        }
     }
     // D[n][k]: k on the lane -> one register = two 128-byte row segments per wave-instruction
 #pragma unroll
@@ -378,33 +402,6 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __re
                 C[(size_t)m * N + n0 + n] = f32_to_bf16(v);
             }
         }
-    }
-}
-
-// gb[n] += sum_m dY[m][n]      thread = 8 columns, rows strided over gridDim.y * 32 row-lanes
-__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ dY, float* __restrict__ gb, int M,
-                                                     int N) {
-    const int cg = blockIdx.x * 8 + (threadIdx.x & 7);            // column group (8 columns)
-    const int rl = threadIdx.x >> 3;                              // 0..31
-    __shared__ float red[32][8][8];
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (cg * 8 < N) {
-        for (int m = blockIdx.y * 32 + rl; m < M; m += gridDim.y * 32) {
-            float f[8];
-            unpack8(*(const u32x4*)(dY + (size_t)m * N + cg * 8), f);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s[k] += f[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[rl][threadIdx.x & 7][k] = s[k];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c8 = threadIdx.x >> 3, k = threadIdx.x & 7;
-        float t = 0.f;
-        for (int r = 0; r < 32; ++r) t += red[r][c8][k];
-        const int col = (blockIdx.x * 8 + c8) * 8 + k;
-        if (col < N) atomicAdd(gb + col, t);
     }
 }
 
@@ -482,16 +479,8 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
     if (mchunk < 64) mchunk = 64;
     splits = (M + mchunk - 1) / mchunk;
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, M, N,
-                       K, mchunk);
-    if (gb) {
-        // ~1024 blocks in flight: each block sums 64 columns over M / ysplit rows (32 row-lanes)
-        const int gx = (N + 63) / 64;
-        int ysplit = (1024 + gx - 1) / gx;
-        if (ysplit > (M + 31) / 32) ysplit = (M + 31) / 32;
-        if (ysplit < 1) ysplit = 1;
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, ysplit), dim3(256), 0, (hipStream_t)stream, dY, gb, M, N);
-    }
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, gb, M,
+                       N, K, mchunk);
     MGX_CHECK_LAUNCH("mgx_linear_dw");
     return MGX_OK;
 }
