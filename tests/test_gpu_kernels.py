@@ -293,6 +293,7 @@ def test_rel_attn_bwd_matches_oracle_autograd(B, L, d, M, padcase):
 
 @pytest.mark.parametrize("M,N,K,act", [(128, 128, 64, 0), (300, 340, 128, 0), (1000, 1536, 512, 0),
                                         (257, 256, 512, 1), (64, 64, 256, 1), (32, 1536, 512, 0), (7, 308, 320, 1),
+                                        (2048, 512, 512, 0), (2304, 384, 64, 1), (4100, 340, 192, 0),
                                         (1, 384, 512, 0), (32, 512, 256, 0)])
 def test_linear_fwd(M, N, K, act):
     from musicgeneration_amd import ops
