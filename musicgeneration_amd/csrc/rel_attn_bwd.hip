@@ -80,19 +80,6 @@ MGX_DEV u32x4 scale8(const u32x4& raw, float sc) {
     return pack8(f);
 }
 
-// store a transposed accumulator pair  T^T[c][x] (c = 32*ct + crow(r,hh) on registers, x on lanes)
-// as 64 consecutive bf16 of row x:  dst_row[c] = val * sc
-MGX_DEV void store_rowsT(uint16_t* dst_row, const f32x16& t0, const f32x16& t1, int hh, float sc) {
-    uint16_t* op = dst_row + 4 * hh;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        u32x2 w0 = {pack_bf16x2(t0[4 * g4] * sc, t0[4 * g4 + 1] * sc), pack_bf16x2(t0[4 * g4 + 2] * sc, t0[4 * g4 + 3] * sc)};
-        u32x2 w1 = {pack_bf16x2(t1[4 * g4] * sc, t1[4 * g4 + 1] * sc), pack_bf16x2(t1[4 * g4 + 2] * sc, t1[4 * g4 + 3] * sc)};
-        *(u32x2*)(op + 8 * g4) = w0;
-        *(u32x2*)(op + 32 + 8 * g4) = w1;
-    }
-}
-
 // ================================================================================================
 // K1: dQ.  Same sweep as the forward (query-block owner, key tiles 0..diagonal).
 //   orientation: keys on registers, queries on lanes (S^T, P^T, dP^T, dS^T), dqs^T[c][a] accumulators.
@@ -325,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         }
         __syncthreads();
     }
-    if (wave_on) store_rowsT(dqkv + ((size_t)b * L + i0 + a) * ld + hd * 64, dq0, dq1, hh, 0.125f);
+    if (wave_on) store_rows_lds(dqkv + ((size_t)b * L + i0) * ld + hd * 64, ld, dq0, dq1, lane, 0.125f, band);
 }
 
 // ErT[c][delta] = Er[delta][c] = Er_rows[(L-1-delta)*64 + c]      (bf16 [64][L], 8 deltas per thread)
@@ -520,9 +507,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         __syncthreads();
     }
     if (wave_on) {
-        uint16_t* row = dqkv + ((size_t)b * L + j0 + bl) * ld + hd * 64;
-        store_rowsT(row + d, dk0, dk1, hh, 1.f);
-        store_rowsT(row + 2 * d, dv0, dv1, hh, 1.f);
+        uint16_t* row0 = dqkv + ((size_t)b * L + j0) * ld + hd * 64;
+        store_rows_lds(row0 + d, ld, dk0, dk1, lane, 1.f, band);
+        store_rows_lds(row0 + 2 * d, ld, dv0, dv1, lane, 1.f, band);
     }
 }
 

@@ -117,4 +117,29 @@ MGX_DEV void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Store a transposed accumulator pair T^T[c][x] (c = 32*ct + crow(r,hh) on registers, x = row on lanes) as rows
+// x = 0..31 of 64 consecutive bf16 each, scaled by sc (per lane = per row).  Written straight from the registers a
+// wave instruction would touch 16 bytes of 32 different rows; parked in a wave-private LDS patch (>= 4,608 B, 144-byte
+// rows) and read back row-major, every global store instruction writes 8 whole 128-byte rows instead.
+MGX_DEV void store_rows_lds(uint16_t* dst, size_t row_stride, const f32x16& t0, const f32x16& t1, int lane, float sc,
+                            char* patch) {
+    const int x = lane & 31, hh = lane >> 5;
+    wave_lds_fence();
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        *(u32x2*)(patch + x * 144 + (8 * g4 + 4 * hh) * 2) =
+            u32x2{pack_bf16x2(t0[4 * g4] * sc, t0[4 * g4 + 1] * sc), pack_bf16x2(t0[4 * g4 + 2] * sc, t0[4 * g4 + 3] * sc)};
+        *(u32x2*)(patch + x * 144 + (32 + 8 * g4 + 4 * hh) * 2) =
+            u32x2{pack_bf16x2(t1[4 * g4] * sc, t1[4 * g4 + 1] * sc), pack_bf16x2(t1[4 * g4 + 2] * sc, t1[4 * g4 + 3] * sc)};
+    }
+    wave_lds_fence();
+    const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rr + 8 * i;
+        *(u32x4*)(dst + (size_t)row * row_stride + ch * 8) = *(const u32x4*)(patch + row * 144 + ch * 16);
+    }
+    wave_lds_fence();
+}
+
 }  // namespace relattn

@@ -219,16 +219,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     if (!WRITE_W && wave_on) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.f / l_tot;
-        uint16_t* op = ctx + ((size_t)b * L + i0 + a) * d + hd * 64 + 4 * hh;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            u32x2 w0 = {pack_bf16x2(o0[4 * g4] * inv, o0[4 * g4 + 1] * inv),
-                        pack_bf16x2(o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv)};
-            u32x2 w1 = {pack_bf16x2(o1[4 * g4] * inv, o1[4 * g4 + 1] * inv),
-                        pack_bf16x2(o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv)};
-            *(u32x2*)(op + 8 * g4) = w0;
-            *(u32x2*)(op + 32 + 8 * g4) = w1;
-        }
+        store_rows_lds(ctx + ((size_t)b * L + i0) * d + hd * 64, (size_t)d, o0, o1, lane, inv, band);
         if (hh == 0) lse_out[((size_t)b * heads + hd) * L + i0 + a] = m_run + __logf(l_tot);
     }
 }
