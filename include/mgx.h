@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped */
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -145,6 +145,17 @@ int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y,
  * Both ACCUMULATE (fp32 atomics), so gradient accumulation over micro-batches needs no extra pass. */
 int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, float* gb,
                   int M, int N, int K, void* stream);
+/* the same for up to MGX_DW_MAX_GROUP weights whose dY / X share the row count M (the four projections of one
+ * encoder block, layers.py:152-161), in one launch: fewer M-splits fill the chip, so less atomic traffic.  */
+#define MGX_DW_MAX_GROUP 8
+typedef struct mgx_dw_problem {
+    const uint16_t* dY;   /* bf16 [M,N] */
+    const uint16_t* X;    /* bf16 [M,K] */
+    float* gW;            /* f32 [N,K], accumulated */
+    float* gb;            /* f32 [N], accumulated, or NULL */
+    int N, K;
+} mgx_dw_problem;
+int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* stream);
 
 /* ---- K12: autoregressive decode with a KV cache (replaces the per-token full-window recompute of
  * network.py:52-77; causal semantics).  The current position t lives in device memory

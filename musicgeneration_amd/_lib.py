@@ -37,6 +37,7 @@ SIGNATURES = {
     "mgx_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_gru_gates": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_linear_dx": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mgx_linear_dw_grouped": [_vp, _i, _i, _vp],
     "mgx_linear_dw": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }
 

@@ -14,6 +14,7 @@
 //   bias     gb += column sums of dY, folded into the dW kernel (its first k-tile column stages those rows anyway).
 #include <stdlib.h>
 #include "rel_attn_common.hpp"
+#include "mgx.h"
 
 using namespace relattn;
 
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
 //   LDS:  dY tile [128 m][64 n] image R;  W tile [64 n][128 k'] as 4 sub-tiles (2 n-blocks x 2 col halves)
 //         of [32][64] image T
 // =================================================================================================
-__global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __restrict__ dY,
+template <bool DBUF>
+__global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_dx_kernel(const uint16_t* __restrict__ dY,
                                                            const uint16_t* __restrict__ W,
                                                            const uint16_t* __restrict__ relu_y,
                                                            const uint16_t* __restrict__ addend,
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
     store_tiles(0);
     __syncthreads();
     for (int nt = 0; nt < nn; ++nt) {
-        const int cur = nt & 1;
+        const int cur = DBUF ? (nt & 1) : 0;
         if (nt + 1 < nn) load_tiles((nt + 1) * BK);
         const char* at = smem + cur * 2 * IMG;
         const char* wt = at + IMG;
@@ -312,7 +314,8 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
             acc[1][0] = mfma(b0, a1, acc[1][0]);
             acc[1][1] = mfma(b1, a1, acc[1][1]);
         }
-        if (nt + 1 < nn) store_tiles(cur ^ 1);
+        if (!DBUF) __syncthreads();                 // single buffer: everyone has read the tile before it is replaced
+        if (nt + 1 < nn) store_tiles(DBUF ? (cur ^ 1) : 0);
         __syncthreads();
     }
     store_tile_lds(dX, relu_y, addend, acc, nullptr, 0, m0 + 64 * wm, k0 + 64 * wn, M, K, lane, smem + w * EPI_PATCH);   // K % 8 == 0
@@ -323,19 +326,15 @@ __global__ __launch_bounds__(256, 2) void linear_dx_kernel(const uint16_t* __res
 //   tile: 128 rows n x 128 cols k, reduction over m in steps of 64
 //   LDS:  dY tile [64 m][128 n] and X tile [64 m][128 k], each as 4 sub-tiles [32][64] image T
 // =================================================================================================
-__global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __restrict__ dY,
-                                                           const uint16_t* __restrict__ X,
-                                                           float* __restrict__ gW, float* __restrict__ gb, int M, int N,
-                                                           int K, int mchunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ gW,
+                     float* __restrict__ gb, int M, int N, int K, int tile, int mbeg, int mend, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
     const int l31 = lane & 31, hh = lane >> 5;
     const int ntk = (K + BN - 1) / BN;
-    const int tk = blockIdx.x % ntk, tn = blockIdx.x / ntk;
+    const int tk = tile % ntk, tn = tile / ntk;
     const int n0 = tn * BM, k0 = tk * BN;
-    const int mbeg = blockIdx.y * mchunk, mend = min(M, mbeg + mchunk);
 
     // staging: 16 consecutive lanes cover one 256-byte row (16 chunks) -> the 8 lanes of a ds_write_b128 group hit
     // 8 distinct 16-byte slots of one sub-tile row (conflict-free), and global reads are 256-byte segments
@@ -430,6 +429,36 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
     }
 }
 
+__global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __restrict__ dY,
+                                                           const uint16_t* __restrict__ X,
+                                                           float* __restrict__ gW, float* __restrict__ gb, int M, int N,
+                                                           int K, int mchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int mbeg = blockIdx.y * mchunk;
+    dw_tile(dY, X, gW, gb, M, N, K, blockIdx.x, mbeg, min(M, mbeg + mchunk), smem);
+}
+
+// Several weight gradients that share the row count M (one encoder block's QKV / fc / FFN projections) in ONE launch:
+// with all their 128 x 128 tiles in the grid, far fewer M-splits fill the chip, and the fp32 atomic traffic -- one
+// partial tile per split, ~1.3 TB/s chip-wide -- drops from 75 MB to ~30 MB per block at cfg2.
+struct DwGroup {
+    const uint16_t* dY[MGX_DW_MAX_GROUP];
+    const uint16_t* X[MGX_DW_MAX_GROUP];
+    float* gW[MGX_DW_MAX_GROUP];
+    float* gb[MGX_DW_MAX_GROUP];
+    int N[MGX_DW_MAX_GROUP], K[MGX_DW_MAX_GROUP];
+    int first_tile[MGX_DW_MAX_GROUP + 1];                  // prefix sums of the tile counts
+    int n;
+};
+
+__global__ __launch_bounds__(256, 2) void linear_dw_grouped_kernel(const DwGroup g, int M, int mchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.first_tile[p + 1]) ++p;
+    const int mbeg = blockIdx.y * mchunk;
+    dw_tile(g.dY[p], g.X[p], g.gW[p], g.gb[p], M, g.N[p], g.K[p], blockIdx.x - g.first_tile[p], mbeg, min(M, mbeg + mchunk), smem);
+}
+
 // =================================================================================================
 // skinny forward (M <= 32: the decode path's projections).  The weights are streamed exactly once:
 // workgroup = 32 output columns, its 4 waves split K; W rows and x rows go straight from global/L2 into
@@ -486,8 +515,9 @@ static bool g_attr_set = false;
 static void set_attrs() {
     if (g_attr_set) return;
     hipFuncSetAttribute((const void*)linear_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)linear_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_dx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_dw_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     g_attr_set = true;
 }
 
@@ -527,8 +557,15 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
                 "mgx_linear_dx: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
     set_attrs();
     const int nwg = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
-    hipLaunchKernelGGL(linear_dx_kernel, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, W, relu_y, addend, dX,
-                       M, N, K);
+    static int sbuf_env = -2;
+    if (sbuf_env == -2) { const char* e = getenv("MGX_GEMM_SINGLE_BUF"); sbuf_env = e ? atoi(e) : -1; }
+    const bool sbuf = sbuf_env >= 0 ? (sbuf_env != 0) : (nwg >= 768);      // as in the forward: 3 workgroups / CU for big grids
+    if (sbuf)
+        hipLaunchKernelGGL(linear_dx_kernel<false>, dim3(nwg), dim3(256), LDS_BYTES / 2, (hipStream_t)stream, dY, W, relu_y,
+                           addend, dX, M, N, K);
+    else
+        hipLaunchKernelGGL(linear_dx_kernel<true>, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, W, relu_y,
+                           addend, dX, M, N, K);
     MGX_CHECK_LAUNCH("mgx_linear_dx");
     return MGX_OK;
 }
@@ -558,5 +595,35 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, gb, M,
                        N, K, mchunk);
     MGX_CHECK_LAUNCH("mgx_linear_dw");
+    return MGX_OK;
+}
+
+extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* stream) {
+    MGX_REQUIRE(problems && count > 0 && count <= MGX_DW_MAX_GROUP && M > 0, MGX_ERR_SHAPE,
+                "mgx_linear_dw_grouped: need 1..%d problems and M > 0 (got %d, M=%d)", MGX_DW_MAX_GROUP, count, M);
+    DwGroup g;
+    g.n = count;
+    g.first_tile[0] = 0;
+    for (int i = 0; i < count; ++i) {
+        const mgx_dw_problem& q = problems[i];
+        MGX_REQUIRE(q.dY && q.X && q.gW, MGX_ERR_NULL, "mgx_linear_dw_grouped: NULL pointer in problem %d", i);
+        MGX_REQUIRE(q.N > 0 && q.K > 0 && q.N % 8 == 0 && q.K % 8 == 0, MGX_ERR_SHAPE,
+                    "mgx_linear_dw_grouped: need N%%8==0 and K%%8==0 (problem %d: N=%d K=%d)", i, q.N, q.K);
+        g.dY[i] = q.dY; g.X[i] = q.X; g.gW[i] = q.gW; g.gb[i] = q.gb; g.N[i] = q.N; g.K[i] = q.K;
+        g.first_tile[i + 1] = g.first_tile[i] + ((q.N + BM - 1) / BM) * ((q.K + BN - 1) / BN);
+    }
+    set_attrs();
+    const int tiles = g.first_tile[count];
+    static int target = -1;
+    if (target < 0) {
+        const char* e = getenv("MGX_DW_GROUP_WGS");
+        target = e ? atoi(e) : 480;                        // ~2 workgroups on every CU
+    }
+    int splits = (target + tiles - 1) / tiles;
+    int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
+    if (mchunk < 64) mchunk = 64;
+    splits = (M + mchunk - 1) / mchunk;
+    hipLaunchKernelGGL(linear_dw_grouped_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, g, M, mchunk);
+    MGX_CHECK_LAUNCH("mgx_linear_dw_grouped");
     return MGX_OK;
 }

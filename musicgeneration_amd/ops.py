@@ -9,6 +9,8 @@ from __future__ import annotations
 import math
 from typing import Optional, Tuple
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -223,6 +225,29 @@ def linear_dw(dy, x, gw, gb=None):
     check(_lib.load().mgx_linear_dw(ptr(dy), ptr(x), ptr(gw), ptr(gb), Mrows, N, K, stream_ptr()), "mgx_linear_dw")
 
 
+class _DwProblem(ctypes.Structure):          # mirrors mgx_dw_problem (include/mgx.h)
+    _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("gW", ctypes.c_void_p), ("gb", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
+def linear_dw_grouped(problems):
+    """problems: list of (dy bf16 [..,N], x bf16 [..,K], gw f32 [N,K], gb f32 [N] or None) sharing the row count:
+    all weight (and bias) gradients in one launch."""
+    arr = (_DwProblem * len(problems))()
+    Mrows = None
+    for i, (dy, x, gw, gb) in enumerate(problems):
+        _need_cuda(dy, x, gw, gb)
+        N, K = gw.shape
+        rows = dy.numel() // N
+        if Mrows is None:
+            Mrows = rows
+        if rows != Mrows or x.numel() != rows * K or not (dy.is_contiguous() and x.is_contiguous()):
+            raise ValueError("linear_dw_grouped: all problems need contiguous dy [M,N], x [M,K] with the same M")
+        arr[i] = _DwProblem(ptr(dy), ptr(x), ptr(gw), ptr(gb), N, K)
+    check(_lib.load().mgx_linear_dw_grouped(ctypes.cast(arr, ctypes.c_void_p), len(problems), Mrows, stream_ptr()),
+          "mgx_linear_dw_grouped")
+
+
 # ---- decode path (no autograd) ----------------------------------------------------------------------
 def decode_embed(tok, table, pe, pos_dev, out):
     _need_cuda(tok, table, pe, pos_dev, out)
@@ -378,21 +403,18 @@ class _EncoderLayer(torch.autograd.Function):
         # LN2 <- FFN_suf <- ReLU <- FFN_pre, residual o1
         df2, dres2 = add_ln_bwd(dout.contiguous(), f2, o1, lp.g2, mean2, rstd2, lp.gg2, lp.gb2, p_drop, seed + 2, lp.gbsuf)
         df1 = linear_dx(df2, lp.wsuf, f1)
-        linear_dw(df2, f1, lp.gwsuf, None)
-        del df2
         do1 = linear_dx(df1, lp.wpre, None, dres2)
-        linear_dw(df1, o1, lp.gwpre, lp.gbpre)
-        del df1, dres2
+        del dres2
         # LN1 <- fc <- attention <- QKV, residual h
         da, dres1 = add_ln_bwd(do1, a, h, lp.g1, mean1, rstd1, lp.gg1, lp.gb1, p_drop, seed + 1, lp.gbfc)
         del do1
         datt = linear_dx(da, lp.wfc)
-        linear_dw(da, att, lp.gwfc, None)
-        del da
         dqkv = rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE)
         del datt
         dh = linear_dx(dqkv, lp.wqkv, None, dres1)
-        linear_dw(dqkv, h, lp.gqkv, lp.gbqkv)
+        # the block's four weight gradients (and the two bias gradients that are not LayerNorm by-products) in one launch
+        linear_dw_grouped([(dqkv, h, lp.gqkv, lp.gbqkv), (da, att, lp.gwfc, None), (df1, o1, lp.gwpre, lp.gbpre),
+                           (df2, f1, lp.gwsuf, None)])
         if done is not None:
             done()
         return dh, None, None, None, None, None, None

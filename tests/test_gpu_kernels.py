@@ -349,3 +349,29 @@ def test_linear_backward_kernels(M, N, K, relu):
     ref_gb = gb0 + dy.float().sum(0)
     assert _relerr(gw.cpu(), ref_gw) < 1e-4
     assert _relerr(gb.cpu(), ref_gb) < 1e-4
+
+
+def test_linear_dw_grouped_matches_separate_launches():
+    """one launch for several weight gradients == the per-weight launches (same kernels body, other M-split)"""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    M = 1500
+    shapes = [(384, 128), (128, 128), (64, 128), (128, 64)]          # (N, K) like QKV / fc / FFN_pre / FFN_suf
+    probs, refs = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        gw0 = torch.randn(N, K, generator=g).to(dev)
+        gb0 = torch.randn(N, generator=g).to(dev) if i % 2 == 0 else None
+        gw, gb = gw0.clone(), (gb0.clone() if gb0 is not None else None)
+        probs.append((dy, x, gw, gb))
+        refs.append((gw0 + dy.float().t() @ x.float(), None if gb0 is None else gb0 + dy.float().sum(0)))
+    ops.linear_dw_grouped(probs)
+    torch.cuda.synchronize()
+    for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
+        assert _relerr(gw.cpu(), rw.cpu()) < 1e-4
+        if gb is not None:
+            assert _relerr(gb.cpu(), rb.cpu()) < 1e-4
+    with pytest.raises(ValueError):
+        ops.linear_dw_grouped([probs[0], (probs[1][0][:100], probs[1][1][:100], probs[1][2], None)])
