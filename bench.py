@@ -97,8 +97,9 @@ def time_kernels(B, L, d, M, reps=10):
         return e0.elapsed_time(e1) / reps
 
     out = {"rel_attn_fwd_kernel": timed(lambda: ops.rel_attn_fwd(qkv, E, None))}
+    # parts bits of mgx_rel_attn_bwd_parts; the dE kernel streams the dS tiles the dQ kernel left in `ws`
     for name, bit in (("attn_delta_kernel", 1), ("rel_attn_dq_kernel", 2), ("rel_attn_dkv_kernel", 4),
-                      ("rel_attn_de_kernel", 8)):
+                      ("rel_attn_de_stream_kernel", 8)):
         out[name] = timed(lambda bit=bit: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, bit, dqkv, ws))
     return out
 
@@ -135,18 +136,20 @@ def pmc_traffic(dom, B, L, d):
     """HBM bytes per launch of the dominant op from the committed PMC passes (tools/traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
     Only reported when this run has the shape the counters were collected on (cfg2, per-GPU batch 16)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_cfg2_b16.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_cfg2_b16_v2.json")
     if not os.path.exists(path) or (B, L, d) != (16, 2048, 512):
         return {"traffic": None}
     k = json.load(open(path))["kernels"]
-    names = (["attn_delta_kernel", "er_transpose_kernel", "rel_attn_dq_kernel", "rel_attn_dkv_kernel", "rel_attn_de_kernel"]
+    names = (["attn_delta_kernel", "er_transpose_kernel", "void rel_attn_dq_kernel<true>", "rel_attn_dkv_kernel",
+              "rel_attn_de_stream_kernel"]
              if dom.startswith("mgx_rel_attn_bwd") else ["void rel_attn_fwd_kernel<false>"])
     if any(n not in k for n in names):
         return {"traffic": None}
     tr = sum(k[n]["hbm_bytes_per_launch"] for n in names)
-    # algorithmic bytes: bf16 Q,K,V,O(,dO) in + O (or dQ,dK,dV) out, E and dE are 256 KiB and ignored
+    # algorithmic bytes: bf16 Q,K,V,O(,dO) in + O (or dQ,dK,dV) out, E and dE are 256 KiB and ignored.  (The backward
+    # additionally moves the dS tiles through HBM by design: 2 x B*h*L*L/2 * 2 bytes, see DESIGN.md)
     nbuf = 8 if dom.startswith("mgx_rel_attn_bwd") else 4
-    return {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b16.json)",
+    return {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b16_v2.json)",
             "algorithmic_bytes_per_launch": nbuf * B * L * d * 2}
 
 
@@ -240,17 +243,18 @@ def main():
         kt = time_kernels(B, L, d, L)
         # credited (algorithmic) and executed product-units per kernel; 1 unit = B*L^2*d FLOPs
         credited = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 2.5, "rel_attn_dkv_kernel": 2.5,
-                    "rel_attn_de_kernel": 1.0}
+                    "rel_attn_de_stream_kernel": 1.0}
         executed = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 5.0, "rel_attn_dkv_kernel": 6.0,
-                    "rel_attn_de_kernel": 6.0}
+                    "rel_attn_de_stream_kernel": 1.0}
         per_kernel = {k: {"ms": kt[k], "credited_tflops": attn_flops_per_launch(B, L, d, credited[k]) / (kt[k] * 1e-3) / 1e12,
                           "executed_tflops": attn_flops_per_launch(B, L, d, executed[k]) / (kt[k] * 1e-3) / 1e12}
                       for k in credited}
         # the dominant launch of the step is the attention backward (ONE C-ABI call, mgx_rel_attn_bwd =
         # delta/transposed-E pre-pass + dQ + dK/dV + dE kernels): 6 credited units per launch
-        bwd_ms = kt["attn_delta_kernel"] + kt["rel_attn_dq_kernel"] + kt["rel_attn_dkv_kernel"] + kt["rel_attn_de_kernel"]
+        bwd_ms = (kt["attn_delta_kernel"] + kt["rel_attn_dq_kernel"] + kt["rel_attn_dkv_kernel"]
+                  + kt["rel_attn_de_stream_kernel"])
         fwd_ms = kt["rel_attn_fwd_kernel"]
-        dom, dom_ms, dom_units, dom_exec = (("mgx_rel_attn_bwd (pre-pass + dq + dkv + de kernels)", bwd_ms, 6.0, 17.0)
+        dom, dom_ms, dom_units, dom_exec = (("mgx_rel_attn_bwd (pre-pass + dq + dkv + de kernels)", bwd_ms, 6.0, 12.0)
                                             if bwd_ms >= fwd_ms else ("rel_attn_fwd_kernel", fwd_ms, 3.0, 3.0))
         ach = attn_flops_per_launch(B, L, d, dom_units) / (dom_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
@@ -264,7 +268,7 @@ def main():
         out["attention_all_kernels"] = {
             "ms_per_layer": sum(kt.values()),
             "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12,
-            "executed_tflops": attn_flops_per_launch(B, L, d, 20.0) / (sum(kt.values()) * 1e-3) / 1e12}
+            "executed_tflops": attn_flops_per_launch(B, L, d, 15.0) / (sum(kt.values()) * 1e-3) / 1e12}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

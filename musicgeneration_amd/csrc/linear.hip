@@ -432,10 +432,13 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __restrict__ dY,
                                                            const uint16_t* __restrict__ X,
                                                            float* __restrict__ gW, float* __restrict__ gb, int M, int N,
-                                                           int K, int mchunk) {
+                                                           int K, int mchunk, int tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int mbeg = blockIdx.y * mchunk;
-    dw_tile(dY, X, gW, gb, M, N, K, blockIdx.x, mbeg, min(M, mbeg + mchunk), smem);
+    // 1-D grid of tiles x splits units, unit = split * tiles + tile; each XCD walks a contiguous run of units, i.e.
+    // (mostly) the tiles of ONE row chunk: the dY / X blocks those tiles share are fetched into that XCD's L2 once
+    const int u = xcd_remap(blockIdx.x, gridDim.x);
+    const int mbeg = (u / tiles) * mchunk;
+    dw_tile(dY, X, gW, gb, M, N, K, u % tiles, mbeg, min(M, mbeg + mchunk), smem);
 }
 
 // Several weight gradients that share the row count M (one encoder block's QKV / fc / FFN projections) in ONE launch:
@@ -453,10 +456,13 @@ struct DwGroup {
 
 __global__ __launch_bounds__(256, 2) void linear_dw_grouped_kernel(const DwGroup g, int M, int mchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles = g.first_tile[g.n];
+    const int u = xcd_remap(blockIdx.x, gridDim.x);        // see linear_dw_kernel
+    const int t = u % tiles;
     int p = 0;
-    while (p + 1 < g.n && (int)blockIdx.x >= g.first_tile[p + 1]) ++p;
-    const int mbeg = blockIdx.y * mchunk;
-    dw_tile(g.dY[p], g.X[p], g.gW[p], g.gb[p], M, g.N[p], g.K[p], blockIdx.x - g.first_tile[p], mbeg, min(M, mbeg + mchunk), smem);
+    while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
+    const int mbeg = (u / tiles) * mchunk;
+    dw_tile(g.dY[p], g.X[p], g.gW[p], g.gb[p], M, g.N[p], g.K[p], t - g.first_tile[p], mbeg, min(M, mbeg + mchunk), smem);
 }
 
 // =================================================================================================
@@ -592,8 +598,8 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
     if (mchunk < 64) mchunk = 64;
     splits = (M + mchunk - 1) / mchunk;
-    hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, gb, M,
-                       N, K, mchunk);
+    hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, gb, M,
+                       N, K, mchunk, tiles);
     MGX_CHECK_LAUNCH("mgx_linear_dw");
     return MGX_OK;
 }
@@ -623,7 +629,7 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, 
     int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
     if (mchunk < 64) mchunk = 64;
     splits = (M + mchunk - 1) / mchunk;
-    hipLaunchKernelGGL(linear_dw_grouped_kernel, dim3(tiles, splits), dim3(256), LDS_BYTES, (hipStream_t)stream, g, M, mchunk);
+    hipLaunchKernelGGL(linear_dw_grouped_kernel, dim3(tiles * splits), dim3(256), LDS_BYTES, (hipStream_t)stream, g, M, mchunk);
     MGX_CHECK_LAUNCH("mgx_linear_dw_grouped");
     return MGX_OK;
 }
