@@ -246,7 +246,8 @@ def test_adam_matches_torch():
 
 
 @pytest.mark.parametrize("B,L,d,M,padcase", [(1, 32, 64, 32, 0), (2, 64, 128, 64, 1), (1, 160, 64, 192, 0),
-                                              (2, 256, 128, 256, 1), (1, 512, 128, 512, 0), (3, 416, 128, 416, 1)])
+                                              (2, 256, 128, 256, 1), (1, 512, 128, 512, 0), (3, 416, 128, 416, 1),
+                                              (3, 96, 192, 96, 1), (5, 32, 64, 40, 0)])
 def test_rel_attn_bwd_matches_oracle_autograd(B, L, d, M, padcase):
     """dq/dk/dv/dE of the three backward kernels vs autograd through the oracle (fp32, same bf16 inputs)."""
     from musicgeneration_amd import ops
