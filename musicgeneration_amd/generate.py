@@ -1,6 +1,7 @@
 """Drop-in for mg/model/MusicTransformer/generate.py:18-123: load a checkpoint, print a 2-sample test
 loss/accuracy, sample ``--max-length`` events from a prior and write them out.
-MIDI output needs pretty_midi (optional); without it the event-index arrays are saved as .npy."""
+MIDI-like samples are written as .mid files (pretty_midi if installed, else the built-in SMF writer, smf.py);
+REMI / MuMIDI samples are saved as event-index arrays (.npy): their MIDI writers need miditoolkit."""
 from __future__ import annotations
 
 import optparse
@@ -59,12 +60,12 @@ def main(argv=None):
     os.makedirs(o.output_dir, exist_ok=True)
     for i, seq in enumerate(res):
         name = os.path.join(o.output_dir, f'gen-{i:03d}')
-        try:
+        if o.repr == 'midi_like':
             n = utils.event_indeces_to_midi_file(seq, name + '.mid')
             print('===> {} ({} notes)'.format(name + '.mid', n))
-        except ImportError:
+        else:       # REMI / MuMIDI writers need miditoolkit (REMI.py:538-674, MuMIDI.py:576-704): keep the event ids
             np.save(name + '.npy', seq.astype(np.uint16))
-            print('===> {} (pretty_midi absent: event indices saved)'.format(name + '.npy'))
+            print('===> {} (event indices)'.format(name + '.npy'))
 
 
 if __name__ == '__main__':

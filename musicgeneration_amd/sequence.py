@@ -54,17 +54,29 @@ class NoteSeq:
 
     @staticmethod
     def from_midi_file(path, *args, **kwargs):
-        from pretty_midi import PrettyMIDI   # optional dependency
+        """sequence.py:44-46 -> from_midi (:37-41): non-drum notes of the selected programs.  Uses pretty_midi when it
+        is installed (the reference's parser), otherwise the built-in SMF reader (smf.py)."""
+        programs = kwargs.get('programs', DEFAULT_LOADING_PROGRAMS)
+        try:
+            from pretty_midi import PrettyMIDI
+        except ImportError:
+            from . import smf
+            return NoteSeq([Note(v, p, s, e) for v, p, s, e in smf.read_notes(path, programs)])
         import itertools
         midi = PrettyMIDI(path)
-        programs = kwargs.get('programs', DEFAULT_LOADING_PROGRAMS)
         notes = itertools.chain(*[inst.notes for inst in midi.instruments
                                   if inst.program in programs and not inst.is_drum])
         return NoteSeq(list(notes))
 
     def to_midi_file(self, path, program=DEFAULT_SAVING_PROGRAM, resolution=DEFAULT_RESOLUTION,
                      tempo=DEFAULT_TEMPO):
-        from pretty_midi import PrettyMIDI, Instrument, Note as PMNote   # optional dependency
+        """sequence.py:65-77: one instrument, constant tempo.  pretty_midi when installed, else smf.write_notes."""
+        try:
+            from pretty_midi import PrettyMIDI, Instrument, Note as PMNote
+        except ImportError:
+            from . import smf
+            smf.write_notes(path, [(n.velocity, n.pitch, n.start, n.end) for n in self.notes], program, resolution, tempo)
+            return
         midi = PrettyMIDI(resolution=resolution, initial_tempo=tempo)
         inst = Instrument(program, False, 'NoteSeq')
         inst.notes = [PMNote(int(n.velocity), int(n.pitch), n.start, n.end) for n in self.notes]

@@ -60,7 +60,7 @@ def get_masked_with_pad_tensor(size, src, trg, pad_token):
 
 
 def event_indeces_to_midi_file(event_indeces, midi_file_name, velocity_scale=0.8):
-    """utils.py:25-31 (MIDI writing needs pretty_midi, an optional dependency)."""
+    """utils.py:25-31"""
     from .sequence import EventSeq
     event_seq = EventSeq.from_array(event_indeces)
     note_seq = event_seq.to_note_seq()

@@ -76,3 +76,43 @@ def test_note_seq_roundtrip():
     back = EventSeq.from_array(arr).to_note_seq().notes
     assert [n.pitch for n in back] == [60, 64, 67]
     assert abs(back[0].start - 0.0) < 1e-9 and abs(back[1].start - 0.25) < 1e-6 and abs(back[2].start - 1.5) < 1e-6
+
+
+def test_smf_roundtrip_and_event_pipeline(tmp_path):
+    """event ids -> EventSeq -> NoteSeq -> .mid -> NoteSeq: the dependency-free SMF writer/reader keeps every note
+    (times to one tick: 60/(120*220) s) -- the decode->MIDI leg of generate.py (utils.py:25-31, sequence.py:37-77)."""
+    import numpy as np
+    from musicgeneration_amd import smf, utils
+    from musicgeneration_amd.sequence import EventSeq, Note, NoteSeq
+    rng = np.random.default_rng(0)
+    notes, t = [], 0.0
+    for i in range(200):                      # a pitch recurs only after 88 notes: no same-pitch overlaps (ambiguous in MIDI)
+        t += float(rng.uniform(0.02, 0.4))
+        dur = float(rng.uniform(0.05, 1.5))
+        notes.append(Note(int(rng.integers(1, 128)), 21 + (37 * i) % 88, t, t + dur))
+    path = str(tmp_path / "a.mid")
+    NoteSeq(notes).to_midi_file(path)
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"MThd" and raw[8:14] == bytes([0, 1, 0, 2, 0, 220])          # format 1, 2 tracks, 220 tpq
+    back = NoteSeq.from_midi_file(path).notes
+    assert len(back) == len(notes)
+    tick = 60.0 / (120 * 220)
+    key = lambda n: (round(n.start / tick), n.pitch)
+    for a, b in zip(sorted(notes, key=key), sorted(back, key=key)):
+        assert a.pitch == b.pitch and a.velocity == b.velocity
+        assert abs(a.start - b.start) <= tick and abs(a.end - b.end) <= tick
+    # program filter and drum channel
+    smf.write_notes(str(tmp_path / "d.mid"), [(90, 40, 0.0, 0.5)], program=5, is_drum=True)
+    assert smf.read_notes(str(tmp_path / "d.mid")) == []
+    smf.write_notes(str(tmp_path / "p.mid"), [(90, 40, 0.0, 0.5)], program=5)
+    assert len(smf.read_notes(str(tmp_path / "p.mid"), programs=[5])) == 1
+    assert smf.read_notes(str(tmp_path / "p.mid"), programs=[0]) == []
+    # the generate.py leg: ids -> file -> ids reproduces the note content
+    es = EventSeq.from_note_seq(NoteSeq(notes[:50]))
+    ids = es.to_array()
+    n = utils.event_indeces_to_midi_file(ids, str(tmp_path / "g.mid"), velocity_scale=1.0)
+    got = NoteSeq.from_midi_file(str(tmp_path / "g.mid")).notes
+    assert n == len(got) > 0
+    ids2 = EventSeq.from_note_seq(NoteSeq(got)).to_array()
+    pitch_on = lambda a: [int(v) for v in a if v < 88]
+    assert pitch_on(ids) == pitch_on(ids2)
