@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops */
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -184,6 +184,23 @@ int mgx_gather_rows(const int32_t* tok, const uint16_t* table, uint16_t* out, in
 /* torch.nn.GRU cell, gate order (r,z,n): gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh bf16 [B,3H];
  * h f32 [B,H] is updated in place, h_bf16 [B,H] receives its bf16 copy (input of the next projection). */
 int mgx_gru_gates(const uint16_t* gi, const uint16_t* gh, float* h, uint16_t* h_bf16, int B, int H, void* stream);
+
+/* ---- K13b: Event_Melody_RNN training (Event_MelodyRNN/network.py:63-84,109-116 SeqForward/Train; torch.nn.GRU cell).
+ * The sequence's input projections are one mgx_linear_fwd per layer; per time step the recurrent projection
+ * (mgx_linear_fwd, M = B) and this cell remain:  h_next f32, y bf16 [B,H] = cell(gi, gh bf16 [B,3H], h_prev f32).   */
+int mgx_gru_cell_fwd(const uint16_t* gi, const uint16_t* gh, const float* h_prev, float* h_next, uint16_t* y,
+                     int B, int H, void* stream);
+/* backward of one step: dh = dh_direct (f32) + d_rec (bf16: step t+1's dgh @ W_hh) + dy (bf16: layer above), each
+ * may be NULL; gates are recomputed from gi/gh.  Out: dgi, dgh bf16 [B,3H], dh_prev_direct f32 [B,H] = dh * z.   */
+int mgx_gru_cell_bwd(const uint16_t* gi, const uint16_t* gh, const float* h_prev, const float* dh_direct,
+                     const uint16_t* d_rec, const uint16_t* dy, uint16_t* dgi, uint16_t* dgh,
+                     float* dh_prev_direct, int B, int H, void* stream);
+/* inverted dropout on a bf16 buffer (nn.GRU's inter-layer dropout); stateless mask = f(seed, index): calling it on
+ * the gradient with the same (p, seed) is its backward.  n % 8 == 0.                                             */
+int mgx_dropout_bf16(const uint16_t* x, uint16_t* out, size_t n, float p_drop, uint64_t seed, void* stream);
+/* dst f32 [V,cols] row idx[r] += src bf16 [n,ld] row r, columns 0..cols-1 (nn.Embedding backward).                */
+int mgx_scatter_add_rows(const int32_t* idx, const uint16_t* src, float* dst, int n, int ld, int cols, int V,
+                         void* stream);
 
 #ifdef __cplusplus
 }

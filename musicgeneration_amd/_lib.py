@@ -37,6 +37,10 @@ SIGNATURES = {
     "mgx_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_gru_gates": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_linear_dx": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mgx_gru_cell_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mgx_gru_cell_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mgx_dropout_bf16": [_vp, _vp, _sz, _f, _u64, _vp],
+    "mgx_scatter_add_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_linear_dw_grouped": [_vp, _i, _i, _vp],
     "mgx_linear_dw": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }

@@ -4,9 +4,10 @@
 row gather, two bf16 MFMA projections per layer (bias fused), one fused gate kernel per layer, the output
 projection and the fused sampler; the whole step is captured in a graph when it is replayed many times.
 
-Scope: sampling (the north-star's cfg5 alternative reading).  ``Train`` is forward-only here (teacher-forced
-logits, used for parity); the GRU training backward and beam search (broken in the reference)
-are not built."""
+``Train`` (teacher-forced logits) is differentiable: ``_GRUSeq`` runs the sequence's input projections as one GEMM per
+layer, the recurrent projection + fused cell per step, and backward-through-time with one cell-backward kernel and one
+recurrent dX GEMM per step; weight gradients are batched over the whole sequence.  Not built: packed variable-length
+batches (``lengths``) and beam search (broken in the reference)."""
 from __future__ import annotations
 
 import numpy as np
@@ -23,6 +24,95 @@ def _pad_cols(w: torch.Tensor, k: int) -> torch.Tensor:
     out = torch.zeros(w.shape[0], k, dtype=BF16, device=w.device)
     out[:, : w.shape[1]] = w.to(BF16)
     return out.contiguous()
+
+
+class _GRUSeq(torch.autograd.Function):
+    """Teacher-forced multi-layer GRU + output projection over a whole sequence (network.py:63-84 SeqForward with the
+    primary step folded in as step 0), forward and backward-through-time on the libmgx kernels.
+
+    forward(tokens int32 [T,B], h0 f32 [layers,B,H], pk (packed bf16 operands), p_drop, seed, *params)
+    -> logits f32 [T,B,V].  ``params`` = embedding, (w_ih, w_hh, b_ih, b_hh) per layer, output weight, output bias:
+    they are only there so that autograd routes the gradients this node returns into their ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, tokens, h0, pk, p_drop, seed, *params):
+        T, B = tokens.shape
+        nl, H = h0.shape[0], h0.shape[2]
+        dev = h0.device
+        tok = tokens.reshape(-1).contiguous()
+        x = torch.empty(T * B, pk["Ep"], dtype=BF16, device=dev)
+        check(_load().mgx_gather_rows(ptr(tok), ptr(pk["emb"]), ptr(x), T * B, pk["Ep"], pk["emb"].shape[0], stream_ptr()),
+              "mgx_gather_rows")
+        saved = []
+        for l, ly in enumerate(pk["layers"]):
+            gi = ops.linear_fwd(x, ly["wih"], ly["bih"], 0).view(T, B, 3 * H)       # all time steps in one GEMM
+            h_all = torch.empty(T + 1, B, H, dtype=torch.float32, device=dev)
+            hp = torch.empty(T + 1, B, H, dtype=BF16, device=dev)                   # hp[t] = bf16(h_{t-1}); y = hp[1:]
+            h_all[0].copy_(h0[l])
+            hp[0].copy_(h0[l])
+            gh = []
+            for t in range(T):
+                g = ops.linear_fwd(hp[t], ly["whh"], ly["bhh"], 0)
+                ops.gru_cell_fwd(gi[t], g, h_all[t], h_all[t + 1], hp[t + 1])
+                gh.append(g)
+            saved.append((x, gi, gh, h_all, hp))
+            x = hp[1:].reshape(T * B, H)
+            if l < nl - 1:
+                x = ops.dropout_bf16(x, p_drop, seed + l)
+        logits = ops.linear_fwd(x, pk["wo"], pk["bo"], 0)
+        ctx.pk, ctx.saved, ctx.cfg, ctx.x_last, ctx.tok = pk, saved, (T, B, H, nl, p_drop, seed), x, tok
+        ctx.shapes = [p.shape for p in params]
+        V = params[0].shape[0]
+        return logits[:, :V].float().view(T, B, V)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        pk, saved = ctx.pk, ctx.saved
+        T, B, H, nl, p_drop, seed = ctx.cfg
+        dev = dlogits.device
+        V, Vp = ctx.shapes[0][0], pk["wo"].shape[0]
+        dl = torch.zeros(T * B, Vp, dtype=BF16, device=dev)
+        dl[:, :V] = dlogits.reshape(T * B, V)
+        g_wo = torch.zeros(Vp, H, device=dev)
+        g_bo = torch.zeros(Vp, device=dev)
+        ops.linear_dw(dl, ctx.x_last, g_wo, g_bo)
+        dx = ops.linear_dx(dl, pk["wo"])                                            # [T*B, H]
+        dh0 = torch.empty(nl, B, H, device=dev)
+        layer_grads = [None] * nl
+        for l in reversed(range(nl)):
+            ly = pk["layers"][l]
+            x_in, gi, gh, h_all, hp = saved[l]
+            if l < nl - 1:
+                dx = ops.dropout_bf16(dx, p_drop, seed + l)
+            dy = dx.view(T, B, H)
+            dgi = torch.empty(T, B, 3 * H, dtype=BF16, device=dev)
+            dgh = torch.empty(T, B, 3 * H, dtype=BF16, device=dev)
+            dh_dir = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
+            d_rec = None
+            for t in reversed(range(T)):
+                cur = dh_dir[t & 1]
+                ops.gru_cell_bwd(gi[t], gh[t], h_all[t], None if t == T - 1 else dh_dir[(t + 1) & 1], d_rec, dy[t], dgi[t],
+                                 dgh[t], cur)
+                d_rec = ops.linear_dx(dgh[t], ly["whh"])
+            dh0[l] = dh_dir[0] + d_rec.float()
+            in_p = ly["wih"].shape[1]
+            g_wih = torch.zeros(3 * H, in_p, device=dev)
+            g_whh = torch.zeros(3 * H, H, device=dev)
+            g_bih = torch.zeros(3 * H, device=dev)
+            g_bhh = torch.zeros(3 * H, device=dev)
+            ops.linear_dw_grouped([(dgi.view(T * B, 3 * H), x_in, g_wih, g_bih),
+                                   (dgh.view(T * B, 3 * H), hp[:-1].reshape(T * B, H), g_whh, g_bhh)])
+            layer_grads[l] = (g_wih, g_whh, g_bih, g_bhh)
+            dx = ops.linear_dx(dgi.view(T * B, 3 * H), ly["wih"])                   # gradient of the layer's input
+        g_emb = torch.zeros(ctx.shapes[0], device=dev)
+        ops.scatter_add_rows(ctx.tok, dx, g_emb)
+        grads = [g_emb]
+        for l in range(nl):
+            g_wih, g_whh, g_bih, g_bhh = layer_grads[l]
+            grads += [g_wih[:, : ctx.shapes[1 + 4 * l][1]], g_whh, g_bih, g_bhh]
+        grads += [g_wo[:V], g_bo[:V]]
+        ctx.saved = None
+        return (None, dh0, None, None, None) + tuple(grads)
 
 
 class Event_Melody_RNN(nn.Module):
@@ -53,7 +143,7 @@ class Event_Melody_RNN(nn.Module):
         if dev.type != "cuda":
             raise ops._lib.MgxError("Event_Melody_RNN runs on the MI355X kernels only: move it to a HIP device")
         Ep = (self.event_dim + 63) // 64 * 64            # embedding width padded to the GEMM's K % 64
-        Vp = (self.event_dim + 3) // 4 * 4               # output rows padded to N % 4
+        Vp = (self.event_dim + 7) // 8 * 8               # output rows padded to N % 8 (forward needs 4, dX/dW 8)
         pk = {"ver": ver, "dev": dev, "Ep": Ep, "Vp": Vp,
               "emb": _pad_cols(self.event_embedding.weight.data, Ep), "layers": []}
         for l in range(self.rnn_layers):
@@ -113,20 +203,24 @@ class Event_Melody_RNN(nn.Module):
     def forward(self, event, hidden=None):
         return self.gen_forward(event, hidden)
 
-    @torch.no_grad()
     def Train(self, init, events, lengths=None):
-        """Teacher-forced logits [T+1,B,V] (network.py:63-84,109-116), forward only."""
+        """Teacher-forced logits [T+1,B,V] (network.py:63-84,109-116): the primary event, then ``events``, through the
+        GRU from ``init_to_hidden(init)``; differentiable (backward-through-time on the libmgx kernels), with nn.GRU's
+        inter-layer dropout in training mode."""
         if lengths is not None:
             raise NotImplementedError("packed variable-length batches are not built")
-        hidden = self.init_to_hidden(init)
-        outs = []
-        ev = self.get_primary_event(init.shape[0])
-        o, hidden = self.gen_forward(ev, hidden)
-        outs.append(o)
-        for t in range(events.shape[0]):
-            o, hidden = self.gen_forward(events[t:t + 1], hidden)
-            outs.append(o)
-        return torch.cat(outs, 0)
+        pk = self._pack()
+        hidden = self.init_to_hidden(init).float().contiguous()
+        B = init.shape[0]
+        tokens = torch.cat([self.get_primary_event(B), events.to(pk["dev"]).long()], 0).to(torch.int32).contiguous()
+        p_drop = float(self.rnn.dropout) if self.training else 0.0
+        self._train_calls = getattr(self, "_train_calls", 0) + 1
+        params = [self.event_embedding.weight]
+        for l in range(self.rnn_layers):
+            params += [getattr(self.rnn, f"{n}_l{l}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+        params += [self.output_fc.weight, self.output_fc.bias]
+        seed = (torch.initial_seed() + 7919 * self._train_calls) & 0x7FFFFFFFFFFF
+        return _GRUSeq.apply(tokens, hidden, pk, p_drop, seed, *params)
 
     @torch.no_grad()
     def generate(self, init, steps, events=None, greedy=1.0, temperature=1.0, teacher_forcing_ratio=1.0,

@@ -225,6 +225,39 @@ def linear_dw(dy, x, gw, gb=None):
     check(_lib.load().mgx_linear_dw(ptr(dy), ptr(x), ptr(gw), ptr(gb), Mrows, N, K, stream_ptr()), "mgx_linear_dw")
 
 
+# ---- Event_Melody_RNN training ops (raw launchers; the autograd node lives in melody_rnn.py) ----------------------
+def gru_cell_fwd(gi, gh, h_prev, h_next, y):
+    """h_next f32 / y bf16 [B,H] <- GRU cell(gi, gh bf16 [B,3H], h_prev f32 [B,H])"""
+    _need_cuda(gi, gh, h_prev, h_next, y)
+    B, H = h_prev.shape
+    check(_lib.load().mgx_gru_cell_fwd(ptr(gi), ptr(gh), ptr(h_prev), ptr(h_next), ptr(y), B, H, stream_ptr()), "mgx_gru_cell_fwd")
+
+
+def gru_cell_bwd(gi, gh, h_prev, dh_direct, d_rec, dy, dgi, dgh, dh_prev_direct):
+    _need_cuda(gi, gh, h_prev, dh_direct, d_rec, dy, dgi, dgh, dh_prev_direct)
+    B, H = h_prev.shape
+    check(_lib.load().mgx_gru_cell_bwd(ptr(gi), ptr(gh), ptr(h_prev), ptr(dh_direct), ptr(d_rec), ptr(dy), ptr(dgi), ptr(dgh),
+                                       ptr(dh_prev_direct), B, H, stream_ptr()), "mgx_gru_cell_bwd")
+
+
+def dropout_bf16(x, p_drop, seed):
+    """stateless inverted dropout; the same call on a gradient is the backward"""
+    _need_cuda(x)
+    if p_drop <= 0:
+        return x
+    out = torch.empty_like(x)
+    check(_lib.load().mgx_dropout_bf16(ptr(x), ptr(out), x.numel(), float(p_drop), int(seed), stream_ptr()), "mgx_dropout_bf16")
+    return out
+
+
+def scatter_add_rows(idx, src, dst):
+    """dst f32 [V,cols][idx[r]] += src bf16 [n,ld][r, :cols]"""
+    _need_cuda(idx, src, dst)
+    V, cols = dst.shape
+    n, ld = src.shape
+    check(_lib.load().mgx_scatter_add_rows(ptr(idx), ptr(src), ptr(dst), n, ld, cols, V, stream_ptr()), "mgx_scatter_add_rows")
+
+
 class _DwProblem(ctypes.Structure):          # mirrors mgx_dw_problem (include/mgx.h)
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("gW", ctypes.c_void_p), ("gb", ctypes.c_void_p),
                 ("N", ctypes.c_int), ("K", ctypes.c_int)]

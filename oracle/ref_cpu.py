@@ -275,3 +275,21 @@ def gru_step(p: Params, event: torch.Tensor, hid: torch.Tensor):
         x = (1 - z) * n + z * hid[l]
         new.append(x)
     return F.linear(x, p["output_fc.weight"], p["output_fc.bias"])[None], torch.stack(new)
+
+
+def gru_train_logits(p: Params, init: torch.Tensor, events: torch.Tensor, layers: int, hidden: int,
+                     primary_event: int) -> torch.Tensor:
+    """Event_Melody_RNN.Train (network.py:109-116 -> SeqForward :63-84): the primary event as step 0, then the
+    teacher-forced ``events`` int64 [T,B], through the GRU from ``init_to_hidden(init)``; logits [T+1,B,V].
+    Dropout between layers is off (eval / dropout=0), as in the golden fixture G8."""
+    hid = gru_init_hidden(p, init, layers, hidden)
+    B = init.shape[0]
+    ev = torch.full((1, B), primary_event, dtype=torch.long)
+    outs = []
+    o, hid = gru_step(p, ev, hid)
+    outs.append(o)
+    for t in range(events.shape[0]):
+        o, hid = gru_step(p, events[t:t + 1].long(), hid)
+        outs.append(o)
+    return torch.cat(outs, 0)
+
