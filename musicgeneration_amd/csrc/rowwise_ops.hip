@@ -31,31 +31,34 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(
 }
 
 // dtable[v, :] += sqrt(d) * sum_{r: tok[r]==v} dropmask * dout[r, :]     one block per vocab row
-// (deterministic: no atomics; tokens are re-scanned from L2 by every block).
+// (deterministic: no atomics; the tokens are re-scanned from L2 by every block).  The token stream is scanned in
+// chunks of 4096 into an LDS hit list, then the block's waves gather the hit rows in parallel (wave = one hit row at a
+// time, lane = 8 columns; d <= 512 per pass) and the four partial sums are folded through LDS at the end.
+constexpr int EB_CHUNK = 4096;
 __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int32_t* __restrict__ tok, const uint16_t* __restrict__ dout, float* __restrict__ dtable,
     int rows, int d, float scale, DropCfg dc) {
     const int v = blockIdx.x;
     const int gpr = d >> 3;
-    __shared__ int hits[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    __shared__ int hits[EB_CHUNK];
     __shared__ int nhit;
-    // each thread owns 8-element groups tid, tid+256, ... (d <= 2048*... handled by loop)
-    for (int g0 = 0; g0 < gpr; g0 += 256) {
-        const int gi = g0 + threadIdx.x;
+    __shared__ float part[3][64][8];
+    for (int g0 = 0; g0 < gpr; g0 += 64) {                  // column pass (one for d <= 512)
+        const int gi = g0 + lane;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int base = 0; base < rows; base += 256) {
-            if (threadIdx.x == 0) nhit = 0;
+        for (int base = 0; base < rows; base += EB_CHUNK) {
+            if (tid == 0) nhit = 0;
             __syncthreads();
-            const int r = base + threadIdx.x;
-            if (r < rows && tok[r] == v) hits[atomicAdd(&nhit, 1)] = r;
+            for (int r = base + tid; r < min(rows, base + EB_CHUNK); r += 256)
+                if (tok[r] == v) hits[atomicAdd(&nhit, 1)] = r;
             __syncthreads();
             const int n = nhit;
             if (gi < gpr) {
-                for (int k = 0; k < n; ++k) {
+                for (int k = w; k < n; k += 4) {
                     const int rr = hits[k];
-                    u32x4 w = *(const u32x4*)(dout + (size_t)rr * d + gi * 8);
                     float f[8];
-                    unpack8(w, f);
+                    unpack8(*(const u32x4*)(dout + (size_t)rr * d + gi * 8), f);
                     if (dc.thr16) {
                         float m[8];
                         drop_mult8(dc, (uint32_t)((size_t)rr * gpr + gi), m);
@@ -68,11 +71,17 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
             }
             __syncthreads();
         }
-        if (gi < gpr) {
+        if (w > 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) part[w - 1][lane][q] = acc[q];
+        }
+        __syncthreads();
+        if (w == 0 && gi < gpr) {
             float* dp = dtable + (size_t)v * d + gi * 8;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dp[q] += acc[q] * scale;
+            for (int q = 0; q < 8; ++q) dp[q] += (acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]) * scale;
         }
+        __syncthreads();
     }
 }
 // NOTE on determinism: hits[] order depends on LDS atomic arrival order, so the fp32 sum order can
