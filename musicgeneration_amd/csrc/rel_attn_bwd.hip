@@ -307,8 +307,8 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
             // the wait for the NEXT step's K/V tiles then only covers stores that have had a whole step to drain.
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                *(bf16x8*)(dsp + (size_t)dq * 1024 + 512 * ks) =
-                    *(const bf16x8*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2);
+                __builtin_nontemporal_store(*(const u32x4*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2),
+                                            (u32x4*)(dsp + (size_t)dq * 1024 + 512 * ks));   // streamed: keep K/V/E in L2
         }
         __syncthreads();
     }
@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
         const bool second = i0 + 32 < L;                   // L % 64 may be 32: the step's second query block is absent
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            areg[i] = (a_colok[i] && (i < 2 || second)) ? *(const u32x4*)(ap + a_src[i]) : u32x4{0, 0, 0, 0};
+            areg[i] = (a_colok[i] && (i < 2 || second)) ? __builtin_nontemporal_load((const u32x4*)(ap + a_src[i]))
+                                                         : u32x4{0, 0, 0, 0};       // read once: do not displace q in L2
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = qrow + 32 * i;
