@@ -6,7 +6,7 @@ the hot path over one synthetic batch: forward + label-smoothed CE/accuracy + ba
 step (+ gradient all-reduce when N > 1), dropout 0.2 as in the reference config.  Inputs are
 device-resident before the timed region.  Workload = BASELINE.json configs[1] (cfg2):
 REMI vocabulary V=337 (336 + pad), 6 layers, d_model=512 (8 heads x 64), L = max_seq = 2048, bf16
-kernels with fp32 master weights / statistics / accumulation, per-GPU batch 16 (weak scaling; the
+kernels with fp32 master weights / statistics / accumulation, per-GPU batch 32 (weak scaling; the
 reference's own default is 6, config.py:35 -- larger batches only help both sides).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling)")
     ap.add_argument("--seq-len", type=int, default=CFG2["seq_len"])
     ap.add_argument("--d-model", type=int, default=CFG2["d_model"])
     ap.add_argument("--layers", type=int, default=CFG2["layers"])
@@ -135,9 +135,9 @@ def cpu_baseline(args):
 def pmc_traffic(dom, B, L, d):
     """HBM bytes per launch of the dominant op from the committed PMC passes (tools/traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
-    Only reported when this run has the shape the counters were collected on (cfg2, per-GPU batch 16)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_cfg2_b16_v2.json")
-    if not os.path.exists(path) or (B, L, d) != (16, 2048, 512):
+    Only reported when this run has the shape the counters were collected on (cfg2, per-GPU batch 32)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_cfg2_b32.json")
+    if not os.path.exists(path) or (B, L, d) != (32, 2048, 512):
         return {"traffic": None}
     k = json.load(open(path))["kernels"]
     names = (["attn_delta_kernel", "er_transpose_kernel", "void rel_attn_dq_kernel<true>", "rel_attn_dkv_kernel",
@@ -149,7 +149,7 @@ def pmc_traffic(dom, B, L, d):
     # algorithmic bytes: bf16 Q,K,V,O(,dO) in + O (or dQ,dK,dV) out, E and dE are 256 KiB and ignored.  (The backward
     # additionally moves the dS tiles through HBM by design: 2 x B*h*L*L/2 * 2 bytes)
     nbuf = 8 if dom.startswith("mgx_rel_attn_bwd") else 4
-    return {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b16_v2.json)",
+    return {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b32.json)",
             "algorithmic_bytes_per_launch": nbuf * B * L * d * 2}
 
 

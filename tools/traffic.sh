@@ -25,7 +25,7 @@ for k in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
     f = acc["FETCH_SIZE"].get(k, [0.0]); w = acc["WRITE_SIZE"].get(k, [0.0])
     fe, wr = sum(f) / len(f), sum(w) / len(w)
     out[k] = {"launches": len(f), "fetch_kb_raw": fe, "write_kb": wr, "hbm_bytes_per_launch": (2 * fe + wr) * 1024}
-json.dump({"command": "bench.py --steps 2 --warmup 1 (cfg2, batch 16)", "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024",
+json.dump({"command": "bench.py --steps 2 --warmup 1 (cfg2, batch 32)", "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024",
            "kernels": out}, open(sys.argv[1], "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:25]:
     print(f"{k[:60]:60s} n={v['launches']:4d} {v['hbm_bytes_per_launch']/1e6:10.2f} MB/launch")
