@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libmgx.so")
+LIB_PATH = os.environ.get("MGX_LIB_PATH") or os.path.join(PKG, "libmgx.so")      # override: A/B two builds in one run
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
