@@ -110,3 +110,41 @@ def test_cfg2_model_step_is_finite_and_learns():
         losses.append(loss.item())
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0] - 0.2, losses
+
+
+def test_full_size_dE_two_ways_and_grouped_dW():
+    """At the bench's per-GPU shape (B=16 here, L=2048, d=512): the streamed dE (from the dQ kernel's dS tiles) equals the
+    full-recompute dE kernel, and the grouped dW launch equals four separate launches -- independent implementations /
+    schedules of the same sums, agreeing to fp32 accumulation order."""
+    from musicgeneration_amd import ops
+    dev = torch.device("cuda")
+    B, L, d = 16, 2048, 512
+    g = torch.Generator().manual_seed(99)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.6).to(torch.bfloat16).to(dev)
+    E = (torch.randn(L, 64, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    dctx = torch.randn(B, L, d, generator=g).to(torch.bfloat16).to(dev)
+    ctx, lse = ops.rel_attn_fwd(qkv, E, None)
+    dE1, dE2 = torch.zeros(L, 64, device=dev), torch.zeros(L, 64, device=dev)
+    dq1 = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE1)                     # pre + dQ + dK/dV + streamed dE
+    dq2 = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE2, parts=1 | 2 | 4 | 16)   # recompute dE, dQ without export
+    torch.cuda.synchronize()
+    assert torch.isfinite(dE1).all() and dE1.abs().max() > 0
+    assert _rel(dE1, dE2) < 2e-5
+    assert torch.equal(dq1, dq2)                                                    # the export does not perturb dQ/dK/dV
+    M = B * L
+    shapes = [(3 * d, d), (d, d), (d // 2, d), (d, d // 2)]
+    probs, sep = [], []
+    for i, (N, K) in enumerate(shapes):
+        dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+        gw, gb = torch.zeros(N, K, device=dev), (torch.zeros(N, device=dev) if i % 2 == 0 else None)
+        gw2, gb2 = torch.zeros(N, K, device=dev), (torch.zeros(N, device=dev) if i % 2 == 0 else None)
+        probs.append((dy, x, gw, gb))
+        ops.linear_dw(dy, x, gw2, gb2)
+        sep.append((gw2, gb2))
+    ops.linear_dw_grouped(probs)
+    torch.cuda.synchronize()
+    for (dy, x, gw, gb), (gw2, gb2) in zip(probs, sep):
+        assert _rel(gw, gw2) < 1e-5
+        if gb is not None:
+            assert _rel(gb, gb2) < 1e-5
