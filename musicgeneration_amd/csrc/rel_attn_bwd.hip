@@ -9,14 +9,17 @@
 //
 // Every output has a different "owner" axis (query row / key row / relative distance).  Summing a
 // non-owned output across workgroups with float atomics would cost >= 150 MB of atomic traffic per
-// layer at cfg2 (~1.3 TB/s chip-wide => > 100 us, more than the MFMA time), so each output gets its
-// own kernel that keeps it in registers for the whole sweep and recomputes P (flash style):
-//   K1 dq_kernel  : workgroup = 128 query rows, sweeps key tiles    (20 MFMA / 32x32 tile)
-//   K2 dkv_kernel : workgroup = 128 keys,       sweeps query tiles  (24 MFMA / tile)
-//   K3 de_kernel  : workgroup = 8 waves = 8 chunks of 32 relative distances, sweeps query tiles along
-//                   its diagonal band (24 MFMA / tile); one float-atomic flush of 64 KB per workgroup.
+// layer at cfg2 (~1.3 TB/s chip-wide => > 100 us, more than the MFMA time), so dQ and dK/dV each get
+// a kernel that keeps its output in registers for the whole sweep and recomputes P (flash style):
+//   K1 dq_kernel   : workgroup = 128 query rows, sweeps key tiles    (20 MFMA / 32x32 tile); it also
+//                    stores every dS tile, already un-skewed to (query, distance), to the workspace
+//   K2 dkv_kernel  : workgroup = 128 keys,       sweeps query tiles  (24 MFMA / tile)
+//   K3s de_stream  : dE as a plain TN product streamed from those dS tiles (HBM-bound, no recompute)
+//   K3 de_kernel   : dE by full recomputation (8 waves = 8 chunks of 32 distances along the diagonal
+//                    band, 24 MFMA / tile) -- kept as an independent cross-check (parts bit 4)
 // The skew / un-skew between (i,j) tiles and (i,delta) chunks is done through per-wave LDS band
-// buffers (see rel_attn_common.hpp); no L x L tensor ever exists.
+// buffers (see rel_attn_common.hpp); the only L x L object that ever exists is the bf16 dS workspace
+// (causal half, tile-blocked), written once and read once per layer.
 #include "rel_attn_common.hpp"
 
 using namespace relattn;
