@@ -96,7 +96,8 @@ class MusicTransformer(torch.nn.Module):
         p = self.dropout_rate if self.training else 0.0
         seed = self._next_seed()
         dp = self._dp
-        done = (lambda name: (lambda: dp.bucket_ready(name))) if (dp is not None and training) else (lambda name: None)
+        done = ((lambda name: (lambda: dp.bucket_ready(name))) if (dp is not None and dp.world > 1 and training)
+                else (lambda name: None))
 
         padbits = ops.pad_bitmap(tok, self.pad_token)
         pe = self.Decoder.pos_encoding.table()
