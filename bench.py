@@ -149,8 +149,13 @@ def pmc_traffic(dom, B, L, d):
     # algorithmic bytes: bf16 Q,K,V,O(,dO) in + O (or dQ,dK,dV) out, E and dE are 256 KiB and ignored.  (The backward
     # additionally moves the dS tiles through HBM by design: 2 x B*h*L*L/2 * 2 bytes)
     nbuf = 8 if dom.startswith("mgx_rel_attn_bwd") else 4
-    return {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b32.json)",
-            "algorithmic_bytes_per_launch": nbuf * B * L * d * 2}
+    out = {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b32.json)",
+           "algorithmic_bytes_per_launch": nbuf * B * L * d * 2}
+    if dom.startswith("mgx_rel_attn_bwd"):
+        # deliberate: the dQ kernel stores the bf16 dS tiles (causal half) and the dE kernel streams them back, instead
+        # of recomputing S/P/dP a third time
+        out["traffic_by_design_ds_roundtrip"] = 2 * (B * (d // 64) * L * L // 2) * 2
+    return out
 
 
 def main():
