@@ -1,0 +1,57 @@
+"""Worker of tests/test_gpu_dp.py: trains the real kernel-backed model for a few steps, either as ONE process on the
+full batch or as a rank of a 2-process data-parallel job (gloo all-reduce of the flat gradient buffer, both ranks on
+cuda:0), and writes the losses and a parameter checksum to a JSON file."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main(out_path):
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
+    from musicgeneration_amd.dp import DataParallel
+    from musicgeneration_amd.network import MusicTransformer
+    from musicgeneration_amd.optim import FusedAdam
+    V, d, nl, L, B = 90, 128, 2, 128, 8
+    torch.manual_seed(100 + rank)                      # ranks start DIFFERENT: the broadcast must fix that
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0).cuda().train()
+    if world == 1:
+        torch.manual_seed(100)
+        mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0).cuda().train()
+    dp = DataParallel(mt)
+    opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale)
+    sch = CustomSchedule(d, warmup_steps=20, optimizer=opt)
+    lossf = SmoothCrossEntropyLoss(0.1, V, V - 1)
+    g = torch.Generator().manual_seed(9)
+    losses = []
+    for it in range(6):
+        xf = torch.randint(0, V - 1, (B, L + 1), generator=g)          # the GLOBAL batch, pad-free
+        if world > 1:
+            xf = xf[rank * (B // world):(rank + 1) * (B // world)]
+        x, y = xf[:, :-1].to(torch.int32).cuda(), xf[:, 1:].to(torch.int32).cuda()
+        loss = lossf(mt(x), y)
+        loss.backward()
+        sch.step()                                                      # waits for the bucket all-reduces, then Adam
+        opt.zero_grad()
+        losses.append(float(dp.all_reduce_scalar_mean(loss.detach())))
+    st = mt.store()
+    res = {"losses": losses, "param_sum": float(st.param.double().sum()), "param_abs": float(st.param.double().abs().sum()),
+           "buckets": len(st.buckets), "bytes_reduced": dp.bytes_reduced}
+    if rank == 0:
+        json.dump(res, open(out_path, "w"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
