@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask */
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -172,10 +172,12 @@ int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, uint16_t* vca
  * most likely ids (0 = all) and then to the smallest set whose mass reaches top_p (1 = all).
  * out_tokens int32 [B,out_ld] (or NULL): column t+1 receives the token; probs_out f32 [B,V] (or NULL)
  * receives the unfiltered softmax.  The draw is a pure function of (seed, t, row).
- * advance != 0: pos_dev[0] += 1 after sampling.  V <= 1024.                                           */
+ * advance != 0: pos_dev[0] += 1 after sampling.  V <= 1024.
+ * allow_table (optional, NULL = none): uint32 [V, ceil(V/32)] grammar mask -- bit v of row t set iff token v may follow
+ * token t (t = the token next_tok holds on entry); disallowed logits are -inf before temperature/top-k/top-p.     */
 int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
                          uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
-                         float* probs_out, int B, int advance, void* stream);
+                         float* probs_out, int B, int advance, const uint32_t* allow_table, void* stream);
 
 /* ---- K13: Event_Melody_RNN step (Event_MelodyRNN/network.py:51-61): the GRU projections run on
  * mgx_linear_fwd; these two kernels are the rest of a step.

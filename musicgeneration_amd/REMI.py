@@ -90,6 +90,34 @@ class REMI_EventSeq:
         return idxs_feat
 
     @staticmethod
+    def next_token_table(pad: bool = True):
+        """First-order grammar of a REMI stream as ``write_midi`` reads it (utils/REMI.py:549-581): bar -> position;
+        position -> note_velocity | chord | tempo_class; note_velocity -> note_on -> note_duration; tempo_class ->
+        tempo_value; note_duration | chord | tempo_value -> position | bar.  Returns np.uint32 [V, ceil(V/32)], bit v of row
+        t set iff token v may follow token t (V = dim() + 1 with the pad id, which may follow nothing and is followed by
+        anything but itself).  Feed it to ``MusicTransformer.generate_cached(grammar=...)``: the mask is applied inside the
+        sampling kernel, raising the share of generated tokens that decode to notes."""
+        fr = REMI_EventSeq.feat_ranges()
+        V = REMI_EventSeq.dim() + (1 if pad else 0)
+        W = (V + 31) // 32
+        follow = {'bar': ['position'], 'position': ['note_velocity', 'chord', 'tempo_class'], 'note_velocity': ['note_on'],
+                  'note_on': ['note_duration'], 'note_duration': ['position', 'bar'], 'chord': ['position', 'bar'],
+                  'tempo_class': ['tempo_value'], 'tempo_value': ['position', 'bar']}
+        table = np.zeros((V, W), dtype=np.uint32)
+
+        def allow(row, names):
+            for nm in names:
+                for v in fr[nm]:
+                    table[row, v >> 5] |= np.uint32(1 << (v & 31))
+
+        for nm, rng in fr.items():
+            for t in rng:
+                allow(t, follow[nm])
+        if pad:
+            allow(V - 1, list(fr.keys()))
+        return table
+
+    @staticmethod
     def get_velocity_bins():
         n = REMI_EventSeq.velocity_range.stop - REMI_EventSeq.velocity_range.start
         return np.arange(REMI_EventSeq.velocity_range.start, REMI_EventSeq.velocity_range.stop,

@@ -33,7 +33,7 @@ SIGNATURES = {
     "mgx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_decode_embed": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_rel_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "mgx_sample_topk_topp": [_vp, _i, _i, _f, _i, _f, _u64, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "mgx_sample_topk_topp": [_vp, _i, _i, _f, _i, _f, _u64, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
     "mgx_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_gru_gates": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_linear_dx": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

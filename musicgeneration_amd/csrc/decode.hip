@@ -132,18 +132,37 @@ MGX_DEV float u01(uint64_t seed, uint32_t step, uint32_t row) {
 __global__ __launch_bounds__(64) void sample_kernel(const uint16_t* __restrict__ logits, int V, int ld, float inv_temp,
                                                     int top_k, float top_p, uint64_t seed, int32_t* __restrict__ pos_dev,
                                                     int32_t* __restrict__ next_tok, int32_t* __restrict__ out_tokens,
-                                                    int out_ld, float* __restrict__ probs_out, int B) {
+                                                    int out_ld, float* __restrict__ probs_out, int B,
+                                                    const uint32_t* __restrict__ allow_table) {
     const int row = blockIdx.x, lane = threadIdx.x;
     const uint16_t* lp = logits + (size_t)row * ld;
     float p[SMP_PER_LANE];
     float mx = -INFINITY;
+    // grammar mask: row `prev` of allow_table (bit v = token v may follow token prev); the previous
+    // token is what next_tok still holds.  A row that allows nothing is ignored.
+    const uint32_t* arow = nullptr;
+    if (allow_table) {
+        int prev = next_tok[row];
+        prev = prev < 0 ? 0 : (prev >= V ? V - 1 : prev);
+        arow = allow_table + (size_t)prev * ((V + 31) >> 5);
+    }
 #pragma unroll
     for (int i = 0; i < SMP_PER_LANE; ++i) {
         const int v = lane + 64 * i;
         p[i] = (v < V) ? bf16_to_f32(lp[v]) * inv_temp : -INFINITY;
+        if (arow && v < V && !((arow[v >> 5] >> (v & 31)) & 1u)) p[i] = -INFINITY;
         mx = fmaxf(mx, p[i]);
     }
     mx = wave_max(mx);
+    if (arow && mx == -INFINITY) {                       // empty row: fall back to the unmasked distribution
+#pragma unroll
+        for (int i = 0; i < SMP_PER_LANE; ++i) {
+            const int v = lane + 64 * i;
+            p[i] = (v < V) ? bf16_to_f32(lp[v]) * inv_temp : -INFINITY;
+            mx = fmaxf(mx, p[i]);
+        }
+        mx = wave_max(mx);
+    }
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < SMP_PER_LANE; ++i) { p[i] = (lane + 64 * i < V) ? __expf(p[i] - mx) : 0.f; sum += p[i]; }
@@ -256,12 +275,12 @@ extern "C" int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, ui
 
 extern "C" int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
                                     uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
-                                    float* probs_out, int B, int advance, void* stream) {
+                                    float* probs_out, int B, int advance, const uint32_t* allow_table, void* stream) {
     MGX_REQUIRE(logits && pos_dev && next_tok, MGX_ERR_NULL, "mgx_sample_topk_topp: NULL pointer");
     MGX_REQUIRE(B > 0 && V > 0 && V <= 64 * SMP_PER_LANE && ld >= V && temperature > 0.f && top_p > 0.f, MGX_ERR_SHAPE,
                 "mgx_sample_topk_topp: need 0<V<=%d, ld>=V, temperature>0, top_p>0 (V=%d ld=%d)", 64 * SMP_PER_LANE, V, ld);
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, V, ld, 1.f / temperature, top_k,
-                       top_p, seed, pos_dev, next_tok, out_tokens, out_ld, probs_out, B);
+                       top_p, seed, pos_dev, next_tok, out_tokens, out_ld, probs_out, B, allow_table);
     if (advance) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos_dev);
     MGX_CHECK_LAUNCH("mgx_sample_topk_topp");
     return MGX_OK;

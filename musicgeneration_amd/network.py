@@ -10,6 +10,7 @@ from __future__ import annotations
 import math
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from . import config, ops
@@ -197,7 +198,8 @@ class MusicTransformer(torch.nn.Module):
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def generate_cached(self, prior: torch.Tensor, length: int, temperature: float = 1.0, top_k: int = 0,
-                        top_p: float = 1.0, seed: int = 0, use_graph: bool = True, return_probs: bool = False):
+                        top_p: float = 1.0, seed: int = 0, use_graph: bool = True, return_probs: bool = False,
+                        grammar=None):
         """Sample ``length`` events after ``prior`` [B,P] with per-layer K/V caches and absolute positions
         0..P+length-1 (requires P+length <= max_seq; no sliding window).  Every step runs
         embed -> N x (QKV GEMM, cached relative attention, fc, LN, FFN, LN) -> vocabulary GEMM -> fused
@@ -240,6 +242,12 @@ class MusicTransformer(torch.nn.Module):
                 w2=st.w(pre + "FFN_suf.weight"), bb2=Pm[pre + "FFN_suf.bias"].data,
                 g2=Pm[pre + "layernorm2.weight"].data, b2=Pm[pre + "layernorm2.bias"].data))
         wv, bv = st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param")
+        # grammar: [V, ceil(V/32)] bit table "token v may follow token t" (e.g. REMI_EventSeq.next_token_table()); applied
+        # inside the sampling kernel, so the constrained step stays graph-captured
+        allow = None
+        if grammar is not None:
+            allow = torch.as_tensor(np.ascontiguousarray(grammar).view(np.int32) if isinstance(grammar, np.ndarray) else grammar)
+            allow = allow.to(device=dev, dtype=torch.int32).contiguous()
 
         def step(sample_into_out: bool):
             h = ops.decode_embed(tok, Pm["Decoder.embedding.weight"].data, pe, pos, hbuf)
@@ -253,7 +261,7 @@ class MusicTransformer(torch.nn.Module):
                 h = ops.add_ln_fwd(f, o1, ly["g2"], ly["b2"], 1e-6)[0]
             logits = ops.linear_fwd(h, wv, bv, 0)
             ops.sample_topk_topp(logits, V, pos, tok, out_tokens if sample_into_out else None, probs_step, temperature,
-                                 top_k, top_p, seed, advance=True)
+                                 top_k, top_p, seed, advance=True, allow_table=allow)
 
         # prefill: the prior is teacher-forced token by token (it also warms every kernel up before capture)
         for p in range(P):
