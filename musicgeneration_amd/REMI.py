@@ -90,6 +90,48 @@ class REMI_EventSeq:
         return idxs_feat
 
     @staticmethod
+    def write_midi(events, output_path, prompt_path=None):
+        """utils/REMI.py:538-672 without the prompt branch: scan the event list for the patterns
+        (position, note_velocity, note_on, note_duration), (position, chord), (position, tempo_class, tempo_value) and
+        'bar'; place them on a 4/4 grid of DEFAULT_FRACTION positions per bar at DEFAULT_RESOLUTION ticks per beat; write
+        notes, tempo changes and chord markers.  The reference writes through miditoolkit; here the built-in SMF writer
+        produces the same content (smf.write_ticks).  Returns (notes, tempos, chords) in ticks."""
+        if prompt_path is not None:
+            raise NotImplementedError("continuing a prompt MIDI file needs miditoolkit's parser")
+        from . import smf
+        temp_notes, temp_chords, temp_tempos = [], [], []
+        ev = events
+        for i in range(len(ev) - 3):
+            if ev[i].name == 'bar' and i > 0:
+                temp_notes.append('bar'); temp_chords.append('bar'); temp_tempos.append('bar')
+            elif ev[i].name == 'position' and ev[i + 1].name == 'note_velocity' and ev[i + 2].name == 'note_on' and \
+                    ev[i + 3].name == 'note_duration':
+                temp_notes.append([int(ev[i].value), int(DEFAULT_VELOCITY_BINS[int(ev[i + 1].value)]), int(ev[i + 2].value),
+                                   int(DEFAULT_DURATION_BINS[int(ev[i + 3].value)])])
+            elif ev[i].name == 'position' and ev[i + 1].name == 'chord':
+                temp_chords.append([int(ev[i].value), ev[i + 1].value])
+            elif ev[i].name == 'position' and ev[i + 1].name == 'tempo_class' and ev[i + 2].name == 'tempo_value':
+                temp_tempos.append([int(ev[i].value), DEFAULT_tempo_INTERVALS[ev[i + 1].value].start + int(ev[i + 2].value)])
+        ticks_per_bar = DEFAULT_RESOLUTION * 4
+
+        def on_grid(items):
+            out, bar = [], 0
+            for it in items:
+                if it == 'bar':
+                    bar += 1
+                    continue
+                flags = np.linspace(bar * ticks_per_bar, (bar + 1) * ticks_per_bar, DEFAULT_FRACTION, endpoint=False, dtype=int)
+                out.append([int(flags[it[0]])] + list(it[1:]))
+            return out
+
+        notes = [(vel, pitch, st, st + dur) for st, vel, pitch, dur in on_grid(temp_notes)]
+        chords = on_grid(temp_chords)
+        tempos = on_grid(temp_tempos)
+        smf.write_ticks(output_path, notes, DEFAULT_RESOLUTION, [(st, bpm) for st, bpm in tempos],
+                        [(st, text) for st, text in chords], program=0)
+        return notes, tempos, chords
+
+    @staticmethod
     def next_token_table(pad: bool = True):
         """First-order grammar of a REMI stream as ``write_midi`` reads it (utils/REMI.py:549-581): bar -> position;
         position -> note_velocity | chord | tempo_class; note_velocity -> note_on -> note_duration; tempo_class ->

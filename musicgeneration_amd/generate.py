@@ -1,7 +1,7 @@
 """Drop-in for mg/model/MusicTransformer/generate.py:18-123: load a checkpoint, print a 2-sample test
 loss/accuracy, sample ``--max-length`` events from a prior and write them out.
-MIDI-like samples are written as .mid files (pretty_midi if installed, else the built-in SMF writer, smf.py);
-REMI / MuMIDI samples are saved as event-index arrays (.npy): their MIDI writers need miditoolkit."""
+MIDI-like and REMI samples are written as .mid files (pretty_midi if installed, else the built-in SMF writer,
+smf.py; REMI through REMI_EventSeq.write_midi); MuMIDI samples are saved as event-index arrays (.npy)."""
 from __future__ import annotations
 
 import optparse
@@ -74,7 +74,12 @@ def main(argv=None):
         if o.repr == 'midi_like':
             n = utils.event_indeces_to_midi_file(seq, name + '.mid')
             print('===> {} ({} notes)'.format(name + '.mid', n))
-        else:       # REMI / MuMIDI writers need miditoolkit (REMI.py:538-674, MuMIDI.py:576-704): keep the event ids
+        elif o.repr == 'remi':
+            from .REMI import REMI_EventSeq
+            ids = [int(v) for v in seq if int(v) < REMI_EventSeq.dim()]            # drop pad ids
+            notes, _, _ = REMI_EventSeq.write_midi(REMI_EventSeq.to_event(ids), name + '.mid')
+            print('===> {} ({} notes)'.format(name + '.mid', len(notes)))
+        else:       # the MuMIDI writer (MuMIDI.py:576-704) needs miditoolkit's multi-track containers: keep the event ids
             np.save(name + '.npy', seq.astype(np.uint16))
             print('===> {} (event indices)'.format(name + '.npy'))
 

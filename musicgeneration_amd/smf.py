@@ -65,6 +65,46 @@ def write_notes(path: str, notes: Sequence[NoteTuple], program: int = 1, resolut
         f.write(_chunk(b"MTrk", bytes(body)))
 
 
+def write_ticks(path: str, notes: Sequence[Tuple[int, int, int, int]], resolution: int = 480,
+                tempo_changes: Sequence[Tuple[int, float]] = (), markers: Sequence[Tuple[int, str]] = (),
+                program: int = 0, is_drum: bool = False) -> None:
+    """Tick-level writer (what miditoolkit's ``MidiFile.dump`` produces for REMI.write_midi, utils/REMI.py:651-670):
+    ``notes`` = (velocity, pitch, start_tick, end_tick); ``tempo_changes`` = (tick, bpm); ``markers`` = (tick, text) --
+    chord symbols go there.  Conductor track: tempo map, 4/4, markers; one instrument track."""
+    cond: List[Tuple[int, int, bytes]] = [(0, 0, b"\xFF\x58\x04\x04\x02\x18\x08")]
+    tc = sorted((int(t), float(b)) for t, b in tempo_changes) or [(0, 120.0)]
+    if tc[0][0] != 0:
+        tc.insert(0, (0, 120.0))
+    for t, bpm in tc:
+        cond.append((t, 1, b"\xFF\x51\x03" + struct.pack(">I", int(round(6e7 / max(bpm, 1e-3))))[1:]))
+    for t, text in markers:
+        tb = str(text).encode("ascii", "replace")
+        cond.append((int(t), 2, b"\xFF\x06" + _vlq(len(tb)) + tb))
+    cond.sort(key=lambda e: (e[0], e[1]))
+    cbody, last = bytearray(), 0
+    for tick, _, msg in cond:
+        cbody += _vlq(tick - last) + msg
+        last = tick
+    cbody += b"\x00\xFF\x2F\x00"
+    chan = 9 if is_drum else 0
+    ev: List[Tuple[int, int, bytes]] = []
+    for vel, pitch, t0, t1 in notes:
+        vel, pitch = max(1, min(127, int(vel))), max(0, min(127, int(pitch)))
+        t0, t1 = int(t0), max(int(t1), int(t0))
+        ev.append((t0, 1, bytes([0x90 | chan, pitch, vel])))
+        ev.append((t1, 0, bytes([0x90 | chan, pitch, 0])))
+    ev.sort(key=lambda e: (e[0], e[1]))
+    body, last = bytearray(b"\x00" + bytes([0xC0 | chan, int(program) & 0x7F])), 0
+    for tick, _, msg in ev:
+        body += _vlq(tick - last) + msg
+        last = tick
+    body += b"\x00\xFF\x2F\x00"
+    with open(path, "wb") as f:
+        f.write(_chunk(b"MThd", struct.pack(">HHH", 1, 2, resolution)))
+        f.write(_chunk(b"MTrk", bytes(cbody)))
+        f.write(_chunk(b"MTrk", bytes(body)))
+
+
 def _read_vlq(buf: bytes, i: int) -> Tuple[int, int]:
     n = 0
     while True:
@@ -177,3 +217,61 @@ def read_notes(path: str, programs: Iterable[int] = range(128)) -> List[NoteTupl
                         notes.append((vel, v[1], to_sec(t0), to_sec(tick)))
     notes.sort(key=lambda nt: nt[2])
     return notes
+
+
+def read_ticks(path: str):
+    """-> dict(resolution, notes=[(velocity, pitch, start_tick, end_tick)], tempo_changes=[(tick, bpm)], markers=[(tick, text)])
+    of every non-drum channel (tick-level twin of ``read_notes``; used to round-trip ``write_ticks`` in the tests)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:4] != b"MThd":
+        raise ValueError("not a Standard MIDI File")
+    hlen = struct.unpack(">I", raw[4:8])[0]
+    _, ntrk, division = struct.unpack(">HHH", raw[8:14])
+    i, notes, tempi, markers = 8 + hlen, [], [], []
+    for _ in range(ntrk):
+        tag, ln = raw[i:i + 4], struct.unpack(">I", raw[i + 4:i + 8])[0]
+        buf = raw[i + 8:i + 8 + ln]
+        i += 8 + ln
+        if tag != b"MTrk":
+            continue
+        # markers need the raw meta events: a light second parse
+        j, tick, status, open_notes = 0, 0, 0, {}
+        while j < len(buf):
+            d, j = _read_vlq(buf, j)
+            tick += d
+            b = buf[j]
+            if b == 0xFF:
+                typ = buf[j + 1]
+                n, k = _read_vlq(buf, j + 2)
+                data = buf[k:k + n]
+                j = k + n
+                if typ == 0x51:
+                    tempi.append((tick, 6e7 / int.from_bytes(data, "big")))
+                elif typ == 0x06:
+                    markers.append((tick, data.decode("ascii", "replace")))
+                elif typ == 0x2F:
+                    break
+                continue
+            if b in (0xF0, 0xF7):
+                n, k = _read_vlq(buf, j + 1)
+                j = k + n
+                continue
+            if b & 0x80:
+                status = b
+                j += 1
+            hi, ch = status & 0xF0, status & 0x0F
+            if hi in (0x80, 0x90, 0xA0, 0xB0, 0xE0):
+                p1, p2 = buf[j], buf[j + 1]
+                j += 2
+                if hi == 0x90 and p2 > 0:
+                    open_notes.setdefault((ch, p1), []).append((tick, p2))
+                elif hi in (0x80, 0x90) and open_notes.get((ch, p1)):
+                    t0, vel = open_notes[(ch, p1)].pop(0)
+                    if ch != 9:
+                        notes.append((vel, p1, t0, tick))
+            elif hi in (0xC0, 0xD0):
+                j += 1
+    notes.sort(key=lambda n: (n[2], n[1]))
+    return {"resolution": division, "notes": notes, "tempo_changes": sorted(tempi), "markers": sorted(markers)}
+

@@ -138,3 +138,33 @@ def test_remi_next_token_table_matches_write_midi_patterns():
     assert not ok(first['bar'], first['bar']) and not ok(first['tempo_class'], first['position'])
     assert not any(ok(a, V - 1) for a in range(V))                 # the pad id is never generated
     assert all(t[a].any() for a in range(V))                       # no dead ends
+
+
+def test_remi_write_midi_roundtrip(tmp_path):
+    """F2 for REMI: ids -> events -> write_midi (utils/REMI.py:538-672 patterns, 4/4 grid of 16 positions at 480 tpq) ->
+    SMF -> notes / tempo map / chord markers read back tick-exact."""
+    import numpy as np
+    from musicgeneration_amd import smf
+    from musicgeneration_amd.REMI import (DEFAULT_DURATION_BINS, DEFAULT_VELOCITY_BINS, REMI_EventSeq)
+    fr = REMI_EventSeq.feat_ranges()
+    f = {k: r[0] for k, r in fr.items()}
+    ids = [f['bar'], f['position'], f['tempo_class'] + 1, f['tempo_value'] + 30,            # bar 0: tempo 90+30 = 120
+           f['position'], f['chord'] + 3,
+           f['position'] + 4, f['note_velocity'] + 2, f['note_on'] + 60, f['note_duration'] + 7,
+           f['bar'],                                                                            # bar 1
+           f['position'] + 8, f['note_velocity'] + 1, f['note_on'] + 64, f['note_duration'] + 3,
+           f['position'] + 8, f['note_velocity'] + 3, f['note_on'] + 67, f['note_duration'] + 15,
+           f['bar'], f['position'], f['position'], f['position']]                               # tail (the scan stops 3 short)
+    events = REMI_EventSeq.to_event(np.array(ids, dtype=np.uint16))
+    path = str(tmp_path / "remi.mid")
+    notes, tempos, chords = REMI_EventSeq.write_midi(events, path)
+    tpb = 480 * 4
+    expect = [(int(DEFAULT_VELOCITY_BINS[2]), 60, 4 * tpb // 16, 4 * tpb // 16 + int(DEFAULT_DURATION_BINS[7])),
+              (int(DEFAULT_VELOCITY_BINS[1]), 64, tpb + 8 * tpb // 16, tpb + 8 * tpb // 16 + int(DEFAULT_DURATION_BINS[3])),
+              (int(DEFAULT_VELOCITY_BINS[3]), 67, tpb + 8 * tpb // 16, tpb + 8 * tpb // 16 + int(DEFAULT_DURATION_BINS[15]))]
+    assert notes == expect and tempos == [[0, 120]] and chords[0][0] == 0
+    back = smf.read_ticks(path)
+    assert back["resolution"] == 480
+    assert back["notes"] == sorted(expect, key=lambda n: (n[2], n[1]))
+    assert [t for t, _ in back["tempo_changes"]] == [0] and abs(back["tempo_changes"][0][1] - 120) < 1e-6
+    assert back["markers"] == [(0, chords[0][1])]
