@@ -78,3 +78,19 @@ def test_melody_rnn_train_cli(tmp_path, capsys):
     assert set(sd) >= {"event_embedding.weight", "rnn.weight_ih_l0", "rnn.weight_hh_l1", "output_fc.weight", "inithid_fc.bias"}
     net = Event_Melody_RNN(init_dim=8, event_dim=sd["output_fc.weight"].shape[0], hidden_dim=64, rnn_layers=2, dropout=0.0)
     net.load_state_dict(sd)
+
+
+def test_generate_cli_remi_grammar_writes_midi(tmp_path, capsys):
+    """generate.py --repr remi --grammar: constrained KV-cache decode, every sample decodes to notes in a MIDI file."""
+    from musicgeneration_amd import generate, smf
+    out = str(tmp_path / "g") + "/"
+    generate.main(["-o", out, "-b", "3", "-l", "96", "--num-layers", "1", "--d-model", "128", "-M", "128", "--repr", "remi",
+                   "--grammar", "--top-p", "0.95", "-d", str(tmp_path / "none")])
+    files = sorted(glob.glob(out + "gen-*.mid"))
+    assert len(files) == 3
+    total = 0
+    for f in files:
+        back = smf.read_ticks(f)
+        assert back["resolution"] == 480
+        total += len(back["notes"])
+    assert total > 0          # with the grammar even an untrained model emits complete (position, velocity, pitch, duration) groups
