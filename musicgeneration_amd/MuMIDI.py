@@ -25,6 +25,9 @@ DEFAULT_DRUM_TYPE = range(1, 129)
 DEFAULT_RESOLUTION = 480
 DEFAULT_TRACKS = ['melody', 'piano', 'bass', 'guitar', 'string', 'drum']
 tracks_idx = {track: idx for idx, track in enumerate(DEFAULT_TRACKS)}
+# General-MIDI programs per track (utils/MuMIDI.py:49-55); the writer uses the first of each list
+instrument_numbers = {'melody': [73], 'piano': [1, 2, 3, 4, 5, 6, 7, 8], 'bass': [33, 34, 35, 36, 37, 38, 39, 40],
+                      'guitar': [25, 26, 27, 28, 29, 30, 31, 32], 'drum': [114, 115, 116, 117, 118, 119], 'string': [66]}
 
 chord_quality = ['maj', 'min', 'dim', 'aug', 'dom']
 chord_root = ['C', 'C#', 'D', 'D#', 'E', 'F', 'F#', 'G', 'G#', 'A', 'A#', 'B']
@@ -142,3 +145,64 @@ class MuMIDI_EventSeq:
     @staticmethod
     def from_array(words):
         return MuMIDI_EventSeq.to_event(words)
+
+    @staticmethod
+    def write_midi(events, output_path):
+        """utils/MuMIDI.py:576-704: 'bar' advances the bar, 'position' (1-based) and a track token set the cursor,
+        (note_velocity, note_on, note_duration) triples become notes of the current track (drum pitches live in the upper
+        half of note_on), chords become markers, (tempo_class, tempo_value) tempo changes; 4/4 grid of DEFAULT_FRACTION
+        positions per bar at DEFAULT_RESOLUTION ticks per beat; one instrument per non-empty track.
+        Deviation (documented, SURVEY A14 quirk ii): the reference only recognises track tokens named ``track_<name>``,
+        which its own ``from_array`` never produces (it yields the bare names), so its writer drops every note of a decoded
+        array; here both spellings select the track.  Written with the built-in SMF writer instead of miditoolkit.
+        Returns {track: [(velocity, pitch, start_tick, end_tick)]}, tempos, chords."""
+        from . import smf
+        npitch = len(DEFAULT_PITCH_RANGE)
+        temp_notes, temp_chords, temp_tempos = [], [], []
+        position, track = -1, ''
+        ev = events
+        for i in range(len(ev) - 3):
+            nm = ev[i].name
+            if nm == 'bar' and i > 0:
+                temp_notes.append('bar'); temp_chords.append('bar'); temp_tempos.append('bar')
+                track = ''
+            elif nm == 'position':
+                position = int(ev[i].value) - 1
+            elif nm.startswith('track') or nm in DEFAULT_TRACKS:
+                track = nm.split('_')[-1]
+            elif nm == 'note_velocity' and ev[i + 1].name == 'note_on' and ev[i + 2].name == 'note_duration':
+                velocity = int(DEFAULT_VELOCITY_BINS[int(ev[i].value)])
+                v = int(ev[i + 1].value)
+                if track == 'drum':
+                    v = v + npitch if v < npitch else v
+                    pitch = v + DEFAULT_DRUM_TYPE.start - npitch
+                else:
+                    v = v - npitch if v >= npitch else v
+                    pitch = v + DEFAULT_PITCH_RANGE.start
+                temp_notes.append([position, velocity, pitch, int(DEFAULT_DURATION_BINS[int(ev[i + 2].value)]), track])
+            elif nm == 'chord':
+                temp_chords.append([position, ev[i].value])
+            elif nm == 'tempo_class' and ev[i + 1].name == 'tempo_value':
+                position = int(ev[i].value)                      # as the reference does (MuMIDI.py:620)
+                temp_tempos.append([position, DEFAULT_TEMPO_INTERVALS[ev[i].value].start + int(ev[i + 1].value)])
+        ticks_per_bar = DEFAULT_RESOLUTION * 4
+
+        def on_grid(items):
+            out, bar = [], 0
+            for it in items:
+                if it == 'bar':
+                    bar += 1
+                    continue
+                flags = np.linspace(bar * ticks_per_bar, (bar + 1) * ticks_per_bar, DEFAULT_FRACTION, endpoint=False, dtype=int)
+                out.append([int(flags[it[0]])] + list(it[1:]))
+            return out
+
+        notes = {}
+        for st, vel, pitch, dur, trk in on_grid(temp_notes):
+            notes.setdefault(trk, []).append((vel, pitch, st, st + dur))
+        chords = on_grid(temp_chords)
+        tempos = on_grid(temp_tempos)
+        insts = [(instrument_numbers[t][0], t == 'drum', t, notes[t]) for t in DEFAULT_TRACKS if notes.get(t)]
+        smf.write_ticks_multi(output_path, insts, DEFAULT_RESOLUTION, [(st, bpm) for st, bpm in tempos],
+                              [(st, text) for st, text in chords])
+        return notes, tempos, chords

@@ -1,7 +1,7 @@
 """Drop-in for mg/model/MusicTransformer/generate.py:18-123: load a checkpoint, print a 2-sample test
 loss/accuracy, sample ``--max-length`` events from a prior and write them out.
 MIDI-like and REMI samples are written as .mid files (pretty_midi if installed, else the built-in SMF writer,
-smf.py; REMI through REMI_EventSeq.write_midi); MuMIDI samples are saved as event-index arrays (.npy)."""
+smf.py; REMI / MuMIDI through their write_midi on the same writer)."""
 from __future__ import annotations
 
 import optparse
@@ -79,7 +79,12 @@ def main(argv=None):
             ids = [int(v) for v in seq if int(v) < REMI_EventSeq.dim()]            # drop pad ids
             notes, _, _ = REMI_EventSeq.write_midi(REMI_EventSeq.to_event(ids), name + '.mid')
             print('===> {} ({} notes)'.format(name + '.mid', len(notes)))
-        else:       # the MuMIDI writer (MuMIDI.py:576-704) needs miditoolkit's multi-track containers: keep the event ids
+        elif o.repr == 'mumidi':
+            from .MuMIDI import MuMIDI_EventSeq
+            ids = [int(v) for v in seq if int(v) < MuMIDI_EventSeq.dim()]          # drop pad ids
+            notes, _, _ = MuMIDI_EventSeq.write_midi(MuMIDI_EventSeq.from_array(ids), name + '.mid')
+            print('===> {} ({} notes)'.format(name + '.mid', sum(len(v) for v in notes.values())))
+        else:
             np.save(name + '.npy', seq.astype(np.uint16))
             print('===> {} (event indices)'.format(name + '.npy'))
 

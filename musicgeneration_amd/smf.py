@@ -65,12 +65,12 @@ def write_notes(path: str, notes: Sequence[NoteTuple], program: int = 1, resolut
         f.write(_chunk(b"MTrk", bytes(body)))
 
 
-def write_ticks(path: str, notes: Sequence[Tuple[int, int, int, int]], resolution: int = 480,
-                tempo_changes: Sequence[Tuple[int, float]] = (), markers: Sequence[Tuple[int, str]] = (),
-                program: int = 0, is_drum: bool = False) -> None:
-    """Tick-level writer (what miditoolkit's ``MidiFile.dump`` produces for REMI.write_midi, utils/REMI.py:651-670):
-    ``notes`` = (velocity, pitch, start_tick, end_tick); ``tempo_changes`` = (tick, bpm); ``markers`` = (tick, text) --
-    chord symbols go there.  Conductor track: tempo map, 4/4, markers; one instrument track."""
+def write_ticks_multi(path: str, instruments, resolution: int = 480, tempo_changes: Sequence[Tuple[int, float]] = (),
+                      markers: Sequence[Tuple[int, str]] = ()) -> None:
+    """Tick-level writer (what miditoolkit's ``MidiFile.dump`` produces for REMI / MuMIDI ``write_midi``):
+    ``instruments`` = [(program, is_drum, name, notes)], notes = (velocity, pitch, start_tick, end_tick);
+    ``tempo_changes`` = (tick, bpm); ``markers`` = (tick, text) -- chord symbols go there.  Conductor track: tempo
+    map, 4/4, markers; one track and one channel per instrument (drums on channel 9)."""
     cond: List[Tuple[int, int, bytes]] = [(0, 0, b"\xFF\x58\x04\x04\x02\x18\x08")]
     tc = sorted((int(t), float(b)) for t, b in tempo_changes) or [(0, 120.0)]
     if tc[0][0] != 0:
@@ -86,23 +86,43 @@ def write_ticks(path: str, notes: Sequence[Tuple[int, int, int, int]], resolutio
         cbody += _vlq(tick - last) + msg
         last = tick
     cbody += b"\x00\xFF\x2F\x00"
-    chan = 9 if is_drum else 0
-    ev: List[Tuple[int, int, bytes]] = []
-    for vel, pitch, t0, t1 in notes:
-        vel, pitch = max(1, min(127, int(vel))), max(0, min(127, int(pitch)))
-        t0, t1 = int(t0), max(int(t1), int(t0))
-        ev.append((t0, 1, bytes([0x90 | chan, pitch, vel])))
-        ev.append((t1, 0, bytes([0x90 | chan, pitch, 0])))
-    ev.sort(key=lambda e: (e[0], e[1]))
-    body, last = bytearray(b"\x00" + bytes([0xC0 | chan, int(program) & 0x7F])), 0
-    for tick, _, msg in ev:
-        body += _vlq(tick - last) + msg
-        last = tick
-    body += b"\x00\xFF\x2F\x00"
+    tracks, next_chan = [], 0
+    for program, is_drum, name, notes in instruments:
+        if is_drum:
+            chan = 9
+        else:
+            chan = next_chan
+            next_chan += 2 if next_chan == 8 else 1          # skip the percussion channel
+            if chan > 15:
+                raise ValueError("more than 15 melodic instruments")
+        ev: List[Tuple[int, int, bytes]] = []
+        for vel, pitch, t0, t1 in notes:
+            vel, pitch = max(1, min(127, int(vel))), max(0, min(127, int(pitch)))
+            t0, t1 = int(t0), max(int(t1), int(t0))
+            ev.append((t0, 1, bytes([0x90 | chan, pitch, vel])))
+            ev.append((t1, 0, bytes([0x90 | chan, pitch, 0])))
+        ev.sort(key=lambda e: (e[0], e[1]))
+        nm = str(name).encode("ascii", "replace")
+        body = bytearray((b"\x00\xFF\x03" + _vlq(len(nm)) + nm) if nm else b"")
+        body += b"\x00" + bytes([0xC0 | chan, int(program) & 0x7F])
+        last = 0
+        for tick, _, msg in ev:
+            body += _vlq(tick - last) + msg
+            last = tick
+        body += b"\x00\xFF\x2F\x00"
+        tracks.append(bytes(body))
     with open(path, "wb") as f:
-        f.write(_chunk(b"MThd", struct.pack(">HHH", 1, 2, resolution)))
+        f.write(_chunk(b"MThd", struct.pack(">HHH", 1, 1 + len(tracks), resolution)))
         f.write(_chunk(b"MTrk", bytes(cbody)))
-        f.write(_chunk(b"MTrk", bytes(body)))
+        for body in tracks:
+            f.write(_chunk(b"MTrk", body))
+
+
+def write_ticks(path: str, notes: Sequence[Tuple[int, int, int, int]], resolution: int = 480,
+                tempo_changes: Sequence[Tuple[int, float]] = (), markers: Sequence[Tuple[int, str]] = (),
+                program: int = 0, is_drum: bool = False) -> None:
+    """single-instrument form of ``write_ticks_multi`` (REMI.write_midi, utils/REMI.py:651-670)"""
+    write_ticks_multi(path, [(program, is_drum, "", notes)], resolution, tempo_changes, markers)
 
 
 def _read_vlq(buf: bytes, i: int) -> Tuple[int, int]:
@@ -229,6 +249,7 @@ def read_ticks(path: str):
     hlen = struct.unpack(">I", raw[4:8])[0]
     _, ntrk, division = struct.unpack(">HHH", raw[8:14])
     i, notes, tempi, markers = 8 + hlen, [], [], []
+    by_channel, programs = {}, {}
     for _ in range(ntrk):
         tag, ln = raw[i:i + 4], struct.unpack(">I", raw[i + 4:i + 8])[0]
         buf = raw[i + 8:i + 8 + ln]
@@ -268,10 +289,16 @@ def read_ticks(path: str):
                     open_notes.setdefault((ch, p1), []).append((tick, p2))
                 elif hi in (0x80, 0x90) and open_notes.get((ch, p1)):
                     t0, vel = open_notes[(ch, p1)].pop(0)
+                    by_channel.setdefault(ch, []).append((vel, p1, t0, tick))
                     if ch != 9:
                         notes.append((vel, p1, t0, tick))
             elif hi in (0xC0, 0xD0):
+                if hi == 0xC0:
+                    programs[ch] = buf[j]
                 j += 1
     notes.sort(key=lambda n: (n[2], n[1]))
-    return {"resolution": division, "notes": notes, "tempo_changes": sorted(tempi), "markers": sorted(markers)}
+    for v in by_channel.values():
+        v.sort(key=lambda n: (n[2], n[1]))
+    return {"resolution": division, "notes": notes, "tempo_changes": sorted(tempi), "markers": sorted(markers),
+            "by_channel": by_channel, "programs": programs}
 

@@ -168,3 +168,35 @@ def test_remi_write_midi_roundtrip(tmp_path):
     assert back["notes"] == sorted(expect, key=lambda n: (n[2], n[1]))
     assert [t for t, _ in back["tempo_changes"]] == [0] and abs(back["tempo_changes"][0][1] - 120) < 1e-6
     assert back["markers"] == [(0, chords[0][1])]
+
+
+def test_mumidi_write_midi_multitrack(tmp_path):
+    """F2 for MuMIDI: ids -> from_array -> write_midi (utils/MuMIDI.py:576-704) -> multi-track SMF: one channel per
+    non-empty track with the reference's GM program, drums on channel 9, chord marker, tempo change, tick-exact notes.
+    (The bare track names from_array yields select the track here -- the reference's writer only knows 'track_<name>'.)"""
+    import numpy as np
+    from musicgeneration_amd import smf
+    from musicgeneration_amd.MuMIDI import (DEFAULT_DURATION_BINS, DEFAULT_VELOCITY_BINS, MuMIDI_EventSeq, instrument_numbers)
+    f = {k: r[0] for k, r in MuMIDI_EventSeq.feat_ranges().items()}
+    ids = [f['bar'],
+           f['tempo_class'] + 1, f['tempo_value'] + 10,                                          # 90 + 10 = 100 bpm
+           f['position'] + 1, f['chord'] + 2,
+           f['track'] + 0, f['note_velocity'] + 19, f['note_on'] + 59, f['note_duration'] + 3,   # melody, pitch 60
+           f['track'] + 5, f['note_velocity'] + 24, f['note_on'] + 128 + 35, f['note_duration'] + 0,   # drum 36
+           f['bar'], f['position'] + 17,
+           f['track'] + 2, f['note_velocity'] + 9, f['note_on'] + 39, f['note_duration'] + 7,    # bass, pitch 40
+           f['bar'], f['position'] + 1, f['position'] + 1, f['position'] + 1]
+    events = MuMIDI_EventSeq.from_array(np.array(ids, dtype=np.uint16))
+    path = str(tmp_path / "mumidi.mid")
+    notes, tempos, chords = MuMIDI_EventSeq.write_midi(events, path)
+    tpb = 480 * 4
+    assert notes['melody'] == [(int(DEFAULT_VELOCITY_BINS[19]), 60, 0, int(DEFAULT_DURATION_BINS[3]))]
+    assert notes['drum'] == [(int(DEFAULT_VELOCITY_BINS[24]), 36, 0, int(DEFAULT_DURATION_BINS[0]))]
+    assert notes['bass'] == [(int(DEFAULT_VELOCITY_BINS[9]), 40, tpb + 16 * tpb // 32, tpb + 16 * tpb // 32 + int(DEFAULT_DURATION_BINS[7]))]
+    back = smf.read_ticks(path)
+    assert back["resolution"] == 480 and len(back["by_channel"]) == 3
+    assert back["by_channel"][9] == notes['drum']
+    assert back["by_channel"][0] == notes['melody'] and back["programs"][0] == instrument_numbers['melody'][0]
+    assert back["by_channel"][1] == notes['bass'] and back["programs"][1] == instrument_numbers['bass'][0]
+    assert back["markers"] == [(0, chords[0][1])]
+    assert any(abs(b - 100) < 1e-6 for _, b in back["tempo_changes"])
