@@ -147,6 +147,33 @@ class MuMIDI_EventSeq:
         return MuMIDI_EventSeq.to_event(words)
 
     @staticmethod
+    def next_token_table(pad: bool = True):
+        """First-order grammar of a MuMIDI stream as ``write_midi`` reads it (utils/MuMIDI.py:584-622): bar -> position |
+        tempo_class; tempo_class -> tempo_value -> position | bar; position -> track | chord; chord -> track | position |
+        bar; track -> note_velocity -> note_on -> note_duration -> note_velocity (next note of the track) | track |
+        position | bar.  'empty' and the pad id are never generated.  np.uint32 [V, ceil(V/32)] as
+        ``REMI_EventSeq.next_token_table``."""
+        fr = MuMIDI_EventSeq.feat_ranges()
+        V = MuMIDI_EventSeq.dim() + (1 if pad else 0)
+        follow = {'empty': ['bar'], 'bar': ['position', 'tempo_class'], 'tempo_class': ['tempo_value'],
+                  'tempo_value': ['position', 'bar'], 'position': ['track', 'chord'], 'chord': ['track', 'position', 'bar'],
+                  'track': ['note_velocity'], 'note_velocity': ['note_on'], 'note_on': ['note_duration'],
+                  'note_duration': ['note_velocity', 'track', 'position', 'bar']}
+        table = np.zeros((V, (V + 31) // 32), dtype=np.uint32)
+
+        def allow(row, names):
+            for nm in names:
+                for v in fr[nm]:
+                    table[row, v >> 5] |= np.uint32(1 << (v & 31))
+
+        for nm, rng in fr.items():
+            for t in rng:
+                allow(t, follow[nm])
+        if pad:
+            allow(V - 1, [k for k in fr if k != 'empty'])
+        return table
+
+    @staticmethod
     def write_midi(events, output_path):
         """utils/MuMIDI.py:576-704: 'bar' advances the bar, 'position' (1-based) and a track token set the cursor,
         (note_velocity, note_on, note_duration) triples become notes of the current track (drum pitches live in the upper

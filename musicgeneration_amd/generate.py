@@ -32,7 +32,7 @@ def get_options(argv=None):
     parser.add_option('--d-model', dest='d_model', type='int', default=config.embedding_dim)
     parser.add_option('--repr', dest='repr', type='string', default='midi_like')
     parser.add_option('--grammar', dest='grammar', action='store_true', default=False,
-                      help='constrain sampling to the REMI event grammar (KV-cache decode, mask inside the sampler)')
+                      help='constrain sampling to the REMI / MuMIDI event grammar (KV-cache decode, mask inside the sampler)')
     parser.add_option('-M', '--max_seq', dest='max_seq', type='int', default=config.max_seq)
     return parser.parse_args(argv)[0]
 
@@ -59,13 +59,16 @@ def main(argv=None):
     mt.test()
     prior = torch.tensor([[24, 28, 31]] * o.batch_size, dtype=torch.long, device=device)
     if o.grammar:
-        if o.repr != 'remi':
-            raise SystemExit('--grammar is defined for --repr remi')
-        from .REMI import REMI_EventSeq
-        bar = REMI_EventSeq.feat_ranges()['bar'][0]
+        if o.repr == 'remi':
+            from .REMI import REMI_EventSeq as Codec
+        elif o.repr == 'mumidi':
+            from .MuMIDI import MuMIDI_EventSeq as Codec
+        else:
+            raise SystemExit('--grammar is defined for --repr remi and --repr mumidi')
+        bar = Codec.feat_ranges()['bar'][0]
         prior = torch.full((o.batch_size, 1), bar, dtype=torch.long, device=device)
         res = mt.generate_cached(prior, o.max_len, temperature=o.temperature, top_k=o.top_k, top_p=o.top_p,
-                                 grammar=REMI_EventSeq.next_token_table()).cpu().numpy()
+                                 grammar=Codec.next_token_table()).cpu().numpy()
     else:
         res = mt.generate(prior, o.max_len, temperature=o.temperature, top_k=o.top_k, top_p=o.top_p).cpu().numpy()
     os.makedirs(o.output_dir, exist_ok=True)

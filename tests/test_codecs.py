@@ -200,3 +200,21 @@ def test_mumidi_write_midi_multitrack(tmp_path):
     assert back["by_channel"][1] == notes['bass'] and back["programs"][1] == instrument_numbers['bass'][0]
     assert back["markers"] == [(0, chords[0][1])]
     assert any(abs(b - 100) < 1e-6 for _, b in back["tempo_changes"])
+
+
+def test_mumidi_next_token_table():
+    import numpy as np
+    from musicgeneration_amd.MuMIDI import MuMIDI_EventSeq
+    fr = MuMIDI_EventSeq.feat_ranges()
+    t = MuMIDI_EventSeq.next_token_table()
+    V = MuMIDI_EventSeq.dim() + 1
+    ok = lambda a, b: bool((t[a, b >> 5] >> np.uint32(b & 31)) & np.uint32(1))
+    f = {k: r[0] for k, r in fr.items()}
+    stream = [f['bar'], f['tempo_class'], f['tempo_value'], f['position'] + 1, f['chord'], f['track'], f['note_velocity'],
+              f['note_on'] + 60, f['note_duration'], f['note_velocity'] + 3, f['note_on'] + 64, f['note_duration'] + 1,
+              f['track'] + 5, f['note_velocity'], f['note_on'] + 128 + 36, f['note_duration'], f['position'] + 9, f['track'] + 2,
+              f['note_velocity'], f['note_on'] + 40, f['note_duration'], f['bar']]
+    assert all(ok(a, b) for a, b in zip(stream, stream[1:]))
+    assert not ok(f['position'], f['note_velocity']) and not ok(f['track'], f['note_on']) and not ok(f['bar'], f['bar'])
+    assert not any(ok(a, V - 1) or ok(a, f['empty']) for a in range(V))
+    assert all(t[a].any() for a in range(V))
