@@ -284,3 +284,47 @@ class Event_Melody_RNN(nn.Module):
         if plain:
             return out_tokens[:, 1:].t().contiguous().long()
         return torch.cat(outputs, 0)
+
+    @torch.no_grad()
+    def beam_search(self, init, steps, beam_size, temperature=1.0, stochastic=False, verbose=False, seed=0):
+        """network.py:168-268, repaired.  The reference's version cannot run (it gathers the hidden state with a
+        hard-coded ``repeat(4, 1, 1, 1024)``) and scores beams with raw logits; this one keeps its interface and
+        its structure -- every step advances batch*beam rows through the GRU step kernels, expands each beam by all events
+        and keeps the ``beam_size`` best -- but scores with log-softmax(logits / temperature), starts from ONE live beam (the
+        others at -inf, so duplicates of the first expansion cannot fill the beam) and re-orders the hidden state by the
+        surviving parents.  ``stochastic=True`` selects survivors by Gumbel-perturbed scores (the reference's variant, with
+        the true scores carried along).  Returns the best sequence per batch row, int64 [steps, batch]."""
+        assert len(init.shape) == 2 and init.shape[1] == self.init_dim
+        assert self.event_dim >= beam_size > 0 and steps > 0
+        pk = self._pack()
+        dev, V, nl, H = pk["dev"], self.event_dim, self.rnn_layers, self.hidden_dim
+        B, K = init.shape[0], beam_size
+        h32 = self.init_to_hidden(init).detach().float()                          # [layers, B, H]
+        h32 = h32[:, :, None, :].repeat(1, 1, K, 1).reshape(nl, B * K, H).contiguous()
+        hbf = h32.to(BF16).contiguous()
+        xbuf = torch.empty(B * K, pk["Ep"], dtype=BF16, device=dev)
+        tok = torch.full((B * K,), self.primary_event, dtype=torch.int32, device=dev)
+        score = torch.full((B, K), float("-inf"), device=dev)
+        score[:, 0] = 0.0
+        seqs = torch.zeros(B, K, 0, dtype=torch.long, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        rows = torch.arange(B, device=dev)[:, None]
+        for _ in range(steps):
+            logits = self._step(pk, tok, h32, hbf, xbuf)[:, :V].float()          # [B*K, V]
+            logp = torch.log_softmax(logits / temperature, -1).view(B, K, V)
+            cand = (score[:, :, None] + logp).view(B, K * V)                      # all expansions of all live beams
+            if stochastic:
+                u = torch.rand(cand.shape, device=dev, generator=gen).clamp_(1e-20, 1.0)
+                pick = (cand - torch.log(-torch.log(u))).topk(K, -1).indices
+            else:
+                pick = cand.topk(K, -1).indices
+            score = cand.gather(-1, pick)
+            parent, event = pick // V, pick % V                                   # [B, K]
+            seqs = torch.cat([seqs[rows, parent], event[:, :, None]], -1)
+            flat = (rows * K + parent).reshape(-1)
+            h32 = h32[:, flat].contiguous()
+            hbf = hbf[:, flat].contiguous()
+            tok = event.reshape(-1).to(torch.int32).contiguous()
+        best = seqs[torch.arange(B, device=dev), score.argmax(-1)]                # [B, steps]
+        return best.t().contiguous()
+
