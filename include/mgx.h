@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd */
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -132,6 +132,13 @@ int mgx_cast_bf16(const float* p, uint16_t* shadow, size_t n, void* stream);
  * vocabulary projection does); M arbitrary (edge tiles are masked).   */
 int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C,
                    int M, int N, int K, int act, void* stream);
+
+/* decode-size fusion (M <= 32, K <= 1024): Z bf16 [M,K] = LayerNorm(X + RES) (layers.py:154-155,159-160 in eval mode,
+ * eps as given) and C bf16 [M,N] = act(Z W^T + bias) in one launch -- the LayerNorm of a decode step rides in the
+ * projection that consumes it.                                                                         */
+int mgx_linear_ln_fwd(const uint16_t* X, const uint16_t* RES, const float* gamma, const float* beta, float eps,
+                      const uint16_t* W, const float* bias, uint16_t* C, uint16_t* Z, int M, int N, int K, int act,
+                      void* stream);
 
 /* backward of the above (autograd of the same reference lines):
  * dX bf16 [M,K] = dY bf16 [M,N] @ W bf16 [N,K]; if relu_y (bf16 [M,K]) is given, dX is zeroed where

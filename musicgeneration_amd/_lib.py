@@ -41,6 +41,7 @@ SIGNATURES = {
     "mgx_gru_cell_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_dropout_bf16": [_vp, _vp, _sz, _f, _u64, _vp],
     "mgx_scatter_add_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_linear_ln_fwd": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_linear_dw_grouped": [_vp, _i, _i, _vp],
     "mgx_linear_dw": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }

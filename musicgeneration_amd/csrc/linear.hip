@@ -517,6 +517,94 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __re
 }
 
 // =================================================================================================
+// =================================================================================================
+// skinny forward with a LayerNorm prologue (decode path): Z = LN(X + RES) (layers.py:154-155,159-160, eps 1e-6, no
+// dropout in eval) and C = act(Z W^T + b) in ONE launch.  Every workgroup owns 32 output columns and, like the kernel
+// above, reads all M <= 32 rows of its operand anyway, so it normalises them itself (row statistics reduced across
+// its 4 k-slices through LDS); workgroup 0 also writes Z, which the next LayerNorm needs as its residual.  Removes
+// the 12 LayerNorm launches of a decode step (each ~4.6 us at the launch floor).  K <= 1024.
+// =================================================================================================
+constexpr int SKLN_MAXF = 16;                              // 16-column fragments per wave: K/4/16 <= 16
+__global__ __launch_bounds__(256) void linear_skinny_ln_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ RES,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, const uint16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, uint16_t* __restrict__ C,
+                                                               uint16_t* __restrict__ Z, int M, int N, int K, int act) {
+    __shared__ float part[4][32][33];
+    __shared__ float stat[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int kq = K >> 2, nf = kq >> 4;                     // fragments of 16 columns per wave
+    const int nrow = n0 + l31, mrow = l31;
+    const bool nv = nrow < N, mv = mrow < M;
+    const size_t xoff = (size_t)(mv ? mrow : 0) * K + w * kq + hh * 8;
+    float z[SKLN_MAXF][8];
+    float s1 = 0.f, s2 = 0.f;
+    // the weight fragments are requested first: their latency hides under the statistics
+    const uint16_t* wp = W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    u32x4 wf[SKLN_MAXF];
+#pragma unroll
+    for (int f = 0; f < SKLN_MAXF; ++f)
+        if (f < nf) wf[f] = nv ? *(const u32x4*)(wp + 16 * f) : u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int f = 0; f < SKLN_MAXF; ++f) {
+        if (f < nf) {
+            float a[8], r[8];
+            unpack8(mv ? *(const u32x4*)(X + xoff + 16 * f) : u32x4{0, 0, 0, 0}, a);
+            unpack8(mv ? *(const u32x4*)(RES + xoff + 16 * f) : u32x4{0, 0, 0, 0}, r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                z[f][k] = a[k] + r[k];
+                s1 += z[f][k];
+                s2 += z[f][k] * z[f][k];
+            }
+        }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (hh == 0) { stat[0][w][l31] = s1; stat[1][w][l31] = s2; }
+    __syncthreads();
+    const float t1 = stat[0][0][l31] + stat[0][1][l31] + stat[0][2][l31] + stat[0][3][l31];
+    const float t2 = stat[1][0][l31] + stat[1][1][l31] + stat[1][2][l31] + stat[1][3][l31];
+    const float mean = t1 / (float)K;
+    const float rstd = rsqrtf(fmaxf(t2 / (float)K - mean * mean, 0.f) + eps);
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int f = 0; f < SKLN_MAXF; ++f) {
+        if (f < nf) {
+            const int kc = w * kq + hh * 8 + 16 * f;
+            const f32x4 g0 = *(const f32x4*)(gamma + kc), g1 = *(const f32x4*)(gamma + kc + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + kc), b1 = *(const f32x4*)(beta + kc + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = (z[f][k] - mean) * rstd * gg[k] + bb[k];
+            const u32x4 yf = pack8(y);
+            if (blockIdx.x == 0 && mv) *(u32x4*)(Z + xoff + 16 * f) = yf;
+            acc = mfma(__builtin_bit_cast(bf16x8, wf[f]), __builtin_bit_cast(bf16x8, mv ? yf : u32x4{0, 0, 0, 0}), acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[w][crow(r, hh)][l31] = acc[r];      // [n][m]
+    __syncthreads();
+    const int n = tid >> 3, m4 = (tid & 7) * 4;
+    if (n0 + n < N) {
+        const float bv = bias ? bias[n0 + n] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m4 + k;
+            if (m < M) {
+                float v = part[0][n][m] + part[1][n][m] + part[2][n][m] + part[3][n][m] + bv;
+                if (act == 1) v = fmaxf(v, 0.f);
+                C[(size_t)m * N + n0 + n] = f32_to_bf16(v);
+            }
+        }
+    }
+}
+
 static bool g_attr_set = false;
 static void set_attrs() {
     if (g_attr_set) return;
@@ -633,3 +721,17 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, 
     MGX_CHECK_LAUNCH("mgx_linear_dw_grouped");
     return MGX_OK;
 }
+
+extern "C" int mgx_linear_ln_fwd(const uint16_t* X, const uint16_t* RES, const float* gamma, const float* beta, float eps,
+                                 const uint16_t* W, const float* bias, uint16_t* C, uint16_t* Z, int M, int N, int K, int act,
+                                 void* stream) {
+    MGX_REQUIRE(X && RES && gamma && beta && W && C && Z, MGX_ERR_NULL, "mgx_linear_ln_fwd: NULL pointer");
+    MGX_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 64 == 0 && K <= 64 * SKLN_MAXF, MGX_ERR_SHAPE,
+                "mgx_linear_ln_fwd: need 0<M<=32, K%%64==0, K<=%d (got M=%d N=%d K=%d)", 64 * SKLN_MAXF, M, N, K);
+    MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_ln_fwd: act must be 0 (none) or 1 (ReLU)");
+    hipLaunchKernelGGL(linear_skinny_ln_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, X, RES, gamma, beta, eps, W,
+                       bias, C, Z, M, N, K, act);
+    MGX_CHECK_LAUNCH("mgx_linear_ln_fwd");
+    return MGX_OK;
+}
+

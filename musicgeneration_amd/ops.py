@@ -207,6 +207,18 @@ def linear_fwd(a, w, bias, act=0):
     return out
 
 
+def linear_ln_fwd(x, res, gamma, beta, w, bias, act=0, eps=1e-6):
+    """decode-size rows (<= 32): z = LayerNorm(x + res), c = act(z @ w^T + bias) in one launch -> (c, z)"""
+    _need_cuda(x, res, gamma, beta, w, bias)
+    N, K = w.shape
+    Mrows = x.numel() // K
+    c = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
+    z = torch.empty_like(x)
+    check(_lib.load().mgx_linear_ln_fwd(ptr(x), ptr(res), ptr(gamma), ptr(beta), float(eps), ptr(w), ptr(bias), ptr(c), ptr(z),
+                                        Mrows, N, K, int(act), stream_ptr()), "mgx_linear_ln_fwd")
+    return c, z
+
+
 def linear_dx(dy, w, relu_y=None, addend=None):
     """dy bf16 [..,N], w bf16 [N,K] -> dx bf16 [..,K] = dy @ w (zeroed where relu_y <= 0) (+ addend)"""
     _need_cuda(dy, w, relu_y, addend)

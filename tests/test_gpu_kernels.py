@@ -376,3 +376,32 @@ def test_linear_dw_grouped_matches_separate_launches():
             assert _relerr(gb.cpu(), rb.cpu()) < 1e-4
     with pytest.raises(ValueError):
         ops.linear_dw_grouped([probs[0], (probs[1][0][:100], probs[1][1][:100], probs[1][2], None)])
+
+
+@pytest.mark.parametrize("M,N,K,act", [(32, 256, 512, 1), (7, 1536, 512, 0), (1, 384, 768, 0), (32, 96, 1024, 1), (5, 40, 64, 0)])
+def test_linear_ln_fwd(M, N, K, act):
+    """decode fusion: Z = LN(X + RES), C = act(Z W^T + b) vs the two separate kernels and vs fp32 torch"""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    res = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    gamma = (1 + 0.1 * torch.randn(K, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(K, generator=g)).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    c, z = ops.linear_ln_fwd(x, res, gamma, beta, w, bias, act)
+    z_ref = ops.add_ln_fwd(x, res, gamma, beta, 1e-6)[0]
+    c_ref = ops.linear_fwd(z_ref, w, bias, act)
+    torch.cuda.synchronize()
+    zf = torch.nn.functional.layer_norm(x.float() + res.float(), (K,), gamma, beta, 1e-6)
+    assert (z.float() - zf).abs().max().item() <= 2 ** -7 * zf.abs().max().item() + 1e-3
+    assert (z.float() - z_ref.float()).abs().max().item() <= 2 ** -6 * zf.abs().max().item()      # <= 1-2 bf16 ulp apart
+    cf = zf @ w.float().t() + bias
+    if act:
+        cf = torch.relu(cf)
+    assert (c.float() - cf).abs().max().item() <= 2e-2 * cf.abs().max().item() + 2e-2
+    assert (c.float() - c_ref.float()).abs().max().item() <= 2e-2 * cf.abs().max().item() + 2e-2
+    with pytest.raises(ops._lib.MgxError):
+        ops.linear_ln_fwd(torch.zeros(33, K, dtype=torch.bfloat16, device=dev), torch.zeros(33, K, dtype=torch.bfloat16, device=dev),
+                          gamma, beta, w, bias, act)
