@@ -116,11 +116,12 @@ MGX_DEV bf16x8 frag_T_onR(const char* tile, int lane, int s, int ct) {
     return out;
 }
 
-template <bool EXPORT_DS>
+template <bool EXPORT_DS, bool OWN_DELTA>
 __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint16_t* __restrict__ ErT,
     const uint32_t* __restrict__ padbits, const uint16_t* __restrict__ dctx, const float* __restrict__ lse,
-    const float* __restrict__ delta, uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel, int L, int d) {
+    float* __restrict__ delta, uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel,
+    const uint16_t* __restrict__ ctx, int L, int d) {
     using namespace k1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -168,7 +169,24 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         }
         const size_t si = ((size_t)b * heads + hd) * L + i0 + a;
         lse2 = lse[si] * LOG2E;
-        dlt = delta[si];
+        if (OWN_DELTA) {
+            // delta_i = sum_c dO[i][c] O[i][c]: this wave owns the row, so it computes the value itself (no pre-pass
+            // kernel) and publishes it for the dK/dV kernel, which runs after this one on the stream
+            const uint16_t* op = ctx + ((size_t)b * L + i0 + a) * d + hd * 64 + hh * 8;
+            float acc_d = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float o8[8], g8[8];
+                unpack8(*(const u32x4*)(op + ks * 16), o8);
+                unpack8(__builtin_bit_cast(u32x4, dof[ks]), g8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc_d += o8[k] * g8[k];
+            }
+            dlt = acc_d + __shfl_xor(acc_d, 32, 64);
+            if (hh == 0) delta[si] = dlt;
+        } else {
+            dlt = delta[si];
+        }
     }
     __syncthreads();
 
@@ -857,8 +875,10 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
                 mgx_rel_attn_bwd_workspace(B, L, d), ws_bytes);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3s::LDS_BYTES);
@@ -870,20 +890,24 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     float* delta = (float*)workspace;
     uint16_t* ErT = (uint16_t*)((char*)workspace + ws_delta_bytes(B, L, d));
     uint16_t* dsrel = (uint16_t*)((char*)ErT + ws_ert_bytes(L));
+    // delta = rowsum(dO o O): when the dQ kernel runs in this call it computes and publishes delta itself (its waves own
+    // the rows); the stand-alone kernel is only needed when dK/dV or the recompute dE kernel run without it
+    const bool dq_makes_delta = (parts & 1) && (parts & 2);
     if (parts & 1) {
-        const long total = (long)B * L * heads * 8;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
+        if (!dq_makes_delta) {
+            const long total = (long)B * L * heads * 8;
+            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
+        }
         hipLaunchKernelGGL(er_transpose_kernel, dim3((64 * (L / 8) + 255) / 256), dim3(256), 0, s, Er, ErT, L);
     }
     const dim3 gq(B * heads, (L + 127) / 128);
     const bool export_ds = (parts & 8) || !(parts & 16);
     if (parts & 2) {
-        if (export_ds)
-            hipLaunchKernelGGL(rel_attn_dq_kernel<true>, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, padbits, dctx, lse, delta,
-                               dqkv, dsrel, L, d);
-        else
-            hipLaunchKernelGGL(rel_attn_dq_kernel<false>, gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, padbits, dctx, lse, delta,
-                               dqkv, dsrel, L, d);
+#define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, \
+                                                   padbits, dctx, lse, delta, dqkv, dsrel, ctx, L, d)
+        if (export_ds) { if (dq_makes_delta) MGX_DQ_LAUNCH(true, true); else MGX_DQ_LAUNCH(true, false); }
+        else           { if (dq_makes_delta) MGX_DQ_LAUNCH(false, true); else MGX_DQ_LAUNCH(false, false); }
+#undef MGX_DQ_LAUNCH
     }
     if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
     if (parts & 8) {
