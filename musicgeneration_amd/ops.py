@@ -357,44 +357,6 @@ class _EmbedPE(torch.autograd.Function):
         return None, None, None, None, None, None, None
 
 
-class _RelAttn(torch.autograd.Function):
-    """K3+K4 (+K4b): fused relative attention over a fused qkv projection.   layers.py:86-106"""
-
-    @staticmethod
-    def forward(ctx, qkv, E_master, E_shadow, padbits, gE, wsink):
-        out, lse = rel_attn_fwd(qkv, E_shadow, padbits)
-        ctx.save_for_backward(qkv, E_shadow, out, lse)
-        ctx.cfg = (padbits, gE)
-        if wsink is not None:        # eval-mode debug output: materialise this layer's [B,h,L,L] weights
-            wsink.append(rel_attn_weights(qkv, E_shadow, padbits, lse))
-        return out
-
-    @staticmethod
-    def backward(ctx, dctx):
-        qkv, E_shadow, out, lse = ctx.saved_tensors
-        padbits, gE = ctx.cfg
-        dqkv = rel_attn_bwd(qkv, E_shadow, padbits, out, dctx.contiguous(), lse, gE)
-        return dqkv, None, None, None, None, None
-
-
-class _AddLN(torch.autograd.Function):
-    """K6: LayerNorm(dropout(x) + res), eps 1e-6                 layers.py:154-155,159-160"""
-
-    @staticmethod
-    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta, gxbias):
-        out, mean, rstd = add_ln_fwd(x, res, gamma, beta, eps, p_drop, seed)
-        ctx.save_for_backward(x, res, gamma, mean, rstd)
-        ctx.cfg = (p_drop, seed, ggamma, gbeta, gxbias)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, res, gamma, mean, rstd = ctx.saved_tensors
-        p_drop, seed, ggamma, gbeta, gxbias = ctx.cfg
-        dx, dres = add_ln_bwd(dout.contiguous(), x, res, gamma, mean, rstd, ggamma, gbeta, p_drop, seed, gxbias)
-        return dx, dres, None, None, None, None, None, None, None, None
-
-
 class _Linear(torch.autograd.Function):
     """K2/K5/K7/K8: y = act(x @ W^T + b) and its backward, all libmgx MFMA kernels:
     forward NT GEMM with fused bias/ReLU; dx = dy @ W (NN, transposed LDS reads); dW += dy^T @ x and
@@ -501,16 +463,6 @@ class _SmoothCE(torch.autograd.Function):
 
 def embed_pe(tok, table, pe, p_drop=0.0, seed=0, gtable=None, done=None):
     return _EmbedPE.apply(tok, table, pe, float(p_drop), int(seed), gtable, done)
-
-
-def rel_attn(qkv, E_master, E_shadow, padbits, gE, wsink=None):
-    return _RelAttn.apply(qkv, E_master, E_shadow, padbits, gE, wsink)
-
-
-def add_ln(x, res, gamma, beta, eps, p_drop, seed, ggamma, gbeta, gxbias=None):
-    """gxbias: fp32 grad view of the bias of the projection that produced x; its gradient (= column sums of
-    dx) is then produced by the LayerNorm backward, and that projection is called with gb=None."""
-    return _AddLN.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed), ggamma, gbeta, gxbias)
 
 
 def linear(x, w_master, w_shadow, bias, act, gw, gb, done=None, x_is_relu=False):
