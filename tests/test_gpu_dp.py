@@ -26,9 +26,16 @@ def _run(world, out, port):
     return json.load(open(out))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_two_ranks_match_one_process(tmp_path):
     one = _run(1, str(tmp_path / "one.json"), 0)
-    two = _run(2, str(tmp_path / "two.json"), 29577)
+    two = _run(2, str(tmp_path / "two.json"), _free_port())
     assert two["buckets"] >= 3 and two["bytes_reduced"] > 0 and one["bytes_reduced"] == 0
     for a, b in zip(one["losses"], two["losses"]):
         assert abs(a - b) <= 2e-3 * abs(a), (one["losses"], two["losses"])     # bf16 kernels, atomics order
