@@ -75,3 +75,29 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_header_is_plain_c_and_library_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/mgx.h must compile as strict C99 (no C++/torch types) and a C program must link
+    against libmgx.so and get the documented error codes back -- no Python, no GPU needed for argument validation."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    from musicgeneration_amd import _lib
+    _lib.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(
+        '#include "mgx.h"\n#include <stdio.h>\n'
+        'int main(void) {\n'
+        '    mgx_dw_problem p = {0};\n'
+        '    int rc = mgx_linear_dw_grouped(&p, 1, 128, NULL);\n'
+        '    printf("%d %d %s\\n", mgx_abi_version(), rc, mgx_last_error());\n'
+        '    return 0;\n}\n')
+    exe = str(tmp_path / "abi")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                    "-o", exe, "-L", libdir, "-l:libmgx.so", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split(None, 2)
+    assert int(out[0]) >= 7 and int(out[1]) == -2 and "NULL pointer" in out[2]
