@@ -157,11 +157,56 @@ def pmc_traffic(dom, B, L, d):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh ranks as CHILD processes
+    (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent
+    never touches the GPU (no HIP call before or after the spawn) and never exec()s."""
+    import subprocess
+    if not args.one_device:
+        n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} HIP device(s) visible", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank launch failed (rc={r.returncode})", file=sys.stderr)
+        return r.returncode or 3
+    if json.loads(line).get("n_gpus") != args.gpus:
+        print(f"bench.py: ranks reported n_gpus={json.loads(line).get('n_gpus')} for --gpus {args.gpus}", file=sys.stderr)
+        return 4
+    print(line, flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a silent 1-GPU run labelled as N (or the reverse) is worse than no number
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     if args.one_device:
@@ -175,6 +220,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
     from musicgeneration_amd.dp import DataParallel
@@ -187,6 +234,7 @@ def main():
     mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=args.dropout).to(dev)
     mt.train()
     dp = DataParallel(mt)
+    dp.measure_overlap = world > 1
     opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale)
     sch = CustomSchedule(d, optimizer=opt)
     ms = MetricsSet({"accuracy": CategoricalAccuracy(), "loss": SmoothCrossEntropyLoss(0.1, V, V - 1),
@@ -201,7 +249,10 @@ def main():
     def step(i):
         x, y = ring[i % len(ring)]
         m = ms(mt(x), y)
-        m["loss"].backward()
+        loss = m["loss"]
+        if world > 1:
+            loss = loss * dp.loss_weight(ms.last_nonpad)      # the 4-byte non-pad-count all-reduce of the real train loop
+        loss.backward()
         sch.step()
         opt.zero_grad()
         return m
@@ -241,8 +292,12 @@ def main():
         "model_mfma_frac": value * train_flops_per_event(nl, d, L, V) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
     if world > 1:
-        out["dp"] = {"backend": args.backend, "buckets": len(mt.store().buckets),
-                     "allreduce_bytes_per_step": dp.bytes_reduced // max(1, args.warmup + args.steps)}
+        exposed = dp.exposed_ms()
+        out["dp"] = dict(dp.describe(), buckets=len(mt.store().buckets),
+                         allreduce_bytes_per_step=dp.bytes_reduced // max(1, args.warmup + args.steps),
+                         exposed_allreduce_ms_per_step=exposed,
+                         exposed_note="compute-stream stall between the end of backward and the Adam kernel (HIP events "
+                                      "around the bucket waits); the rest of the all-reduce ran under backward")
     if rank == 0 and not args.no_kernel_timing:
         kt = time_kernels(B, L, d, L)
         # credited (algorithmic) and executed product-units per kernel; 1 unit = B*L^2*d FLOPs

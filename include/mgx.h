@@ -34,7 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace */
+#define MGX_ABI_VERSION 8
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -64,13 +65,17 @@ int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, int B, int L, int pad, vo
  * Rows whose every key j<=i is padding (leading pads; never produced by the reference's data
  * path, data.py:96-107) attend uniformly over j<=i (the reference's result there is a rounding
  * artefact of -1e9+x in fp32 and is outside the parity contract).                             */
+/* workspace: caller-provided scratch, 256-byte aligned, >= mgx_rel_attn_fwd_workspace(L) bytes (a copy of E in
+ * the order the MFMA lanes consume it, rebuilt by a pre-pass on every call: 128*L bytes).                    */
+size_t mgx_rel_attn_fwd_workspace(int L);
 int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
-                     uint16_t* ctx, float* lse, int B, int L, int d, int M, void* stream);
+                     uint16_t* ctx, float* lse, void* workspace, size_t ws_bytes,
+                     int B, int L, int d, int M, void* stream);
 /* eval/debug output of the reference (`attention_weights`, layers.py:102,109): weights f32 [B,h,L,L] =
  * softmax rows recomputed from qkv and the lse of mgx_rel_attn_fwd.  The caller zero-fills `weights`
  * first (tiles above the diagonal are not visited); masked entries inside visited tiles are written as 0. */
 int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const float* lse,
-                         float* weights, int B, int L, int d, int M, void* stream);
+                         float* weights, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream);
 /* backward of the above (autograd of layers.py:86-106).  dctx bf16 [B,L,d] -> dqkv bf16 [B,L,3d];
  * dE f32 [M,64] is ACCUMULATED into (caller zeroes it once per optimiser step).
  * workspace: caller-provided scratch, 256-byte aligned, >= mgx_rel_attn_bwd_workspace(B,L,d) bytes

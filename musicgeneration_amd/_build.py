@@ -23,6 +23,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm; set HIPCC=/path/to/hipcc)")
 
 
+def have_hipcc() -> bool:
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -11,6 +11,10 @@ LIB_PATH = os.environ.get("MGX_LIB_PATH") or os.path.join(PKG, "libmgx.so")     
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
+# the ABI the SIGNATURES table below was written for (MGX_ABI_VERSION of include/mgx.h).  A left-over
+# libmgx.so of another ABI still exports the same names: calling it with this table would shift arguments.
+EXPECTED_ABI = 8
+
 # name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
 SIGNATURES = {
     "mgx_abi_version": [],
@@ -18,8 +22,9 @@ SIGNATURES = {
     "mgx_embed_pe_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_pad_bitmap": [_vp, _vp, _i, _i, _i, _vp],
-    "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "mgx_rel_attn_weights": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_fwd_workspace": [_i],                  # returns size_t
+    "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_bwd_workspace": [_i, _i, _i],          # returns size_t
     "mgx_rel_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_bwd_parts": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
@@ -61,14 +66,25 @@ def load() -> C.CDLL:
     # torch must load ITS libamdhip64 first: libmgx.so then binds to the same HIP runtime instance
     # (loading libmgx first would pull in /opt/rocm's copy and leave two runtimes in one process).
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH) or os.environ.get("MGX_REBUILD") == "1":
+    own = os.path.abspath(LIB_PATH) == os.path.join(PKG, "libmgx.so")
+    if own:
         from . import _build
-        _build.build()
+        force = os.environ.get("MGX_REBUILD") == "1"
+        if force or not os.path.exists(LIB_PATH) or (_build.have_hipcc() and _build._stale()):
+            # absent or older than a source / the header: rebuild when a compiler is here (the GPU box has one too)
+            if _build.have_hipcc():
+                _build.build(force=force)
     if not os.path.exists(LIB_PATH):
         raise MgxError(f"{LIB_PATH} is missing: run `python -m musicgeneration_amd._build` (needs hipcc)")
     lib = C.CDLL(LIB_PATH)
     lib.mgx_last_error.restype = C.c_char_p
     lib.mgx_last_error.argtypes = []
+    lib.mgx_abi_version.restype = C.c_int
+    lib.mgx_abi_version.argtypes = []
+    abi = lib.mgx_abi_version()
+    if abi != EXPECTED_ABI:
+        raise MgxError(f"{LIB_PATH} has ABI version {abi}, this package binds ABI {EXPECTED_ABI} (include/mgx.h): "
+                       "stale build -- rebuild with `python -m musicgeneration_amd._build --force`")
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
         fn.restype = C.c_size_t if name.endswith("_workspace") else C.c_int

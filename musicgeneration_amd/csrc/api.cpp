@@ -13,7 +13,7 @@ void mgx_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mgx_last_error(void) { return g_err; }
-extern "C" int mgx_abi_version(void) { return 7; }
+extern "C" int mgx_abi_version(void) { return MGX_ABI_VERSION; }
 extern "C" int mgx_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

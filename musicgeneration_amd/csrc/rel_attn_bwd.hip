@@ -118,7 +118,7 @@ MGX_DEV bf16x8 frag_T_onR(const char* tile, int lane, int s, int ct) {
 
 template <bool EXPORT_DS, bool OWN_DELTA>
 __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint16_t* __restrict__ ErT,
+    const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const u32x4* __restrict__ EfT,
     const uint32_t* __restrict__ padbits, const uint16_t* __restrict__ dctx, const float* __restrict__ lse,
     float* __restrict__ delta, uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel,
     const uint16_t* __restrict__ ctx, int L, int d) {
@@ -141,14 +141,11 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     const int st_offR = imgR_off(srow, sch);
     const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;
     const uint16_t* vg = kg + d;
+    // fragment-ordered copies of Er (er_frag_kernel, rel_attn_common.hpp): 1 KB contiguous per wave load
     // Er row fragment ks of chunk q (row t = lane&31 of the chunk, i.e. delta = 32q + t)
-    auto e_frag = [&](int q, int ks) {
-        return __builtin_bit_cast(bf16x8, *(const u32x4*)(Er + (size_t)(L - 1 - 32 * q - a) * 64 + hh * 8 + ks * 16));
-    };
+    auto e_frag = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, EfA[(size_t)(q * 4 + ks) * 64 + lane]); };
     // ErT fragment: row c = 32*ct + (lane&31), k = t = 16*ks + 8*hh + j of chunk q
-    auto et_frag = [&](int q, int ks, int ct) {
-        return __builtin_bit_cast(bf16x8, *(const u32x4*)(ErT + (size_t)(32 * ct + a) * L + 32 * q + 16 * ks + 8 * hh));
-    };
+    auto et_frag = [&](int q, int ks, int ct) { return __builtin_bit_cast(bf16x8, EfT[(size_t)((q * 2 + ks) * 2 + ct) * 64 + lane]); };
 
     {   // prologue staging
         *(u32x4*)(smem + OFF_KR + st_offR) = *(const u32x4*)kg;
@@ -336,18 +333,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     if (wave_on) store_rows_lds(dqkv + ((size_t)b * L + i0) * ld + hd * 64, ld, dq0, dq1, lane, 0.125f, band);
 }
 
-// ErT[c][delta] = Er[delta][c] = Er_rows[(L-1-delta)*64 + c]      (bf16 [64][L], 8 deltas per thread)
-__global__ __launch_bounds__(256) void er_transpose_kernel(const uint16_t* __restrict__ Er, uint16_t* __restrict__ ErT,
-                                                           int L) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = gid & 63, d8 = gid >> 6;
-    if (d8 * 8 >= L) return;
-    float f[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = bf16_to_f32(Er[(size_t)(L - 1 - (d8 * 8 + k)) * 64 + c]);
-    *(u32x4*)(ErT + (size_t)c * L + d8 * 8) = pack8(f);
-}
-
 // ================================================================================================
 // K2: dK, dV.  workgroup = 128 keys (wave = 32 keys, K/V row fragments in registers), sweeps query
 // tiles i0 = J0, J0+32, ...  orientation: queries on registers, keys on lanes (S, P, dP, dS);
@@ -367,7 +352,7 @@ constexpr int LDS_BYTES = OFF_BAND + WAVES * 8192;         // 66,048 B -> 2 work
 }  // namespace k2
 
 __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ Er, const uint32_t* __restrict__ padbits,
+    const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
     uint16_t* __restrict__ dqkv, int L, int d) {
     using namespace k2;
@@ -390,10 +375,8 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
     const uint16_t* qg = qkv_b + (size_t)(J0 + srow) * ld + hd * 64 + sch * 8;                  // + t*32*ld
     const uint16_t* og = dctx + ((size_t)b * L + J0 + srow) * d + hd * 64 + sch * 8;            // + t*32*d
-    // fragment ks of Er chunk q for this lane
-    auto e_frag = [&](int q, int ks) {
-        return __builtin_bit_cast(bf16x8, *(const u32x4*)(Er + (size_t)(L - 1 - 32 * q - bl) * 64 + hh * 8 + ks * 16));
-    };
+    // fragment ks of Er chunk q for this lane (fragment-ordered copy: 1 KB contiguous per wave load)
+    auto e_frag = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, EfA[(size_t)(q * 4 + ks) * 64 + lane]); };
     auto stat_src = [&](int t) {   // tid < 64: lse (0..31) / delta (32..63) of query tile t
         const int i = J0 + 32 * t + (tid & 31);
         return (tid < 32) ? lse[stat_base + i] * LOG2E : delta[stat_base + i];
@@ -852,11 +835,11 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
 
 static size_t ws_delta_bytes(int B, int L, int d) { return (((size_t)B * (d / 64) * L * 4) + 255) / 256 * 256; }
 
-static size_t ws_ert_bytes(int L) { return (((size_t)64 * L * 2) + 255) / 256 * 256; }
+static size_t ws_ert_bytes(int L) { return 2 * er_frag_bytes(L); }   // EfA | EfT
 
 extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
     if (B <= 0 || L <= 0 || d <= 0) return 0;
-    // delta f32 [B,h,L] | ErT bf16 [64][L] | dS by (query, distance) bf16 [B,h,L,L]
+    // delta f32 [B,h,L] | fragment-ordered Er (EfA, EfT) | dS by (query, distance) bf16 [B,h,L,L]
     return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * L * L * 2;
 }
 
@@ -888,8 +871,9 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     const int heads = d / 64;
     const uint16_t* Er = E + (size_t)(M - L) * 64;
     float* delta = (float*)workspace;
-    uint16_t* ErT = (uint16_t*)((char*)workspace + ws_delta_bytes(B, L, d));
-    uint16_t* dsrel = (uint16_t*)((char*)ErT + ws_ert_bytes(L));
+    u32x4* EfA = (u32x4*)((char*)workspace + ws_delta_bytes(B, L, d));
+    u32x4* EfT = (u32x4*)((char*)EfA + er_frag_bytes(L));
+    uint16_t* dsrel = (uint16_t*)((char*)EfA + ws_ert_bytes(L));
     // delta = rowsum(dO o O): when the dQ kernel runs in this call it computes and publishes delta itself (its waves own
     // the rows); the stand-alone kernel is only needed when dK/dV or the recompute dE kernel run without it
     const bool dq_makes_delta = (parts & 1) && (parts & 2);
@@ -898,18 +882,18 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
             const long total = (long)B * L * heads * 8;
             hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
         }
-        hipLaunchKernelGGL(er_transpose_kernel, dim3((64 * (L / 8) + 255) / 256), dim3(256), 0, s, Er, ErT, L);
+        launch_er_frag(Er, EfA, EfT, L, s);
     }
     const dim3 gq(B * heads, (L + 127) / 128);
     const bool export_ds = (parts & 8) || !(parts & 16);
     if (parts & 2) {
-#define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, Er, ErT, \
+#define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, \
                                                    padbits, dctx, lse, delta, dqkv, dsrel, ctx, L, d)
         if (export_ds) { if (dq_makes_delta) MGX_DQ_LAUNCH(true, true); else MGX_DQ_LAUNCH(true, false); }
         else           { if (dq_makes_delta) MGX_DQ_LAUNCH(false, true); else MGX_DQ_LAUNCH(false, false); }
 #undef MGX_DQ_LAUNCH
     }
-    if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, Er, padbits, dctx, lse, delta, dqkv, L, d);
+    if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, L, d);
     if (parts & 8) {
         long nwg = 0;
         for (int t = 0; t < (L + k3s::DT - 1) / k3s::DT; ++t)

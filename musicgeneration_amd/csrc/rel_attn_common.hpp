@@ -142,4 +142,45 @@ MGX_DEV void store_rows_lds(uint16_t* dst, size_t row_stride, const f32x16& t0, 
     wave_lds_fence();
 }
 
+// ---- fragment-ordered copies of Er ------------------------------------------------------------------------------
+// The MFMA operands built from E are 16 bytes per lane of 32 DIFFERENT rows of E: read from E's natural
+// [delta][64] layout one wave load touches 32 cache lines for 1 KB of data.  A tiny pre-pass (256 KB at L = 2048,
+// once per attention call) rewrites Er[delta] = E[M-1-delta] in the order the lanes consume it, so every wave load
+// is 1 KB contiguous:
+//   EfA[(q*4 + ks)*64 + lane]            (u32x4) = Er[32q + (lane&31)][16ks + 8(lane>>5) + j],        j = 0..7
+//       row fragment ks of chunk q: B operand of Q.Er^T (forward, dQ, dK/dV kernels)
+//   EfT[((q*2 + ks)*2 + ct)*64 + lane]   (u32x4) = Er[32q + 16ks + 8(lane>>5) + j][32ct + (lane&31)], j = 0..7
+//       fragment of the transposed chunk: A operand of dq^T += Er^T . dQE^T (dQ kernel)
+inline size_t er_frag_bytes(int L) { return (((size_t)L * 64 * 2) + 255) / 256 * 256; }
+
+static __global__ __launch_bounds__(256) void er_frag_kernel(const uint16_t* __restrict__ Er, u32x4* __restrict__ EfA,
+                                                             u32x4* __restrict__ EfT, int L) {
+    const int n = (L >> 5) * 4 * 64;                      // u32x4 units per buffer
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n) {
+        const int lane = gid & 63, ks = (gid >> 6) & 3, q = gid >> 8;
+        const int delta = 32 * q + (lane & 31);
+        EfA[gid] = *(const u32x4*)(Er + (size_t)(L - 1 - delta) * 64 + 16 * ks + 8 * (lane >> 5));
+    } else if (gid < 2 * n && EfT) {
+        const int g = gid - n;
+        const int lane = g & 63, ct = (g >> 6) & 1, ks = (g >> 7) & 1, q = g >> 8;
+        const int col = 32 * ct + (lane & 31);
+        uint16_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int delta = 32 * q + 16 * ks + 8 * (lane >> 5) + j;
+            v[j] = Er[(size_t)(L - 1 - delta) * 64 + col];
+        }
+        u32x4 o;
+        o.x = v[0] | ((uint32_t)v[1] << 16); o.y = v[2] | ((uint32_t)v[3] << 16);
+        o.z = v[4] | ((uint32_t)v[5] << 16); o.w = v[6] | ((uint32_t)v[7] << 16);
+        EfT[g] = o;
+    }
+}
+
+static inline void launch_er_frag(const uint16_t* Er, u32x4* EfA, u32x4* EfT, int L, hipStream_t s) {
+    const int n = (L >> 5) * 4 * 64 * (EfT ? 2 : 1);
+    hipLaunchKernelGGL(er_frag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Er, EfA, EfT, L);
+}
+
 }  // namespace relattn

@@ -29,9 +29,17 @@ def _load_array(fname, field=None):
 
 
 class Data:
-    def __init__(self, dir_path, max_length, field: Optional[str] = None, rng: Optional[random.Random] = None):
+    def __init__(self, dir_path, max_length, field: Optional[str] = None, rng: Optional[random.Random] = None,
+                 min_length: Optional[int] = None):
+        """``min_length`` (extra): keep only files with at least this many events.  The reference keeps
+        ``len >= max_length`` (data.py:33-40) although ``slide_seq2seq_batch`` crops ``max_length + 1`` events with
+        ``randrange(0, len - (max_length+1))``: a file of exactly ``max_length`` events raises IndexError at sampling
+        time and one of ``max_length + 1`` raises ValueError (empty range).  Data-parallel training passes
+        ``min_length = max_length + 2`` so that no rank can ever skip a micro-batch on its own (every rank must
+        issue the same collectives)."""
         self.files = list(utils.find_files_by_extensions(dir_path, ['.data']))
         self.field = field
+        self.min_length = min_length
         self._rng = rng if rng is not None else random
         self._cache: Dict[str, np.ndarray] = {}
         n = len(self.files)
@@ -52,10 +60,18 @@ class Data:
         kept = []
         for fname in files:
             arr, n = _load_array(fname, self.field)
-            if arr is not None and max_length <= n:
+            if arr is not None and max(max_length, self.min_length or 0) <= n:
                 self._cache[fname] = arr
                 kept.append(fname)
         return kept
+
+    def check_vocab(self, vocab_size):
+        """Raise if any kept file holds a token id outside [0, vocab_size): the reference's nn.Embedding / one_hot raise
+        on such input (a dataset / --repr mismatch), the HIP kernels would clamp silently.  Host-side, once per dataset."""
+        for fname, arr in self._cache.items():
+            if len(arr) and (int(arr.max()) >= vocab_size or int(arr.min()) < 0):
+                raise ValueError(f"{fname}: token id {int(arr.max())} outside the vocabulary [0, {vocab_size}) "
+                                 f"(dataset written for another event representation?)")
 
     def _get_seq(self, fname, max_length=None):
         """random crop of max_length events (data.py:96-107); IndexError when the file is too short"""

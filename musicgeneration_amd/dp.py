@@ -27,6 +27,8 @@ class DataParallel:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._works: List = []
         self._sync = True
+        self._exposed: List = []          # (event before wait, event after wait) pairs of the compute stream
+        self.measure_overlap = False
         model._dp = self
         if self.world > 1:
             st = model.store()
@@ -62,9 +64,51 @@ class DataParallel:
         raise KeyError(name)
 
     def wait_all(self):
+        """make the compute stream wait for every outstanding bucket (RCCL: a stream dependency, not a host
+        block).  With ``measure_overlap`` the stall of the compute stream is bracketed by two HIP events: the
+        time between them is the part of the all-reduce that backward did NOT hide."""
+        if not self._works:
+            return
+        ev = None
+        if self.measure_overlap and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()
         self._works.clear()
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
+
+    def exposed_ms(self) -> Optional[float]:
+        """mean exposed (un-overlapped) all-reduce time per optimiser step, from the recorded event pairs"""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed.clear()
+        return sum(v) / len(v)
+
+    def loss_weight(self, n_local: torch.Tensor) -> torch.Tensor:
+        """The reference divides the summed loss by the non-pad count of the batch it sees
+        (criterion.py:58-60).  Each rank normalises by its LOCAL count n_r, gradients are summed over ranks and
+        scaled by 1/world in the optimiser; multiplying rank r's loss by  n_r * world / sum_r n_r  makes the
+        result the global-batch mean exactly (one 4-byte all-reduce; == 1 on pad-free data).  Device-side, no
+        host sync."""
+        if self.world == 1:
+            return torch.ones((), dtype=torch.float32, device=n_local.device)
+        tot = n_local.detach().to(torch.float32).clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.pg)
+        return n_local.detach().to(torch.float32) * float(self.world) / tot.clamp_min(1.0)
+
+    def describe(self) -> Dict:
+        out = {"world": self.world, "backend": dist.get_backend(self.pg) if dist.is_initialized() else None}
+        if out["backend"] == "nccl":
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:        # noqa: BLE001 -- informational only
+                out["rccl_version"] = None
+        return out
 
     def all_reduce_scalar_mean(self, t: torch.Tensor) -> torch.Tensor:
         if self.world == 1:

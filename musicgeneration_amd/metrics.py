@@ -62,6 +62,7 @@ class MetricsSet(object):
         losses = [k for k, m in self.metrics.items() if isinstance(m, SmoothCrossEntropyLoss)]
         if len(losses) == 1 and self.metrics[losses[0]].reduction == 'mean':
             loss, stats, argmax = self.metrics[losses[0]].fused(input, target)
+            self.last_nonpad = stats[1]          # device scalar: non-pad targets of this batch (dp.loss_weight)
             out = {}
             for k, m in self.metrics.items():
                 if k == losses[0]:
@@ -73,4 +74,5 @@ class MetricsSet(object):
                 else:
                     out[k] = m(input, target)
             return out
+        self.last_nonpad = None
         return {k: metric(input, target) for k, metric in self.metrics.items()}

@@ -65,8 +65,10 @@ def rel_attn_fwd(qkv, E, padbits, M=None) -> Tuple[torch.Tensor, torch.Tensor]:
     M = E.shape[0] if M is None else M
     ctx = torch.empty(B, L, d, dtype=BF16, device=qkv.device)
     lse = torch.empty(B, d // 64, L, dtype=torch.float32, device=qkv.device)
-    check(_lib.load().mgx_rel_attn_fwd(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(lse), B, L, d, M, stream_ptr()),
-          "mgx_rel_attn_fwd")
+    lib = _lib.load()
+    ws = torch.empty(lib.mgx_rel_attn_fwd_workspace(L), dtype=torch.uint8, device=qkv.device)
+    check(lib.mgx_rel_attn_fwd(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(lse), ptr(ws), ws.numel(), B, L, d, M,
+                               stream_ptr()), "mgx_rel_attn_fwd")
     return ctx, lse
 
 
@@ -76,8 +78,10 @@ def rel_attn_weights(qkv, E, padbits, lse) -> torch.Tensor:
     B, L, d3 = qkv.shape
     d = d3 // 3
     w = torch.zeros(B, d // 64, L, L, dtype=torch.float32, device=qkv.device)
-    check(_lib.load().mgx_rel_attn_weights(ptr(qkv), ptr(E), ptr(padbits), ptr(lse), ptr(w), B, L, d, E.shape[0],
-                                           stream_ptr()), "mgx_rel_attn_weights")
+    lib = _lib.load()
+    ws = torch.empty(lib.mgx_rel_attn_fwd_workspace(L), dtype=torch.uint8, device=qkv.device)
+    check(lib.mgx_rel_attn_weights(ptr(qkv), ptr(E), ptr(padbits), ptr(lse), ptr(w), ptr(ws), ws.numel(), B, L, d,
+                                   E.shape[0], stream_ptr()), "mgx_rel_attn_weights")
     return w
 
 

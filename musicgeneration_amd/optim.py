@@ -36,10 +36,18 @@ class FusedAdam(torch.optim.Optimizer):
                       g["betas"][1], g["eps"], self._t, self.grad_scale)
 
     # ---- torch.optim.Adam-compatible checkpoint format --------------------------------------------
+    # torch (and the reference's ``Adam(mt.parameters())``, train.py:143) number the per-parameter state by
+    # ``model.parameters()`` order (Wq.weight, Wq.bias, Wk.weight, ...), NOT by the flat store's order
+    # (Wq.weight, Wk.weight, Wv.weight, Wq.bias, ...): emit and read that numbering, so a checkpoint written here loads
+    # into ``torch.optim.Adam(mt.parameters())`` and vice versa.  ``param_names`` (extra key) records the order used.
+    def _torch_order(self):
+        return [n for n, _ in self.model.named_parameters()]
+
     def state_dict(self):
         st = self.store
+        names = self._torch_order()
         state = {}
-        for i, n in enumerate(st.names):
+        for i, n in enumerate(names):
             o, k = st.offsets[n]
             shp = st.params[n].shape
             state[i] = {"step": torch.tensor(float(self._t)), "exp_avg": self.m[o:o + k].view(shp).clone(),
@@ -47,20 +55,23 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         group = {"lr": g["lr"], "betas": g["betas"], "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                 "params": list(range(len(st.names)))}
-        return {"state": state, "param_groups": [group], "param_names": list(st.names)}
+                 "decoupled_weight_decay": False, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group], "param_names": names}
 
     def load_state_dict(self, sd):
         st = self.store
         names = sd.get("param_names")
         if names is None:
-            # a torch.optim.Adam checkpoint: parameters are numbered in model.parameters() order
-            names = [n for n, _ in self.model.named_parameters()]
+            names = self._torch_order()        # a torch.optim.Adam checkpoint
+        if len(names) != len(st.names) or set(names) != set(st.names):
+            raise ValueError("optimizer state_dict does not match this model's parameters")
         for i, n in enumerate(names):
-            if i not in sd["state"]:
+            s = sd["state"].get(i)
+            if s is None:
                 continue
             o, k = st.offsets[n]
-            s = sd["state"][i]
+            if s["exp_avg"].numel() != k:
+                raise ValueError(f"optimizer state {i} has {s['exp_avg'].numel()} elements, parameter {n} has {k}")
             self.m[o:o + k].copy_(s["exp_avg"].reshape(-1))
             self.v[o:o + k].copy_(s["exp_avg_sq"].reshape(-1))
             self._t = int(float(s["step"]))

@@ -105,8 +105,12 @@ def main(argv=None):
         'bucket': LogitsBucketting(vocab)})
 
     log(options.data_path)
-    dataset = Data(options.data_path, options.max_seq, field=options.field, rng=random.Random(1234 + rank))
+    # under data parallelism a rank must never skip a micro-batch alone (the others would wait in the all-reduce):
+    # drop the files whose random crop can fail (len < max_seq + 2, see Data.__init__) on every rank alike
+    dataset = Data(options.data_path, options.max_seq, field=options.field, rng=random.Random(1234 + rank),
+                   min_length=options.max_seq + 2 if multi_gpu else None)
     log(dataset)
+    dataset.check_vocab(vocab)        # out-of-vocabulary ids raise here (the kernels do not range-check per step)
 
     log('Loading model')
     mt = MusicTransformer(**model_config)
@@ -164,7 +168,12 @@ def main(argv=None):
                 try:
                     batch_x, batch_y = dataset.slide_seq2seq_batch(options.batch_size, options.max_seq)
                     batch_x, batch_y = to_dev(batch_x), to_dev(batch_y)
-                except IndexError:
+                except (IndexError, ValueError):
+                    # the reference swallows IndexError (train.py:261-262); a file of exactly max_seq+1 events raises
+                    # ValueError from randrange instead.  Single process: skip like the reference.
+                    if dp is not None and dp.world > 1:
+                        raise RuntimeError("a rank failed to draw a batch under data parallelism: the ranks would stop "
+                                           "issuing the same collectives (dataset changed after the min_length filter?)")
                     continue
                 mt.train()
                 last_micro = (b + 1) % options.accum_grad == 0
@@ -173,6 +182,8 @@ def main(argv=None):
                     sample = mt.forward(batch_x)
                     metrics = metric_set(sample, batch_y)
                     loss = metrics['loss'] / options.accum_grad
+                    if dp is not None and dp.world > 1 and metric_set.last_nonpad is not None:
+                        loss = loss * dp.loss_weight(metric_set.last_nonpad)     # exact global-batch mean on padded data
                     loss.backward()
                 if last_micro:
                     scheduler.step()

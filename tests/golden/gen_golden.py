@@ -8,7 +8,14 @@ no reference source text is copied.  Two invocations are needed because the refe
 two different top-level modules called ``utils``:
 
     python tests/golden/gen_golden.py mt      # MusicTransformer model/loss/schedule (G1-G4,G6,G7,G9)
-    python tests/golden/gen_golden.py codec   # codecs + Event_Melody_RNN (G5, G8)
+    python tests/golden/gen_golden.py codec   # codecs + Event_Melody_RNN (G5, G8) + GRU feeders (G10b)
+    python tests/golden/gen_golden.py mt2     # round 2: G9b optimiser run at d=128, G10a Data feeder, G11 d=256 model
+
+``mt2`` loads parameters made by the repo's own seeded initialiser (oracle.ref_cpu.init_params) INTO the reference
+model, so those fixtures store only inputs, outputs and a parameter checksum.  The reference calls
+``torch.load(path)`` with the defaults of the torch it was written for; on torch >= 2.6 the default
+``weights_only=True`` rejects pickled numpy arrays, so the feeder fixtures are generated with
+``torch.load`` defaulting to ``weights_only=False`` (plumbing of this script, not of the reference's arithmetic).
 
 Fixtures are small .npz / .json files in tests/golden/.
 """
@@ -305,6 +312,197 @@ def gen_codec():
     print("codec fixtures written")
 
 
+def _legacy_torch_load():
+    import functools
+    import torch
+    if not getattr(torch.load, "_legacy", False):
+        orig = torch.load
+        f = functools.partial(orig, weights_only=False)
+        f._legacy = True
+        torch.load = f
+
+
+def feeder_corpus():
+    """the synthetic ``.data`` corpus of the feeder fixtures: name -> uint16 array (written with torch.save, like
+    the reference's preprocess_*.py:36-41).  Lengths straddle the filter / crop edge cases."""
+    import numpy as np
+    rng = np.random.RandomState(20)
+    lens = [33, 34, 40, 57, 64, 32, 31, 90, 128, 35, 200, 77, 45, 36, 150]
+    return {"s%02d-%08x.data" % (i, 0xabc0 + i): rng.randint(0, 300, size=n).astype(np.uint16) for i, n in enumerate(lens)}
+
+
+def write_corpus(root):
+    import torch
+    os.makedirs(root, exist_ok=True)
+    for name, arr in feeder_corpus().items():
+        torch.save(arr, os.path.join(root, name))
+
+
+def gen_mt2():
+    import random
+    import tempfile
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(REF, "MusicTransformer"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))       # repo root: oracle.ref_cpu (parameter initialiser)
+    import config  # noqa
+    import criterion  # noqa
+    import network  # noqa
+    import utils  # noqa
+    import data as refdata  # noqa
+    from oracle import ref_cpu as R
+
+    torch.set_num_threads(4)
+
+    def npy(t):
+        return t.detach().cpu().numpy()
+
+    def checksum(sd):
+        return float(sum(v.double().abs().sum().item() for v in sd.values()))
+
+    V = 309
+    pad = V - 1
+    config.pad_token = pad
+    config.vocab_size = V
+    lossf = criterion.SmoothCrossEntropyLoss(config.label_smooth, V, pad)
+
+    # ---- G9b: 3 optimizer steps, accum_grad=2, at the smallest width the HIP kernels support (d=128) -------
+    d, nl, L, B = 128, 2, 32, 2
+    p0 = R.init_params(V, d, nl, L, seed=9)
+    mt3 = network.MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0)
+    mt3.load_state_dict(p0)
+    opt = torch.optim.Adam(mt3.parameters(), lr=0, betas=(0.9, 0.98), eps=1e-9)
+    sch = criterion.CustomSchedule(d, optimizer=opt)
+    g9 = {"shape": np.array([V, d, nl, L, B]), "seed": np.int64(9), "p0_checksum": np.float64(checksum(p0))}
+    gen9 = torch.Generator().manual_seed(99)
+    xs, losses, lrs = [], [], []
+    opt.zero_grad()
+    mt3.train()
+    for it in range(6):
+        xf = torch.randint(0, V - 1, (B, L + 1), generator=gen9)
+        xs.append(npy(xf))
+        lg = mt3(xf[:, :-1].to(torch.int))
+        loss = lossf(lg, xf[:, 1:].to(torch.int)) / 2
+        loss.backward()
+        losses.append(float(loss) * 2)
+        if (it + 1) % 2 == 0:
+            sch.step()
+            lrs.append(sch._rate)
+            opt.zero_grad()
+    g9["xs"] = np.stack(xs)
+    g9["losses"] = np.array(losses, dtype=np.float64)
+    g9["lrs"] = np.array(lrs, dtype=np.float64)
+    # parameter movement is tiny (lr ~ 1e-7): store the DELTA p3 - p0 of a few tensors at full precision and the
+    # per-parameter L2 norm of the delta for all of them
+    sd3 = mt3.state_dict()
+    for k in ("fc.bias", "Decoder.enc_layers.0.rga.E", "Decoder.enc_layers.1.layernorm2.weight",
+              "Decoder.enc_layers.0.FFN_pre.bias"):
+        g9["delta." + k] = npy(sd3[k] - p0[k]).astype(np.float32)
+    g9["delta_norm_names"] = np.array(list(sd3.keys()))
+    g9["delta_norms"] = np.array([float((sd3[k].double() - p0[k].double()).norm()) for k in sd3.keys()])
+    np.savez_compressed(os.path.join(HERE, "g9b_optim_d128.npz"), **g9)
+
+    # ---- G11: cfg1-family model (d=256, h=4), L=64, tamed logits: forward + loss + selected gradients -------
+    d, nl, L, B = 256, 2, 64, 2
+    p1 = R.init_params(V, d, nl, L, seed=11)
+    for k in p1:
+        if k.endswith("embedding.weight") or k.endswith("rga.E"):
+            p1[k] = p1[k] * 0.25
+    mt4 = network.MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0)
+    mt4.load_state_dict(p1)
+    mt4.train()
+    gen11 = torch.Generator().manual_seed(111)
+    x = torch.randint(0, V - 1, (B, L + 1), generator=gen11)
+    x[1, -5:] = pad                                        # trailing pads: masked keys + ignored targets
+    lg = mt4(x[:, :-1].to(torch.int))
+    loss = lossf(lg, x[:, 1:].to(torch.int))
+    loss.backward()
+    g11 = {"shape": np.array([V, d, nl, L, B]), "seed": np.int64(11), "scale": np.float64(0.25),
+           "p_checksum": np.float64(checksum(p1)), "x": npy(x), "logits": npy(lg), "loss": npy(loss)}
+    named = dict(mt4.named_parameters())
+    for k in ("Decoder.enc_layers.0.rga.E", "Decoder.enc_layers.0.rga.Wq.weight", "Decoder.enc_layers.1.FFN_pre.weight",
+              "Decoder.enc_layers.1.rga.fc.bias", "Decoder.enc_layers.0.layernorm1.weight", "fc.bias"):
+        g11["g." + k] = npy(named[k].grad)
+    g11["grad_norm_names"] = np.array(list(named.keys()))
+    g11["grad_norms"] = np.array([float(v.grad.double().norm()) for v in named.values()])
+    np.savez_compressed(os.path.join(HERE, "g11_model_d256.npz"), **g11)
+
+    # ---- G10a: Data feeder (MusicTransformer/data.py) on the synthetic corpus -----------------------------
+    _legacy_torch_load()
+    with tempfile.TemporaryDirectory() as root:
+        write_corpus(root)
+        names = sorted(feeder_corpus())
+        # the split follows directory-walk order (data.py:11-17), which is a property of the file system: pin it
+        utils.find_files_by_extensions = lambda r, exts=None: iter([os.path.join(r, n) for n in names])
+        refdata.utils = utils
+        max_len = 32
+        dd = refdata.Data(root, max_len)
+        g10 = {"max_length": np.int64(max_len), "names": np.array(names)}
+        for mode in ("train", "valid", "test"):
+            g10["files_" + mode] = np.array([os.path.basename(f) for f in dd.file_dict[mode]])
+        # files of exactly max_len+... events: which exception the crop of max_len+1 raises
+        outcomes = []
+        for n in names:
+            try:
+                random.seed(1)
+                dd._get_seq(os.path.join(root, n), max_len + 1)
+                outcomes.append("ok")
+            except Exception as e:          # noqa: BLE001
+                outcomes.append(type(e).__name__)
+        g10["crop_outcome"] = np.array(outcomes)
+        # drawn batches: seed -> (x, y); train-split files with len >= max_len + 2 only (no exception possible)
+        dd.file_dict["train"] = [f for f in dd.file_dict["train"] if len(feeder_corpus()[os.path.basename(f)]) >= max_len + 2]
+        g10["files_train_safe"] = np.array([os.path.basename(f) for f in dd.file_dict["train"]])
+        for seed in (0, 7):
+            random.seed(seed)
+            for k in range(3):
+                bx, by = dd.slide_seq2seq_batch(4, max_len)
+                g10[f"x_{seed}_{k}"] = bx
+                g10[f"y_{seed}_{k}"] = by
+        random.seed(3)
+        a, b2 = dd.seq2seq_batch(2, 16)
+        g10["s2s_x"], g10["s2s_y"] = a, b2
+        np.savez_compressed(os.path.join(HERE, "g10a_data_feeder.npz"), **g10)
+    print("mt2 fixtures written")
+
+
+def gen_feeders_gru():
+    """G10b: Event_Dataset / SegBatchify / SeqBatchify of mg/model/utils/data.py"""
+    import tempfile
+    import numpy as np
+    _legacy_torch_load()
+    sys.path.insert(0, REF)
+    import utils.shared as shared  # noqa
+    import utils.data as udata  # noqa
+    with tempfile.TemporaryDirectory() as root:
+        write_corpus(root)
+        names = sorted(feeder_corpus())
+        udata.utils.find_files_by_extensions = lambda r, exts=None: iter([os.path.join(r, n) for n in names])
+        ds = udata.Event_Dataset(root, limlen=40)
+        g = {"names": np.array(names), "limlen": np.int64(40), "seqlens": np.array(ds.seqlens), "avglen": np.float64(ds.avglen)}
+        idx = ds.batches(4, 16, 8)
+        g["batches"] = np.array([[i, s0, e0] for i, (s0, e0) in idx], dtype=np.int64)
+        pick = [idx[k] for k in (0, 3, 10, len(idx) - 1, 17)]
+        g["pick"] = np.array([[i, s0, e0] for i, (s0, e0) in pick], dtype=np.int64)
+        g["seg"] = ds.SegBatchify(pick)
+        g["count50"] = np.float64(ds.count(50))
+        ragged = [ds.samples[2][:9], ds.samples[0][:14], ds.samples[1][:5], ds.samples[3][:14]]
+        X, Y, lens = udata.SeqBatchify([np.array(r) for r in ragged])
+        g["sb_in_lens"] = np.array([len(r) for r in ragged])
+        g["sb_in"] = np.concatenate([np.array(r) for r in ragged])
+        g["sb_X"], g["sb_Y"], g["sb_lengths"] = X, Y, lens
+        np.savez_compressed(os.path.join(HERE, "g10b_gru_feeders.npz"), **g)
+    print("gru feeder fixtures written")
+
+
 if __name__ == "__main__":
     _stub_modules()
-    {"mt": gen_mt, "codec": gen_codec}[sys.argv[1]]()
+    mode = sys.argv[1]
+    if mode == "codec":
+        gen_codec()
+        gen_feeders_gru()
+    elif mode == "feeders_gru":
+        gen_feeders_gru()
+    else:
+        {"mt": gen_mt, "mt2": gen_mt2}[mode]()

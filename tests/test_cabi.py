@@ -40,7 +40,7 @@ def test_fails_loudly_without_gpu():
     from musicgeneration_amd import _lib, ops
     from musicgeneration_amd.network import MusicTransformer
     lib = _lib.load()
-    assert lib.mgx_abi_version() >= 1
+    assert lib.mgx_abi_version() == _lib.EXPECTED_ABI
     assert lib.mgx_device_count() < 0 and b"hipGetDeviceCount" in lib.mgx_last_error()
     with pytest.raises(_lib.MgxError):
         ops.pad_bitmap(torch.zeros(2, 32, dtype=torch.int32), 5)          # CPU tensor: no fallback
@@ -54,16 +54,20 @@ def test_shape_errors_have_messages():
     from musicgeneration_amd import _lib
     lib = _lib.load()
     one = ctypes.c_void_p(16)
-    rc = lib.mgx_rel_attn_fwd(one, one, None, one, one, 1, 33, 64, 64, None)
+    aligned = ctypes.c_void_p(4096)
+    rc = lib.mgx_rel_attn_fwd(one, one, None, one, one, aligned, 1 << 20, 1, 33, 64, 64, None)
     assert rc == -1 and b"L%32==0" in lib.mgx_last_error()
-    rc = lib.mgx_rel_attn_fwd(None, one, None, one, one, 1, 32, 64, 64, None)
+    rc = lib.mgx_rel_attn_fwd(None, one, None, one, one, aligned, 1 << 20, 1, 32, 64, 64, None)
     assert rc == -2
+    assert lib.mgx_rel_attn_fwd_workspace(2048) == 2048 * 128
+    rc = lib.mgx_rel_attn_fwd(one, one, None, one, one, aligned, 64, 1, 32, 64, 64, None)      # workspace too small
+    assert rc == -1 and b"workspace" in lib.mgx_last_error()
     rc = lib.mgx_linear_fwd(one, one, None, one, 4, 4, 48, 0, None)
     assert rc == -1 and b"K%64==0" in lib.mgx_last_error()
     rc = lib.mgx_add_ln_fwd(one, one, one, one, one, one, one, 4, 4100, 1e-6, 0.0, 0, None)
     assert rc == -1
-    # delta f32 [B,h,L] + transposed E bf16 [64,L] + dS by (query, distance) bf16 [B,h,L,L]
-    assert lib.mgx_rel_attn_bwd_workspace(8, 2048, 512) == 8 * 8 * 2048 * 4 + 64 * 2048 * 2 + 8 * 8 * 2048 * 2048 * 2
+    # delta f32 [B,h,L] + two fragment-ordered bf16 copies of E [L,64] + dS by (query, distance) bf16 [B,h,L,L]
+    assert lib.mgx_rel_attn_bwd_workspace(8, 2048, 512) == 8 * 8 * 2048 * 4 + 2 * 64 * 2048 * 2 + 8 * 8 * 2048 * 2048 * 2
     assert lib.mgx_add_ln_bwd_workspace(100, 512) == 512 * 3 * 512 * 4
     rc = lib.mgx_add_ln_bwd(one, one, one, one, one, one, one, one, one, one, None, one, 16, 8, 512, 0.0, 0, None)
     assert rc == -1 and b"workspace" in lib.mgx_last_error()
@@ -100,4 +104,38 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), str(src),
                     "-o", exe, "-L", libdir, "-l:libmgx.so", "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split(None, 2)
-    assert int(out[0]) >= 7 and int(out[1]) == -2 and "NULL pointer" in out[2]
+    assert int(out[0]) >= 8 and int(out[1]) == -2 and "NULL pointer" in out[2]
+
+
+def test_stale_library_abi_is_rejected(monkeypatch):
+    """a left-over libmgx.so of another ABI exports the same names: load() must refuse it instead of calling it with
+    shifted arguments"""
+    from musicgeneration_amd import _lib
+    _lib.load()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "EXPECTED_ABI", _lib.EXPECTED_ABI + 1)
+    with pytest.raises(_lib.MgxError, match="ABI version"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "EXPECTED_ABI", _lib.EXPECTED_ABI - 1)
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert _lib.load().mgx_abi_version() == _lib.EXPECTED_ABI
+    # the header's constant, the library and the binding agree
+    hdr = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    assert f"#define MGX_ABI_VERSION {_lib.EXPECTED_ABI}" in hdr
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """`bench.py --gpus N` must never print a line for another N: launched with a WORLD_SIZE that differs from --gpus it
+    exits non-zero before touching the GPU; without a launcher and without N devices the self-launch refuses too."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and '"metric"' not in r.stdout and "HIP device" in r.stderr

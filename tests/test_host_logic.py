@@ -122,3 +122,90 @@ def test_event_dataset_and_seqbatchify(tmp_path):
     X, Y, lengths = SeqBatchify([[1, 2, 3], [4, 5, 6, 7, 8], [9]])
     assert lengths.tolist() == [5, 3, 1] and X.shape == (3, 5) and X.dtype == np.int16
     assert Y.tolist() == [5, 6, 7, 8, 2, 3]
+
+
+# ---- G10: the integer feeders against outputs of the reference itself (tests/golden/gen_golden.py mt2 / codec) ----
+def _write_feeder_corpus(root):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(os.path.dirname(__file__), "golden", "gen_golden.py"))
+    gg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gg)            # only defines functions; the reference is NOT imported by this
+    gg.write_corpus(root)
+    return gg.feeder_corpus()
+
+
+def test_g10a_data_feeder_bit_exact(golden_dir, tmp_path, monkeypatch):
+    """Data.file_filter / split / _get_seq / slide_seq2seq_batch / seq2seq_batch reproduce the reference's
+    output for the same `random` seed, bit for bit (data.py:11-17,33-49,51-67,96-107)."""
+    import random
+    from musicgeneration_amd import data as D
+    g = dict(np.load(os.path.join(golden_dir, "g10a_data_feeder.npz")))
+    corpus = _write_feeder_corpus(str(tmp_path))
+    names = [str(n) for n in g["names"]]
+    # the 80/10/10 split follows directory-walk order, a property of the file system: pinned as in the generator
+    monkeypatch.setattr(D.utils, "find_files_by_extensions", lambda r, exts=None: iter([os.path.join(r, n) for n in names]))
+    L = int(g["max_length"])
+    dd = D.Data(str(tmp_path), L)          # module-level `random`, like the reference
+    for mode in ("train", "valid", "test"):
+        assert [os.path.basename(f) for f in dd.file_dict[mode]] == [str(n) for n in g["files_" + mode]], mode
+    outcomes = []
+    for n in names:
+        try:
+            random.seed(1)
+            dd._get_seq(os.path.join(str(tmp_path), n), L + 1)
+            outcomes.append("ok")
+        except Exception as e:      # noqa: BLE001
+            outcomes.append(type(e).__name__)
+    assert outcomes == [str(o) for o in g["crop_outcome"]]          # IndexError / ValueError / ok, file by file
+    # the DP-safe filter keeps exactly the files whose crop cannot fail
+    safe = D.Data(str(tmp_path), L, min_length=L + 2)
+    assert [os.path.basename(f) for f in safe.file_dict["train"]] == [str(n) for n in g["files_train_safe"]]
+    dd.file_dict["train"] = safe.file_dict["train"]
+    for seed in (0, 7):
+        random.seed(seed)
+        for k in range(3):
+            x, y = dd.slide_seq2seq_batch(4, L)
+            assert x.dtype == g[f"x_{seed}_{k}"].dtype == np.int16
+            assert (x == g[f"x_{seed}_{k}"]).all() and (y == g[f"y_{seed}_{k}"]).all(), (seed, k)
+    random.seed(3)
+    a, b = dd.seq2seq_batch(2, 16)
+    assert (a == g["s2s_x"]).all() and (b == g["s2s_y"]).all()
+    # a private random.Random stream seeded alike draws the same batches (what each DP rank uses)
+    dr = D.Data(str(tmp_path), L, rng=random.Random(7), min_length=L + 2)
+    assert (dr.slide_seq2seq_batch(4, L)[0] == g["x_7_0"]).all()
+    assert len(corpus) == len(names)
+
+
+def test_g10b_event_dataset_bit_exact(golden_dir, tmp_path, monkeypatch):
+    """Event_Dataset.batches / SegBatchify / count and SeqBatchify vs the reference (utils/data.py:23-36,49-114)."""
+    from musicgeneration_amd import data as D
+    g = dict(np.load(os.path.join(golden_dir, "g10b_gru_feeders.npz")))
+    _write_feeder_corpus(str(tmp_path))
+    names = [str(n) for n in g["names"]]
+    monkeypatch.setattr(D.utils, "find_files_by_extensions", lambda r, exts=None: iter([os.path.join(r, n) for n in names]))
+    ds = D.Event_Dataset(str(tmp_path), limlen=int(g["limlen"]))
+    assert ds.seqlens == g["seqlens"].tolist() and ds.avglen == float(g["avglen"])
+    idx = ds.batches(4, 16, 8)
+    assert np.array([[i, s, e] for i, (s, e) in idx], dtype=np.int64).tolist() == g["batches"].tolist()
+    pick = [(int(i), (int(s), int(e))) for i, s, e in g["pick"]]
+    seg = ds.SegBatchify(pick)
+    assert seg.dtype == g["seg"].dtype and (seg == g["seg"]).all()
+    assert (ds.Batchify(pick) == g["seg"]).all()
+    assert ds.count(50) == float(g["count50"])
+    ragged, o = [], 0
+    for n in g["sb_in_lens"]:
+        ragged.append(g["sb_in"][o:o + int(n)])
+        o += int(n)
+    X, Y, lengths = D.SeqBatchify(ragged)
+    assert X.dtype == g["sb_X"].dtype and (X == g["sb_X"]).all()
+    assert Y.dtype == g["sb_Y"].dtype and (Y == g["sb_Y"]).all() and (lengths == g["sb_lengths"]).all()
+
+
+def test_data_check_vocab_rejects_out_of_range_ids(tmp_path):
+    from musicgeneration_amd.data import Data
+    torch.save(np.array([1, 2, 400] * 20, dtype=np.uint16), os.path.join(str(tmp_path), "a-0.data"))
+    torch.save(np.array([1, 2, 3] * 20, dtype=np.uint16), os.path.join(str(tmp_path), "b-1.data"))
+    ds = Data(str(tmp_path), 16)
+    ds.check_vocab(401)
+    with pytest.raises(ValueError, match="outside the vocabulary"):
+        ds.check_vocab(309)
