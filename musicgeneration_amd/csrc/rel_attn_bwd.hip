@@ -20,6 +20,7 @@
 // The skew / un-skew between (i,j) tiles and (i,delta) chunks is done through per-wave LDS band
 // buffers (see rel_attn_common.hpp); the only L x L object that ever exists is the bf16 dS workspace
 // (causal half, tile-blocked), written once and read once per layer.
+#include <type_traits>
 #include "rel_attn_common.hpp"
 
 using namespace relattn;
@@ -96,7 +97,9 @@ constexpr int OFF_VR = OFF_KR + 2 * TILE_BYTES;            // 2 x 4K  V image R 
 constexpr int OFF_BAND = OFF_VR + 2 * TILE_BYTES;          // 4 x 8,704 B fp32 rotated band (see common.hpp)
 constexpr int DB_STRIDE = 144;                             // bytes per dband row (64 bf16 + pad)
 constexpr int OFF_DBAND = OFF_BAND + WAVES * BAND_BYTES;   // 4 x 4,608 B bf16 [32][72]: dS by (query, delta&63)
-constexpr int LDS_BYTES = OFF_DBAND + WAVES * 32 * DB_STRIDE;   // 69,632 B -> 2 workgroups per CU
+constexpr int OFF_PAD = OFF_DBAND + WAVES * 32 * DB_STRIDE; // key-padding words of this batch row (first 256)
+constexpr int OFF_FLAG = OFF_PAD + 1024;                   // "this batch row has padded keys" flag
+constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 70,672 B -> 2 workgroups per CU
 }  // namespace k1
 
 // transposed fragment read from an image-R tile (2-way bank conflict, saves a second LDS image):
@@ -123,17 +126,21 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     float* __restrict__ delta, uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel,
     const uint16_t* __restrict__ ctx, int L, int d) {
     using namespace k1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band stores XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;   // x = (b,h) fast, y = heaviness rank slow
     const int qb = gridDim.y - 1 - blockIdx.y;
-    const int I0 = qb * 128, Q0 = I0 >> 5, i0 = I0 + w * 32;
+    const int I0 = qb * 128, Q0 = I0 >> 5;
     const int nchunk = L >> 5;
-    const bool wave_on = i0 < L;
-    const int nsteps = min(Q0 + 4, nchunk);
+    const bool wave_on = I0 + w * 32 < L;
+    // a wave beyond the end of the sequence (L % 128 != 0) shadows the last valid 32-row block: it recomputes that
+    // block's values (its duplicate stores of delta / dS carry identical data) and skips the dq store
+    const int q0 = wave_on ? Q0 + w : nchunk - 1;
+    const int i0 = q0 * 32;
+    const int ntw = min(Q0 + 4, nchunk);                 // key tiles this workgroup visits
     const size_t ld = (size_t)3 * d;
     const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
 
@@ -141,11 +148,16 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     const int st_offR = imgR_off(srow, sch);
     const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;
     const uint16_t* vg = kg + d;
-    // fragment-ordered copies of Er (er_frag_kernel, rel_attn_common.hpp): 1 KB contiguous per wave load
+    const size_t tile_stride = (size_t)32 * ld;
+    // fragment-ordered copies of Er (er_frag_kernel, rel_attn_common.hpp): 1 KB contiguous per wave load.  Every load
+    // of the sweep is unconditional with a clamped index (a load inside a branch makes the compiler drain the whole
+    // VMEM queue where the branch rejoins); data of clamped tiles / chunks is never used.
     // Er row fragment ks of chunk q (row t = lane&31 of the chunk, i.e. delta = 32q + t)
-    auto e_frag = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, EfA[(size_t)(q * 4 + ks) * 64 + lane]); };
+    auto e_frag = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, EfA[(size_t)(max(q, 0) * 4 + ks) * 64 + lane]); };
     // ErT fragment: row c = 32*ct + (lane&31), k = t = 16*ks + 8*hh + j of chunk q
-    auto et_frag = [&](int q, int ks, int ct) { return __builtin_bit_cast(bf16x8, EfT[(size_t)((q * 2 + ks) * 2 + ct) * 64 + lane]); };
+    auto et_frag = [&](int q, int ks, int ct) {
+        return __builtin_bit_cast(bf16x8, EfT[(size_t)((max(q, 0) * 2 + ks) * 2 + ct) * 64 + lane]);
+    };
 
     {   // prologue staging
         *(u32x4*)(smem + OFF_KR + st_offR) = *(const u32x4*)kg;
@@ -153,16 +165,37 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         // zero the dS band (its never-written half must read as 0 on the first step)
         for (int o = tid * 16; o < WAVES * 32 * DB_STRIDE; o += 256 * 16) *(u32x4*)(smem + OFF_DBAND + o) = u32x4{0, 0, 0, 0};
     }
-    bf16x8 qf[4], dof[4], ecur[4];
+    int anypad = 0;
+    if (padbits) {
+        if (tid == 0) *(volatile uint32_t*)(smem + OFF_FLAG) = 0u;
+        __syncthreads();
+        uint32_t acc = 0;
+#pragma unroll 1
+        for (int t = tid; t < ntw; t += 256) {
+            const uint32_t pwv = padbits[(size_t)b * nchunk + t];
+            if (t < 256) *(uint32_t*)(smem + OFF_PAD + 4 * t) = pwv;
+            acc |= pwv;
+        }
+        if (acc) *(volatile uint32_t*)(smem + OFF_FLAG) = 1u;
+        __syncthreads();
+        anypad = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)(smem + OFF_FLAG));
+    }
+    auto padword = [&](int kt) -> uint32_t {             // wave-uniform
+        if (!anypad) return 0u;
+        uint32_t v = *(const uint32_t*)(smem + OFF_PAD + 4 * min(kt, 255));
+        if (kt >= 256) v = padbits[(size_t)b * nchunk + kt];
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    bf16x8 qf[4], dof[4], e[4];
     float lse2 = 0.f, dlt = 0.f;
-    if (wave_on) {
+    {
         const uint16_t* qp = qkv_b + (size_t)(i0 + a) * ld + hd * 64 + hh * 8;
         const uint16_t* dp = dctx + ((size_t)b * L + i0 + a) * d + hd * 64 + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             qf[ks] = __builtin_bit_cast(bf16x8, scale8(*(const u32x4*)(qp + ks * 16), 0.125f));
             dof[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(dp + ks * 16));
-            ecur[ks] = e_frag(Q0 + w, ks);                 // the wave's first "hi" chunk
+            e[ks] = e_frag(q0, ks);                        // the wave's first "hi" chunk
         }
         const size_t si = ((size_t)b * heads + hd) * L + i0 + a;
         lse2 = lse[si] * LOG2E;
@@ -187,14 +220,32 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     }
     __syncthreads();
 
-    char* band = smem + OFF_BAND + w * BAND_BYTES;
+    // band addressing (rotated band, rows placed so that the register index r is the row slot and the lane half hh
+    // selects a 256-byte-aligned region).  wcl[r] = ABSOLUTE LDS address of (wave band + region + column byte offset): every
+    // term but the column is a multiple of 256, so XOR-ing bit 7 of the whole value flips the chunk parity (one VALU per
+    // store); the row slot r*272 is the instruction's immediate offset.
+    const int band_base = OFF_BAND + w * BAND_BYTES;
     char* dband = smem + OFF_DBAND + w * (32 * DB_STRIDE);
-    // band addressing (rotated band, rows placed so that the register index r is the row slot and the
-    // lane half hh selects a 256-byte-aligned region: XOR-ing byte-address bit 7 then flips chunk parity)
-    int wcl[16];
+    uint32_t wcl[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) wcl[r] = hh * BAND_REGION + (((crow(r, hh) - a) & 63) << 2);
-    const int rbase = band_rowoff(a) + 16 * hh;
+    for (int r = 0; r < 16; ++r)
+        wcl[r] = lds_addr_of(smem) + band_base + hh * BAND_REGION + (((crow(r, hh) - a) & 63) << 2);
+    const int rbase = band_base + band_rowoff(a) + 16 * hh;
+    auto band_put = [&](const f32x16& v, int q) {        // chunk q of Q.Er^T -> band
+        const uint32_t tog = (q & 1) << 7;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds_store_f32((wcl[r] ^ tog) + r * BAND_STRIDE, v[r]);
+    };
+    auto band_get = [&](int dq) {                        // Srel^T of the tile with D/32 = dq
+        const char* rb = smem + rbase + ((dq & 1) << 7);
+        f32x16 c;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 v = *(const f32x4*)(rb + 32 * g4);
+            c[4 * g4] = v.x; c[4 * g4 + 1] = v.y; c[4 * g4 + 2] = v.z; c[4 * g4 + 3] = v.w;
+        }
+        return c;
+    };
     // dband (unrotated, [a][delta&63] bf16): write offsets for D/32 even; odd flips column bit 5
     int dwa0[16], dwa1[16];
 #pragma unroll
@@ -202,135 +253,154 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         dwa0[r] = a * DB_STRIDE + (((a - crow(r, hh)) & 63) << 1);
         dwa1[r] = a * DB_STRIDE + (((a - crow(r, hh) + 32) & 63) << 1);
     }
-    if (wave_on) {      // first "hi" chunk -> band
-        const int q = Q0 + w;
+    {      // first "hi" chunk -> band
         f32x16 qe = zero16();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], ecur[ks], qe);
-        const int tog = (q & 1) << 7;
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
+        band_put(qe, q0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) *(float*)(band + r * BAND_STRIDE + (wcl[r] ^ tog)) = qe[r];
-        if (q >= 1) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ecur[ks] = e_frag(q - 1, ks);    // new chunk of step 0
-        }
+        for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(q0 - 1, ks);    // new chunk of step 0
     }
     f32x16 dq0 = zero16(), dq1 = zero16();
     // dS by (query, relative distance) for the dE kernel, tile-blocked: tile (b,h, query block i0/32, chunk q) is 2 KB at
     // ((bh*nchunk + i0/32)*nchunk + q)*1024 elements; inside, the 16-byte unit of (row a, columns 16ks+8hh..+7) sits at
     // ks*512 + a*16 + hh*8 elements -- each wave store instruction below writes 1 KB contiguously.
     uint16_t* dsp = nullptr;
-    if (EXPORT_DS && wave_on) {   // chunks above the diagonal chunk inside this 128-row block read as zeros downstream
+    if (EXPORT_DS) {   // chunks above the diagonal chunk inside this 128-row block read as zeros downstream
         dsp = dsrel + (((size_t)b * heads + hd) * nchunk + (i0 >> 5)) * nchunk * 1024 + a * 16 + hh * 8;
-        for (int q = Q0 + w + 1; q < min(Q0 + 4, nchunk); ++q) {
-            *(u32x4*)(dsp + (size_t)q * 1024) = u32x4{0, 0, 0, 0};
-            *(u32x4*)(dsp + (size_t)q * 1024 + 512) = u32x4{0, 0, 0, 0};
+        if (wave_on) {
+            for (int q = q0 + 1; q < min(Q0 + 4, nchunk); ++q) {
+                *(u32x4*)(dsp + (size_t)q * 1024) = u32x4{0, 0, 0, 0};
+                *(u32x4*)(dsp + (size_t)q * 1024 + 512) = u32x4{0, 0, 0, 0};
+            }
         }
     }
+    const int am = a - 4 * hh;                           // key crow(r,hh) is in the future of query a  <=>  crow(r,0) > am
 
-    for (int s = 0; s < nsteps; ++s) {
-        const int cur = s & 1;
-        u32x4 kreg, vreg;
-        const bool have_next = (s + 1 < nsteps);
-        if (have_next) {
-            kreg = *(const u32x4*)(kg + (size_t)(s + 1) * 32 * ld);
-            vreg = *(const u32x4*)(vg + (size_t)(s + 1) * 32 * ld);
+    // ---- one tile, from S^T (band term already in c) to the exported dS chunk ---------------------------------------
+    // MASKED: apply the diagonal / key-padding masks (general body only)
+    auto tile_tail = [&](f32x16& c, int dq, int cur, uint32_t pw, auto masked_tag, const bf16x8 (&et)[4]) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const char* kt = smem + OFF_KR + cur * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
+        if (MASKED) {
+            if (dq == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (crow(r, 0) > am) ? -INFINITY : c[r];
+            }
+            if (pw) {
+                const uint32_t pwl = pw >> (4 * hh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (pwl & (1u << crow(r, 0))) ? -INFINITY : c[r];
+            }
         }
-        const int dq = Q0 + w - s;
-        if (wave_on && dq >= 0) {
-            // fragments of ErT for chunk dq (used at the end of this step) and Er for chunk dq-2 (next step)
-            bf16x8 et[4], enext[4];
+        // P^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(c[r], LOG2E, -lse2));
+        // dP^T = V dO^T
+        f32x16 dp = zero16();
+        const char* vt = smem + OFF_VR + cur * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(vt, a, hh, ks), dof[ks], dp);
+        // dS^T
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = c[r] * (dp[r] - dlt);
+        // dqs^T += K^T dS^T
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 df = acc_to_frag(c, ss);
+            dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df, dq0);
+            dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df, dq1);
+        }
+        // un-skew dS into the (query, delta) band, then the completed chunk dq feeds dq_rel
+        if (dq & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa1[r]) = f32_to_bf16(c[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa0[r]) = f32_to_bf16(c[r]);
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2);
+            dq0 = mfma(et[2 * ks], gq, dq0);
+            dq1 = mfma(et[2 * ks + 1], gq, dq1);
+        }
+    };
+    auto export_chunk = [&](int dq) {
+        // completed chunk dq of dS[i][delta] -> workspace.  Last in the step: VMEM operations retire in order, so
+        // the wait for the NEXT step's K/V tiles then only covers stores that have had a whole step to drain.
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            __builtin_nontemporal_store(*(const u32x4*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2),
+                                        (u32x4*)(dsp + (size_t)dq * 1024 + 512 * ks));   // streamed: keep K/V/E in L2
+    };
+
+    // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: ONE branch-free body -------------
+    const int nmain = anypad ? 0 : Q0;                    // Q0 <= ntw - 1: a next tile always exists inside this loop
+    size_t koff = (ntw > 1) ? tile_stride : 0;            // element offset of the tile to prefetch
+    int s = 0;
+    for (; s < nmain; ++s) {
+        const int cur = s & 1;
+        const u32x4 kreg = *(const u32x4*)(kg + koff);
+        const u32x4 vreg = *(const u32x4*)(vg + koff);
+        koff += (s + 2 < ntw) ? tile_stride : 0;
+        const int dq = q0 - s;                            // >= 1
+        // fragments of ErT for chunk dq (used at the end of this step)
+        bf16x8 et[4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { et[2 * ks] = et_frag(dq, ks, 0); et[2 * ks + 1] = et_frag(dq, ks, 1); }
+        f32x16 c = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = mfma(qf[ks], e[ks], c);
+        band_put(c, dq - 1);
+        wave_lds_fence();
+        c = band_get(dq);
+        wave_lds_fence();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(dq - 2, ks);      // Er chunk of the next step
+        tile_tail(c, dq, cur, 0u, std::false_type{}, et);
+        *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
+        *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
+        if (EXPORT_DS) export_chunk(dq);
+        __syncthreads();
+    }
+
+    // ---- general body: the diagonal 128 x 128 block (a wave is full / on its diagonal / done), padded keys ------------
+    for (; s < ntw; ++s) {
+        const int cur = s & 1;
+        const u32x4 kreg = *(const u32x4*)(kg + koff);
+        const u32x4 vreg = *(const u32x4*)(vg + koff);
+        koff += (s + 2 < ntw) ? tile_stride : 0;
+        const int dq = q0 - s;
+        if (dq >= 0) {
+            const uint32_t pw = padword(s);
+            bf16x8 et[4];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) { et[2 * ks] = et_frag(dq, ks, 0); et[2 * ks + 1] = et_frag(dq, ks, 1); }
             if (dq >= 1) {
                 f32x16 qe = zero16();
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], ecur[ks], qe);
-                const int tog = ((dq - 1) & 1) << 7;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) *(float*)(band + r * BAND_STRIDE + (wcl[r] ^ tog)) = qe[r];
-            }
-            if (dq >= 2) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) enext[ks] = e_frag(dq - 2, ks);
+                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
+                band_put(qe, dq - 1);
             }
             wave_lds_fence();
-            f32x16 c;
-            {
-                const char* rb = band + rbase + ((dq & 1) << 7);
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const f32x4 v = *(const f32x4*)(rb + 32 * g4);
-                    c[4 * g4] = v.x; c[4 * g4 + 1] = v.y; c[4 * g4 + 2] = v.z; c[4 * g4 + 3] = v.w;
-                }
-            }
-            const char* kt = smem + OFF_KR + cur * TILE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
-            if (dq == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c[r] = (crow(r, hh) > a) ? -INFINITY : c[r];
-            }
-            if (padbits) {
-                const uint32_t pw = padbits[(size_t)b * nchunk + s];
-                if (pw) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) c[r] = ((pw >> crow(r, hh)) & 1u) ? -INFINITY : c[r];
-                }
-            }
-            // P^T
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(c[r], LOG2E, -lse2));
-            // dP^T = V dO^T
-            f32x16 dp = zero16();
-            const char* vt = smem + OFF_VR + cur * TILE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(vt, a, hh, ks), dof[ks], dp);
-            // dS^T
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = c[r] * (dp[r] - dlt);
-            // dqs^T += K^T dS^T
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const bf16x8 df = acc_to_frag(c, ss);
-                dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df, dq0);
-                dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df, dq1);
-            }
-            // un-skew dS into the (query, delta) band, then the completed chunk dq feeds dq_rel
-            if (dq & 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa1[r]) = f32_to_bf16(c[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa0[r]) = f32_to_bf16(c[r]);
-            }
+            f32x16 c = band_get(dq);
             wave_lds_fence();
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2);
-                dq0 = mfma(et[2 * ks], gq, dq0);
-                dq1 = mfma(et[2 * ks + 1], gq, dq1);
-            }
-            if (dq >= 2) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) ecur[ks] = enext[ks];
-            }
+            for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(dq - 2, ks);
+            tile_tail(c, dq, cur, pw, std::true_type{}, et);
         }
-        if (have_next) {
+        if (s + 1 < ntw) {
             *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
             *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
         }
-        if (EXPORT_DS && wave_on && dq >= 0) {
-            // completed chunk dq of dS[i][delta] -> workspace.  Last in the step: VMEM operations retire in order, so
-            // the wait for the NEXT step's K/V tiles then only covers stores that have had a whole step to drain.
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                __builtin_nontemporal_store(*(const u32x4*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2),
-                                            (u32x4*)(dsp + (size_t)dq * 1024 + 512 * ks));   // streamed: keep K/V/E in L2
-        }
+        if (EXPORT_DS && dq >= 0) export_chunk(dq);
         __syncthreads();
     }
-    if (wave_on) store_rows_lds(dqkv + ((size_t)b * L + i0) * ld + hd * 64, ld, dq0, dq1, lane, 0.125f, band);
+    if (wave_on) store_rows_lds(dqkv + ((size_t)b * L + i0) * ld + hd * 64, ld, dq0, dq1, lane, 0.125f, smem + band_base);
 }
 
 // ================================================================================================

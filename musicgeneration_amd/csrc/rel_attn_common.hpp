@@ -23,6 +23,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float PAD_NEG = -1.0e9f;        // additive mask value of the reference (layers.py:100)
 
 typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+typedef __attribute__((address_space(3))) float* lds_f32_ptr;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+// LDS byte address of a __shared__ object as an integer, and a store through such an integer.  Address arithmetic done
+// on the integer (XOR included) stays ONE VALU per store: through a generic pointer the compiler re-adds the (link-time)
+// base of the dynamic LDS segment after every XOR.
+MGX_DEV uint32_t lds_addr_of(const char* p) { return (uint32_t)(uintptr_t)(lds_char_ptr)p; }
+MGX_DEV void lds_store_f32(uint32_t addr, float v) { *(lds_f32_ptr)(uintptr_t)addr = v; }
 
 // row index (within the 32-row tile) held by accumulator register r of a lane in half hh
 MGX_DEV int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }

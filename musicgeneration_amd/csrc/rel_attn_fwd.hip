@@ -2,9 +2,9 @@
 //
 // Work decomposition: workgroup = 4 waves = 128 consecutive query rows of one (batch, head); each wave
 // owns 32 query rows and keeps O^T (64 x 32 fp32), a softmax reference m and the running sum l in
-// registers.  The workgroup sweeps key tiles from j0 = 0 up to its own diagonal, NSUB 32-key tiles per
-// step; K and V tiles are staged once per workgroup in LDS (shared by the 4 waves), the next step's
-// tiles prefetched into registers while the current ones are computed (one barrier per step).
+// registers.  The workgroup sweeps 32-key tiles from j0 = 0 up to its own diagonal; K and V tiles are staged
+// once per workgroup in LDS (shared by the 4 waves), the next tile prefetched into registers while the
+// current one is computed (one barrier per step).
 //
 // Per 32-key tile and wave (all MFMA 32x32x16 bf16, fp32 accumulate):
 //   QE   = Q_tile . Er_chunk^T            4 MFMA   -> LDS band (skew buffer, see rel_attn_common.hpp)
@@ -16,14 +16,19 @@
 //
 // * The Er chunk operands come from a FRAGMENT-ORDERED copy of E (er_frag_kernel, rel_attn_common.hpp):
 //   one wave load instruction reads 1 KB contiguous.  (Read from E's natural [delta][64] layout the same
-//   instruction touched 32 B of 32 different rows; a build without those loads ran 19 % faster.)
+//   instruction touched 32 B of 32 different rows.)
 // * Lazy softmax reference: m is NOT the running maximum.  A tile is exponentiated against the current m
 //   straight away (no max chain, no cross-half shuffle, no rescale of O); only when a lane's partial sum
 //   shows that some exponent left the safe range (first tile; a score that jumps by > 40 nats) the tile
 //   is redone against the true maximum and O, l are rescaled once.  exp2(S - m) with m <= true maximum is
 //   exact to fp32 / bf16 relative precision however far m lags, so the result is the same softmax.
-// * Steps whose tiles are all full (no diagonal, no padded key) run a branch-free body in which the
-//   NSUB tiles' MFMA chains, band traffic and exponentials are independent instruction streams.
+// * Loop structure: a workgroup's key tiles 0 .. Q0-1 lie strictly below the diagonal of ALL its four waves.
+//   That main loop has one body without a single branch (every tile full, every load unconditional), so the
+//   compiler keeps loads in flight across iterations and needs no register copies where paths would rejoin
+//   (a build with one loop and a full/general branch inside spent ~45 v_mov per step on such copies and
+//   waited for the next step's E loads at the end of every step).  The last (up to) four tiles -- the
+//   128 x 128 diagonal block, where a wave is full, on its diagonal, or already done -- and batch rows with
+//   padded keys run a general body.
 //
 // Algorithmic FLOPs per (b,h): 3 products x 2*64 x L(L+1)/2 (causal half) -- DESIGN.md.
 #include "rel_attn_common.hpp"
@@ -32,29 +37,25 @@ using namespace relattn;
 
 namespace {
 constexpr int WAVES = 4;
-template <int NSUB>
-struct FwdCfg {
-    static constexpr int KT = NSUB * TILE_BYTES;                    // one step's K (or V) tiles
-    static constexpr int OFF_K = 0;                                 // 2 x KT  image R
-    static constexpr int OFF_V = 2 * KT;                            // 2 x KT  image T
-    static constexpr int OFF_BAND = 4 * KT;                         // 4 x (32 rows x 272 B) fp32 rotated band
-    static constexpr int OFF_PAD = OFF_BAND + WAVES * BAND_BYTES;   // key-padding words of this batch row (<= 256)
-    static constexpr int LDS_BYTES = OFF_PAD + 1024;
-};
+constexpr int OFF_K = 0;                                        // 2 x 4 KiB   image R
+constexpr int OFF_V = OFF_K + 2 * TILE_BYTES;                   // 2 x 4 KiB   image T
+constexpr int OFF_BAND = OFF_V + 2 * TILE_BYTES;                // 4 x (32 rows x 272 B) fp32 rotated band
+constexpr int OFF_PAD = OFF_BAND + WAVES * BAND_BYTES;          // key-padding words of this batch row (first 256)
+constexpr int OFF_FLAG = OFF_PAD + 1024;                        // "this batch row has padded keys" flag
+constexpr int LDS_BYTES = OFF_FLAG + 16;                        // 52,240 B -> 3 workgroups per CU
 constexpr float M_INIT = -1.0e37f;      // "no reference yet": finite, so exp2(-inf - m) is 0 and not NaN
-constexpr float L_SAFE = 1.0e24f;       // a lane's partial sum of one step above this => redo against the true max
+constexpr float L_SAFE = 1.0e24f;       // a lane's partial sum of one tile above this => redo against the true max
 }  // namespace
 
 // WRITE_W = false: the training/inference forward (ctx + lse).
 // WRITE_W = true : debug/eval output of the reference (layers.py:102,109): the same sweep recomputes S and
 //                  writes weights[b,h,i,j] = exp(S - lse_i) (fp32, caller pre-zeroes the future triangle).
-template <int NSUB, bool WRITE_W>
-__global__ __launch_bounds__(256, NSUB == 1 ? 3 : 2) void rel_attn_fwd_kernel(
+template <bool WRITE_W>
+__global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ Ef /* fragment-ordered Er, see er_frag_kernel */,
     const uint32_t* __restrict__ padbits, uint16_t* __restrict__ ctx, float* __restrict__ lse_out,
     const float* __restrict__ lse_in, float* __restrict__ weights, int L, int d) {
-    using C = FwdCfg<NSUB>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band stores XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -65,11 +66,12 @@ __global__ __launch_bounds__(256, NSUB == 1 ? 3 : 2) void rel_attn_fwd_kernel(
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int qb = gridDim.y - 1 - blockIdx.y;
     const int I0 = qb * 128, Q0 = I0 >> 5;
-    const int i0 = I0 + w * 32;
     const int nchunk = L >> 5;                           // number of 32-row chunks / key tiles
-    const bool wave_on = i0 < L;
+    const bool wave_on = I0 + w * 32 < L;
+    // a wave beyond the end of the sequence (L % 128 != 0) shadows the last valid 32-row block and stores nothing
+    const int q0 = wave_on ? Q0 + w : nchunk - 1;        // the wave's diagonal tile / first "hi" chunk
+    const int i0 = q0 * 32;
     const int ntw = min(Q0 + 4, nchunk);                 // key tiles this workgroup visits
-    const int nsteps = (ntw + NSUB - 1) / NSUB;
     const size_t ld = (size_t)3 * d;                     // qkv row stride (elements)
     const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
 
@@ -78,38 +80,39 @@ __global__ __launch_bounds__(256, NSUB == 1 ? 3 : 2) void rel_attn_fwd_kernel(
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
     const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;       // + 32*tile*ld
     const uint16_t* vg = kg + d;
-    // every load below is unconditional with a clamped index (a load inside a branch makes the compiler drain
-    // the whole VMEM queue where the branch rejoins); data of clamped tiles / chunks is never used
-    auto tile_off = [&](int kt) { return (size_t)min(kt, nchunk - 1) * 32 * ld; };
+    const size_t tile_stride = (size_t)32 * ld;
+    // every load of the sweep is unconditional with a clamped index: a load inside a branch makes the compiler drain
+    // the whole VMEM queue where the branch rejoins.  Data of clamped tiles / chunks is never used.
     auto ef = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, Ef[(size_t)(max(q, 0) * 4 + ks) * 64 + lane]); };
 
-    // ---- prologue: K/V tiles of step 0, key-padding words ------------------------------------------
-#pragma unroll
-    for (int u = 0; u < NSUB; ++u) {
-        *(u32x4*)(smem + C::OFF_K + u * TILE_BYTES + st_offR) = *(const u32x4*)(kg + tile_off(u));
-        *(u32x4*)(smem + C::OFF_V + u * TILE_BYTES + st_offT) = *(const u32x4*)(vg + tile_off(u));
-    }
+    // ---- prologue: K/V tile 0, key-padding words ---------------------------------------------------
+    *(u32x4*)(smem + OFF_K + st_offR) = *(const u32x4*)kg;
+    *(u32x4*)(smem + OFF_V + st_offT) = *(const u32x4*)vg;
+    // (no __syncthreads_or: it allocates static LDS, which moves the dynamic base off 0 and costs one v_add per band store)
     int anypad = 0;
     if (padbits) {
+        if (tid == 0) *(volatile uint32_t*)(smem + OFF_FLAG) = 0u;
+        __syncthreads();
         uint32_t acc = 0;
 #pragma unroll 1
         for (int t = tid; t < ntw; t += 256) {
             const uint32_t pwv = padbits[(size_t)b * nchunk + t];
-            if (t < 256) *(uint32_t*)(smem + C::OFF_PAD + 4 * t) = pwv;
+            if (t < 256) *(uint32_t*)(smem + OFF_PAD + 4 * t) = pwv;
             acc |= pwv;
         }
-        anypad = __syncthreads_or(acc != 0);
+        if (acc) *(volatile uint32_t*)(smem + OFF_FLAG) = 1u;      // every writer stores the same value
+        __syncthreads();
+        anypad = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)(smem + OFF_FLAG));
     }
-    const uint32_t* padrow = padbits + (size_t)b * nchunk;
     auto padword = [&](int kt) -> uint32_t {             // wave-uniform
-        if (!anypad || kt >= ntw) return 0u;
-        const uint32_t v = (kt < 256) ? *(const uint32_t*)(smem + C::OFF_PAD + 4 * kt) : padrow[kt];
+        if (!anypad) return 0u;
+        uint32_t v = *(const uint32_t*)(smem + OFF_PAD + 4 * min(kt, 255));      // unconditional LDS read (no pointer select)
+        if (kt >= 256) v = padbits[(size_t)b * nchunk + kt];                     // L > 8192 only
         return __builtin_amdgcn_readfirstlane(v);
     };
     // Q fragments (A operand of QE, B operand of S^T), pre-scaled by 1/8
-    bf16x8 qf[4], e[NSUB][4];
-    const int q0 = Q0 + w;                               // the wave's diagonal tile / first "hi" chunk
-    if (wave_on) {
+    bf16x8 qf[4], e[4];
+    {
         const uint16_t* qp = qkv_b + (size_t)(i0 + a) * ld + hd * 64 + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -119,24 +122,25 @@ __global__ __launch_bounds__(256, NSUB == 1 ? 3 : 2) void rel_attn_fwd_kernel(
 #pragma unroll
             for (int k = 0; k < 8; ++k) f[k] *= 0.125f;
             qf[ks] = __builtin_bit_cast(bf16x8, pack8(f));
-            e[0][ks] = ef(q0, ks);
+            e[ks] = ef(q0, ks);
         }
     }
     __syncthreads();
 
-    // band addressing (rel_attn_common.hpp): register r writes row slot r of region hh at the precomputed
-    // absolute LDS offset wcl[r] (XOR bit 7 for odd chunks: OFF_BAND and BAND_BYTES are multiples of 256, so
-    // the low 8 bits are the column byte offset); a lane reads its own row with four ds_read_b128 at
-    // rbase + 32*g4 (+128 when D/32 is odd)
-    const int band_base = C::OFF_BAND + w * BAND_BYTES;
-    int wcl[16];
+    // band addressing (rel_attn_common.hpp): register r writes row slot r of region hh.  wcl[r] = absolute LDS address of
+    // (wave band + region + column byte offset): every term but the column is a multiple of 256, so XOR-ing bit 7 of the
+    // whole value flips the chunk parity; the row slot r*272 is the instruction's immediate offset.  A lane reads its own
+    // row with four ds_read_b128 at rbase + 32*g4 (+128 when D/32 is odd).
+    const int band_base = OFF_BAND + w * BAND_BYTES;
+    uint32_t wcl[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) wcl[r] = band_base + hh * BAND_REGION + (((crow(r, hh) - a) & 63) << 2);
+    for (int r = 0; r < 16; ++r)
+        wcl[r] = lds_addr_of(smem) + band_base + hh * BAND_REGION + (((crow(r, hh) - a) & 63) << 2);
     const int rbase = band_base + band_rowoff(a) + 16 * hh;
     auto band_put = [&](const f32x16& v, int q) {        // chunk q of Q.Er^T -> band
-        const int tog = (q & 1) << 7;
+        const uint32_t tog = (q & 1) << 7;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) *(float*)(smem + r * BAND_STRIDE + (wcl[r] ^ tog)) = v[r];
+        for (int r = 0; r < 16; ++r) lds_store_f32((wcl[r] ^ tog) + r * BAND_STRIDE, v[r]);
     };
     auto band_get = [&](int dq) {                        // Srel^T of the tile with D/32 = dq
         const char* rb = smem + rbase + ((dq & 1) << 7);
@@ -148,193 +152,149 @@ __global__ __launch_bounds__(256, NSUB == 1 ? 3 : 2) void rel_attn_fwd_kernel(
         }
         return c;
     };
-    if (wave_on) {
+    {
         f32x16 qe = zero16();
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[0][ks], qe);
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
         band_put(qe, q0);
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) e[u][ks] = ef(q0 - u - 1, ks);      // new chunks of step 0
+        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(q0 - 1, ks);      // new chunk of step 0
     }
 
     f32x16 o0 = zero16(), o1 = zero16();
     float m_ref = M_INIT, l_run = 0.f;
     float lse2w = 0.f;
-    if (WRITE_W && wave_on) lse2w = lse_in[((size_t)b * heads + hd) * L + i0 + a] * LOG2E;
+    if (WRITE_W) lse2w = lse_in[((size_t)b * heads + hd) * L + i0 + a] * LOG2E;
 
-    // ---- softmax of the step's tiles against the lazy reference, then O^T += V^T P^T ---------------
+    // ---- softmax of one tile against the lazy reference, then O^T += V^T P^T ------------------------
     // P^T goes straight into the bf16 operand fragments of the O^T product (k order kappa, see acc_to_frag)
-    auto exp_tiles = [&](const f32x16 (&c)[NSUB], const bool (&act)[NSUB], float mneg, bf16x8 (&pf)[NSUB][2]) {
+    auto exp_tile = [&](const f32x16& c, float mneg, bf16x8 (&pf)[2]) {
         float lsum = 0.f;
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) {
-            if (!act[u]) continue;
+        for (int ss = 0; ss < 2; ++ss) {
+            u32x4 wv;
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                u32x4 wv;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(c[u][8 * ss + 2 * jj], LOG2E, mneg));
-                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(c[u][8 * ss + 2 * jj + 1], LOG2E, mneg));
-                    lsum += p0;
-                    lsum += p1;
-                    wv[jj] = pack_bf16x2(p0, p1);
-                }
-                pf[u][ss] = __builtin_bit_cast(bf16x8, wv);
+            for (int jj = 0; jj < 4; ++jj) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(c[8 * ss + 2 * jj], LOG2E, mneg));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(c[8 * ss + 2 * jj + 1], LOG2E, mneg));
+                lsum += p0;
+                lsum += p1;
+                wv[jj] = pack_bf16x2(p0, p1);
             }
+            pf[ss] = __builtin_bit_cast(bf16x8, wv);
         }
         return lsum;
     };
-    auto softmax_pv = [&](const f32x16 (&c)[NSUB], const bool (&act)[NSUB], int cur) {
-        bf16x8 pf[NSUB][2];
-        float lsum = exp_tiles(c, act, -m_ref * LOG2E, pf);
+    auto softmax_pv = [&](const f32x16& c, int cur) {
+        bf16x8 pf[2];
+        float lsum = exp_tile(c, -m_ref * LOG2E, pf);
         if (__builtin_expect(__any(!(lsum <= L_SAFE)), 0)) {
             // redo against the true maximum (both lane halves of a query row must agree on m)
-            float tmax = -INFINITY;
+            float tmax = c[0];
 #pragma unroll
-            for (int u = 0; u < NSUB; ++u) {
-                if (!act[u]) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, c[u][r]);
-            }
+            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, c[r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m_ref, tmax);       // finite: every visited tile has a key j <= i (or PAD_NEG)
             const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * LOG2E);
-            lsum = exp_tiles(c, act, -m_new * LOG2E, pf);
+            lsum = exp_tile(c, -m_new * LOG2E, pf);
             l_run *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
             m_ref = m_new;
         }
         l_run += lsum;
+        const char* vt = smem + OFF_V + cur * TILE_BYTES;
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) {
-            if (!act[u]) continue;
-            const char* vt = smem + C::OFF_V + cur * C::KT + u * TILE_BYTES;
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                o0 = mfma(frag_T(vt, lane, ss, 0), pf[u][ss], o0);
-                o1 = mfma(frag_T(vt, lane, ss, 1), pf[u][ss], o1);
-            }
+        for (int ss = 0; ss < 2; ++ss) {
+            o0 = mfma(frag_T(vt, lane, ss, 0), pf[ss], o0);
+            o1 = mfma(frag_T(vt, lane, ss, 1), pf[ss], o1);
         }
     };
     const int am = a - 4 * hh;                           // key crow(r,hh) is in the future of query a  <=>  crow(r,0) > am
 
-    for (int s = 0; s < nsteps; ++s) {
+    // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: ONE branch-free body -------------
+    const int nmain = (WRITE_W || anypad) ? 0 : Q0;       // Q0 <= ntw - 1: a next tile always exists inside this loop
+    size_t koff = (ntw > 1) ? tile_stride : 0;            // element offset of the tile to prefetch
+    int s = 0;
+    for (; s < nmain; ++s) {
         const int cur = s & 1;
-        // ---- prefetch the next step's tiles into registers -------------------------------------------
-        u32x4 kreg[NSUB], vreg[NSUB];
+        const u32x4 kreg = *(const u32x4*)(kg + koff);
+        const u32x4 vreg = *(const u32x4*)(vg + koff);
+        koff += (s + 2 < ntw) ? tile_stride : 0;
+        const int dq = q0 - s;                            // >= 1
+        f32x16 c = zero16();
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) {
-            kreg[u] = *(const u32x4*)(kg + tile_off(NSUB * (s + 1) + u));
-            vreg[u] = *(const u32x4*)(vg + tile_off(NSUB * (s + 1) + u));
-        }
-        const int dq0 = q0 - NSUB * s;                   // D/32 of the step's first tile for this wave
-        if (wave_on && dq0 >= 0) {
-            uint32_t pw[NSUB];
-            bool full = !WRITE_W && (dq0 - (NSUB - 1) >= 1);
+        for (int ks = 0; ks < 4; ++ks) c = mfma(qf[ks], e[ks], c);
+        band_put(c, dq - 1);
+        wave_lds_fence();
+        c = band_get(dq);
+        wave_lds_fence();
 #pragma unroll
-            for (int u = 0; u < NSUB; ++u) {
-                pw[u] = padword(NSUB * s + u);
-                full = full && (pw[u] == 0);
+        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(dq - 2, ks);          // chunk of the next step
+        const char* kt = smem + OFF_K + cur * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
+        softmax_pv(c, cur);
+        *(u32x4*)(smem + OFF_K + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
+        *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
+        __syncthreads();
+    }
+
+    // ---- general body: the diagonal 128 x 128 block (a wave is full / on its diagonal / done), padded keys,
+    //      weights output ------------------------------------------------------------------------------------------
+    for (; s < ntw; ++s) {
+        const int cur = s & 1;
+        const u32x4 kreg = *(const u32x4*)(kg + koff);
+        const u32x4 vreg = *(const u32x4*)(vg + koff);
+        koff += (s + 2 < ntw) ? tile_stride : 0;
+        const int dq = q0 - s;                            // wave active iff dq >= 0
+        if (dq >= 0) {
+            const uint32_t pw = padword(s);
+            if (dq >= 1) {
+                f32x16 qe = zero16();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
+                band_put(qe, dq - 1);
             }
-            const char* kt = smem + C::OFF_K + cur * C::KT;
-            if (full) {
-                // ---- branch-free body: every tile of the step is full (below the diagonal, no padded key) --
-                f32x16 c[NSUB];
+            wave_lds_fence();
+            f32x16 c = band_get(dq);
+            wave_lds_fence();
 #pragma unroll
-                for (int u = 0; u < NSUB; ++u) {
-                    c[u] = zero16();
+            for (int ks = 0; ks < 4; ++ks) e[ks] = ef(dq - 2, ks);
+            const char* kt = smem + OFF_K + cur * TILE_BYTES;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) c[u] = mfma(qf[ks], e[u][ks], c[u]);
+            for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
+            if (dq == 0) {                                // diagonal tile: key b > query a is the future
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (crow(r, 0) > am) ? -INFINITY : c[r];
+            }
+            if (pw) {                                     // padded key: the reference's additive -1e9 (future keys stay -inf)
+                const uint32_t pwl = pw >> (4 * hh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (pwl & (1u << crow(r, 0))) ? fminf(c[r], PAD_NEG) : c[r];
+            }
+            if (WRITE_W) {
+                // weights[b,h,i0+a, j0 + 8*g4 + 4*hh + k] = exp(S - lse); masked entries are exactly 0
+                if (wave_on) {
+                    float* wrow = weights + (((size_t)b * heads + hd) * L + i0 + a) * L + 32 * s + 4 * hh;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sv = c[4 * g4 + k];
+                            v[k] = (sv <= PAD_NEG) ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sv, LOG2E, -lse2w));
+                        }
+                        *(f32x4*)(wrow + 8 * g4) = v;
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < NSUB; ++u) {          // LDS operations of a wave execute in order
-                    band_put(c[u], dq0 - u - 1);
-                    wave_lds_fence();
-                    c[u] = band_get(dq0 - u);
-                    wave_lds_fence();
-                }
-#pragma unroll
-                for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) e[u][ks] = ef(dq0 - u - 1 - NSUB, ks);    // chunks of the next step
-#pragma unroll
-                for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) c[u] = mfma(frag_R(kt + u * TILE_BYTES, a, hh, ks), qf[ks], c[u]);
-                bool all_on[NSUB];
-#pragma unroll
-                for (int u = 0; u < NSUB; ++u) all_on[u] = true;
-                softmax_pv(c, all_on, cur);
             } else {
-                // ---- general body: diagonal tile, padded keys, tiles beyond the diagonal, weights output ----
-                f32x16 c[NSUB];
-                bool act[NSUB];
-#pragma unroll
-                for (int u = 0; u < NSUB; ++u) {
-                    const int dq = dq0 - u;
-                    act[u] = dq >= 0;
-                    c[u] = zero16();
-                    if (dq >= 1) {
-                        f32x16 qe = zero16();
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[u][ks], qe);
-                        band_put(qe, dq - 1);
-                    }
-                    wave_lds_fence();
-                    if (act[u]) {
-                        c[u] = band_get(dq);
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) c[u] = mfma(frag_R(kt + u * TILE_BYTES, a, hh, ks), qf[ks], c[u]);
-                        if (dq == 0) {                    // diagonal tile: key b > query a is the future
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) c[u][r] = (crow(r, 0) > am) ? -INFINITY : c[u][r];
-                        }
-                        if (pw[u]) {                      // padded key: the reference's additive -1e9 (future keys stay -inf)
-                            const uint32_t pwl = pw[u] >> (4 * hh);
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                c[u][r] = (pwl & (1u << crow(r, 0))) ? fminf(c[u][r], PAD_NEG) : c[u][r];
-                        }
-                    }
-                    wave_lds_fence();
-                }
-#pragma unroll
-                for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) e[u][ks] = ef(dq0 - u - 1 - NSUB, ks);
-                if (WRITE_W) {
-                    // weights[b,h,i0+a, j0 + 8*g4 + 4*hh + k] = exp(S - lse); masked entries are exactly 0
-#pragma unroll
-                    for (int u = 0; u < NSUB; ++u) {
-                        if (!act[u]) continue;
-                        float* wrow = weights + (((size_t)b * heads + hd) * L + i0 + a) * L + 32 * (NSUB * s + u) + 4 * hh;
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            f32x4 v;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float sv = c[u][4 * g4 + k];
-                                v[k] = (sv <= PAD_NEG) ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sv, LOG2E, -lse2w));
-                            }
-                            *(f32x4*)(wrow + 8 * g4) = v;
-                        }
-                    }
-                } else {
-                    softmax_pv(c, act, cur);
-                }
+                softmax_pv(c, cur);
             }
         }
-        // ---- publish the prefetched tiles into the other buffers ---------------------------------
-        if (s + 1 < nsteps) {
-#pragma unroll
-            for (int u = 0; u < NSUB; ++u) {
-                *(u32x4*)(smem + C::OFF_K + (cur ^ 1) * C::KT + u * TILE_BYTES + st_offR) = kreg[u];
-                *(u32x4*)(smem + C::OFF_V + (cur ^ 1) * C::KT + u * TILE_BYTES + st_offT) = vreg[u];
-            }
+        if (s + 1 < ntw) {
+            *(u32x4*)(smem + OFF_K + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
+            *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
         }
         __syncthreads();
     }
@@ -348,18 +308,11 @@ __global__ __launch_bounds__(256, NSUB == 1 ? 3 : 2) void rel_attn_fwd_kernel(
     }
 }
 
-// NSUB: 32-key tiles per step.  2 => 64-key steps, 67.6 KB LDS, 2 workgroups per CU with up to 256 VGPRs (two
-// independent tile streams per wave); 1 => 32-key steps, 52.2 KB, 3 workgroups per CU.
-#ifndef MGX_FWD_NSUB
-#define MGX_FWD_NSUB 1
-#endif
-
 static void set_fwd_attrs() {
     static bool attr_set = false;
     if (attr_set) return;
-    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<MGX_FWD_NSUB, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        FwdCfg<MGX_FWD_NSUB>::LDS_BYTES);
-    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FwdCfg<1>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
 }
 
@@ -382,9 +335,8 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
     set_fwd_attrs();
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
     dim3 grid(B * (d / 64), (L + 127) / 128);
-    hipLaunchKernelGGL((rel_attn_fwd_kernel<MGX_FWD_NSUB, false>), grid, dim3(256), FwdCfg<MGX_FWD_NSUB>::LDS_BYTES,
-                       (hipStream_t)stream, qkv, (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr,
-                       (float*)nullptr, L, d);
+    hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
+                       (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");
     return MGX_OK;
 }
@@ -397,7 +349,7 @@ extern "C" int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, cons
     set_fwd_attrs();
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
     dim3 grid(B * (d / 64), (L + 127) / 128);
-    hipLaunchKernelGGL((rel_attn_fwd_kernel<1, true>), grid, dim3(256), FwdCfg<1>::LDS_BYTES, (hipStream_t)stream, qkv,
+    hipLaunchKernelGGL(rel_attn_fwd_kernel<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
                        (const u32x4*)workspace, padbits, (uint16_t*)nullptr, (float*)nullptr, lse, weights, L, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_weights");
     return MGX_OK;
