@@ -415,7 +415,8 @@ constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K  dO image R
 constexpr int OFF_OT = OFF_OR + 2 * TILE_BYTES;            // 2 x 4K  dO image T
 constexpr int OFF_ST = OFF_OT + 2 * TILE_BYTES;            // 2 x 256 B: lse2[32], delta[32]
 constexpr int OFF_BAND = OFF_ST + 2 * 256;                 // 4 x 8K fp32 [32][64]
-constexpr int LDS_BYTES = OFF_BAND + WAVES * 8192;         // 66,048 B -> 2 workgroups per CU
+constexpr int OFF_FLAG = OFF_BAND + WAVES * 8192;          // "a key of this workgroup is padded" flag
+constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 66,064 B -> 2 workgroups per CU
 // The Er chunks (B operand of Q.Er^T: column t = lane&31, 16 contiguous bytes of row L-1-32q-t) are
 // loaded straight from global/L2 into registers, one new chunk per step (the previous "hi" chunk is
 // the next "lo" chunk), so E needs no LDS here.
@@ -426,17 +427,19 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
     uint16_t* __restrict__ dqkv, int L, int d) {
     using namespace k2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band reads XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bl = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int J0 = blockIdx.y * 128;                       // small J0 = longest sweep = dispatched first
-    const int j0 = J0 + w * 32;
     const int nchunk = L >> 5;
-    const bool wave_on = j0 < L;
-    const int nT = (L - J0) >> 5;
+    const int nT = (L - J0) >> 5;                          // query tiles i0 = J0 + 32 t
+    const bool wave_on = J0 + w * 32 < L;
+    // a wave beyond the end of the sequence (L % 128 != 0) shadows the last valid key block and stores nothing
+    const int wk = wave_on ? w : nT - 1;                   // the wave's key tile inside the workgroup; D/32 = t - wk
+    const int j0 = J0 + wk * 32;
     const size_t ld = (size_t)3 * d;
     const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
     const size_t stat_base = ((size_t)b * heads + hd) * L;
@@ -445,10 +448,13 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
     const uint16_t* qg = qkv_b + (size_t)(J0 + srow) * ld + hd * 64 + sch * 8;                  // + t*32*ld
     const uint16_t* og = dctx + ((size_t)b * L + J0 + srow) * d + hd * 64 + sch * 8;            // + t*32*d
-    // fragment ks of Er chunk q for this lane (fragment-ordered copy: 1 KB contiguous per wave load)
-    auto e_frag = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, EfA[(size_t)(q * 4 + ks) * 64 + lane]); };
+    // fragment ks of Er chunk q for this lane (fragment-ordered copy: 1 KB contiguous per wave load).  Every load of the
+    // sweep is unconditional with a clamped index; data of clamped tiles / chunks is never used.
+    auto e_frag = [&](int q, int ks) {
+        return __builtin_bit_cast(bf16x8, EfA[(size_t)(min(max(q, 0), nchunk - 1) * 4 + ks) * 64 + lane]);
+    };
     auto stat_src = [&](int t) {   // tid < 64: lse (0..31) / delta (32..63) of query tile t
-        const int i = J0 + 32 * t + (tid & 31);
+        const int i = J0 + 32 * min(t, nT - 1) + (tid & 31);
         return (tid < 32) ? lse[stat_base + i] * LOG2E : delta[stat_base + i];
     };
 
@@ -461,74 +467,83 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         *(u32x4*)(smem + OFF_OT + st_offT) = oo;
         if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0);
     }
-    bf16x8 kf[4], vf[4], ehi[4], elo[4];
+    // E chunk fragments: a step's "hi" chunk (t - wk) sits in e[PAR], the "lo" chunk (t - wk - 1) in e[PAR^1]; the slot of
+    // the lo chunk receives chunk t - wk + 1 once it has been used, which is the next step's hi chunk.  The main loop
+    // alternates PAR = 0, 1 (two steps per trip); the general body always uses PAR = 0 and swaps the slots afterwards.
+    bf16x8 kf[4], vf[4], e[2][4];
     uint32_t padlane = 0;
-    if (wave_on) {
-        if (w == 0) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ehi[ks] = e_frag(0, ks);      // wave 0 starts on its diagonal (chunk 0)
-        }
+    int wgpad = 0;
+    {
         const uint16_t* kp = qkv_b + (size_t)(j0 + bl) * ld + d + hd * 64 + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             kf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + ks * 16));
             vf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + d + ks * 16));
+            e[0][ks] = e_frag(0, ks);                       // the wave's first step (t = wk) is its diagonal: hi chunk 0
+            e[1][ks] = e[0][ks];
         }
-        if (padbits) padlane = (padbits[(size_t)b * nchunk + (j0 >> 5)] >> bl) & 1u;
+        if (padbits) {
+            const uint32_t pwv = padbits[(size_t)b * nchunk + (j0 >> 5)];
+            padlane = (pwv >> bl) & 1u;
+            // any padded key in this workgroup's 128 keys?  (no __syncthreads_or: it allocates static LDS)
+            if (tid == 0) *(volatile uint32_t*)(smem + OFF_FLAG) = 0u;
+            __syncthreads();
+            if (pwv) *(volatile uint32_t*)(smem + OFF_FLAG) = 1u;
+            __syncthreads();
+            wgpad = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)(smem + OFF_FLAG));
+        }
     }
     __syncthreads();
-    char* band = smem + OFF_BAND + w * 8192;
+    const int band_base = OFF_BAND + w * 8192;
+    char* band = smem + band_base;
+    // band (plain [32 query rows][64 distances] fp32): QE[ar][t] of chunk q is written at column 32(q&1) + t; the tile reads
+    // column (D + ar - bl) & 63 of row ar = crow(r,hh).  rd[r] = ABSOLUTE LDS address for D/32 even; odd flips address bit 7
+    // (row bases are multiples of 256): one VALU per read.
+    uint32_t rd[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rd[r] = lds_addr_of(smem) + band_base + crow(r, hh) * 256 + (((crow(r, hh) - bl) & 63) << 2);
+    const uint32_t wr0 = lds_addr_of(smem) + band_base + hh * 1024 + bl * 4;      // + crow(r,0)*256 as the immediate
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
-    for (int t = 0; t < nT; ++t) {
-        const int cur = t & 1;
-        u32x4 qreg, oreg;
-        float streg = 0.f;
-        const bool have_next = (t + 1 < nT);
-        if (have_next) {
-            qreg = *(const u32x4*)(qg + (size_t)(t + 1) * 32 * ld);
-            oreg = *(const u32x4*)(og + (size_t)(t + 1) * 32 * d);
-            if (tid < 64) streg = stat_src(t + 1);
+    // ---- one query tile.  cur = t & 1 (LDS buffers), PAR = E slot of the hi chunk; MASKED: diagonal / padded-key masks ----
+    auto tile = [&](int dq, int cur, auto par_tag, auto masked_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const char* qr = smem + OFF_QR + cur * TILE_BYTES;
+        bf16x8 qa[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_R(qr, bl, hh, ks);
+        // QE for chunks dq and dq-1: rows = query a, cols = t
+        {
+            f32x16 qe = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR][ks], qe);
+            const uint32_t wa = wr0 + ((dq & 1) << 7);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds_store_f32(wa + crow(r, 0) * 256, qe[r]);
         }
-        const int dq = t - w;
-        bf16x8 enext[4];
-        const bool load_e = wave_on && have_next && (dq + 1 >= 0);     // chunk dq+1 <= nT-1 < nchunk
-        if (load_e) {
+        if (!MASKED || dq >= 1) {
+            f32x16 qe = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) enext[ks] = e_frag(dq + 1, ks);
+            for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR ^ 1][ks], qe);
+            const uint32_t wa = wr0 + (((dq - 1) & 1) << 7);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds_store_f32(wa + crow(r, 0) * 256, qe[r]);
         }
-        if (wave_on && dq >= 0) {
-            const int D = dq * 32;
-            const char* qr = smem + OFF_QR + cur * TILE_BYTES;
-            bf16x8 qa[4];
+        // the lo slot is free now: fetch the next step's hi chunk into it
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_R(qr, bl, hh, ks);
-            // QE for chunks dq (and dq-1): rows = query a, cols = t
-            {
-                f32x16 qe = zero16();
+        for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
+        wave_lds_fence();
+        f32x16 c;
+        {
+            const uint32_t tog = (dq & 1) << 7;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], ehi[ks], qe);
-                const int cb = (dq & 1) * 32 + bl;
+            for (int r = 0; r < 16; ++r) c[r] = *(lds_f32_ptr)(uintptr_t)(rd[r] ^ tog);
+        }
+        wave_lds_fence();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
-            }
-            if (dq >= 1) {
-                f32x16 qe = zero16();
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], elo[ks], qe);
-                const int cb = ((dq - 1) & 1) * 32 + bl;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) *(float*)(band + (crow(r, hh) * 64 + cb) * 4) = qe[r];
-            }
-            wave_lds_fence();
-            f32x16 c;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ar = crow(r, hh);
-                c[r] = *(const float*)(band + (ar * 64 + ((D + ar - bl) & 63)) * 4);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) c = mfma(qa[ks], kf[ks], c);
+        for (int ks = 0; ks < 4; ++ks) c = mfma(qa[ks], kf[ks], c);
+        if (MASKED) {
             if (dq == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c[r] = (bl > crow(r, hh)) ? -INFINITY : c[r];
@@ -537,49 +552,84 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c[r] = -INFINITY;
             }
-            const char* st = smem + OFF_ST + cur * 256;
-            f32x16 dp = zero16();
-            const char* orr = smem + OFF_OR + cur * TILE_BYTES;
+        }
+        const char* st = smem + OFF_ST + cur * 256;
+        f32x16 dp = zero16();
+        const char* orr = smem + OFF_OR + cur * TILE_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(orr, bl, hh, ks), vf[ks], dp);
-            f32x16 ds;
+        for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(orr, bl, hh, ks), vf[ks], dp);
+        f32x16 ds;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
-                const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
+            const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], LOG2E, -l4[k]));
-                    c[4 * g4 + k] = p;
-                    ds[4 * g4 + k] = p * (dp[4 * g4 + k] - d4[k]);
-                }
-            }
-            const char* ot = smem + OFF_OT + cur * TILE_BYTES;
-            const char* qt = smem + OFF_QT + cur * TILE_BYTES;
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const bf16x8 pf = acc_to_frag(c, ss);
-                const bf16x8 df = acc_to_frag(ds, ss);
-                dv0 = mfma(frag_T(ot, lane, ss, 0), pf, dv0);
-                dv1 = mfma(frag_T(ot, lane, ss, 1), pf, dv1);
-                dk0 = mfma(frag_T(qt, lane, ss, 0), df, dk0);
-                dk1 = mfma(frag_T(qt, lane, ss, 1), df, dk1);
+            for (int k = 0; k < 4; ++k) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], LOG2E, -l4[k]));
+                c[4 * g4 + k] = p;
+                ds[4 * g4 + k] = p * (dp[4 * g4 + k] - d4[k]);
             }
         }
-        if (have_next) {
-            const u32x4 qq = scale8(qreg, 0.125f);
-            *(u32x4*)(smem + OFF_QR + (cur ^ 1) * TILE_BYTES + st_offR) = qq;
-            *(u32x4*)(smem + OFF_QT + (cur ^ 1) * TILE_BYTES + st_offT) = qq;
-            *(u32x4*)(smem + OFF_OR + (cur ^ 1) * TILE_BYTES + st_offR) = oreg;
-            *(u32x4*)(smem + OFF_OT + (cur ^ 1) * TILE_BYTES + st_offT) = oreg;
-            if (tid < 64) *(float*)(smem + OFF_ST + (cur ^ 1) * 256 + tid * 4) = streg;
-        }
-        if (load_e) {     // this step's "hi" chunk is the next step's "lo" chunk
+        const char* ot = smem + OFF_OT + cur * TILE_BYTES;
+        const char* qt = smem + OFF_QT + cur * TILE_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { elo[ks] = ehi[ks]; ehi[ks] = enext[ks]; }
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 pf = acc_to_frag(c, ss);
+            const bf16x8 df = acc_to_frag(ds, ss);
+            dv0 = mfma(frag_T(ot, lane, ss, 0), pf, dv0);
+            dv1 = mfma(frag_T(ot, lane, ss, 1), pf, dv1);
+            dk0 = mfma(frag_T(qt, lane, ss, 0), df, dk0);
+            dk1 = mfma(frag_T(qt, lane, ss, 1), df, dk1);
         }
+    };
+    // prefetch of the next query tile (registers) and its publication into the other LDS buffers
+    u32x4 qreg, oreg;
+    float streg = 0.f;
+    auto prefetch = [&](int t) {      // tile t + 1, clamped
+        const int tn = min(t + 1, nT - 1);
+        qreg = *(const u32x4*)(qg + (size_t)tn * 32 * ld);
+        oreg = *(const u32x4*)(og + (size_t)tn * 32 * d);
+        if (tid < 64) streg = stat_src(tn);
+    };
+    auto publish = [&](int nxt) {
+        const u32x4 qq = scale8(qreg, 0.125f);
+        *(u32x4*)(smem + OFF_QR + nxt * TILE_BYTES + st_offR) = qq;
+        *(u32x4*)(smem + OFF_QT + nxt * TILE_BYTES + st_offT) = qq;
+        *(u32x4*)(smem + OFF_OR + nxt * TILE_BYTES + st_offR) = oreg;
+        *(u32x4*)(smem + OFF_OT + nxt * TILE_BYTES + st_offT) = oreg;
+        if (tid < 64) *(float*)(smem + OFF_ST + nxt * 256 + tid * 4) = streg;
+    };
+
+    // ---- general body: the diagonal 128 x 128 block (t < 4: a wave is not started / on its diagonal / full), every
+    //      step when a key of this workgroup is padded, and an odd last step ------------------------------------------------
+    auto general_step = [&](int t) {
+        prefetch(t);
+        const int dq = t - wk;
+        if (dq >= 0) {
+            tile(dq, t & 1, std::integral_constant<int, 0>{}, std::true_type{});
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { const bf16x8 x = e[0][ks]; e[0][ks] = e[1][ks]; e[1][ks] = x; }
+        }
+        publish((t & 1) ^ 1);
+        __syncthreads();
+    };
+    int t = 0;
+    const int nhead = wgpad ? nT : min(4, nT);
+    for (; t < nhead; ++t) general_step(t);
+    // ---- main loop (t >= 4 is even here): every wave's tile is full, no masks: branch-free bodies, two steps per trip so
+    //      that the LDS buffer and the E slot of each step are compile-time constants -----------------------------------------
+    for (; t + 1 < nT; t += 2) {
+        prefetch(t);
+        tile(t - wk, 0, std::integral_constant<int, 0>{}, std::false_type{});
+        publish(1);
+        __syncthreads();
+        prefetch(t + 1);
+        tile(t + 1 - wk, 1, std::integral_constant<int, 1>{}, std::false_type{});
+        publish(0);
         __syncthreads();
     }
+    for (; t < nT; ++t) general_step(t);
+
     if (wave_on) {
         uint16_t* row0 = dqkv + ((size_t)b * L + j0) * ld + hd * 64;
         store_rows_lds(row0 + d, ld, dk0, dk1, lane, 1.f, band);

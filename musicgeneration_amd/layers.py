@@ -51,8 +51,47 @@ class DynamicPositionEmbedding(torch.nn.Module):
         return x + self._pe[: x.size(1)].to(x.dtype)[None]
 
 
+def key_padding_from_mask(mask: torch.Tensor, L: int):
+    """The kernels build the reference's look-ahead mask themselves (future keys, structurally; padded keys, from a
+    bitmap).  A mask tensor handed to a layer (utils.get_masked_with_pad_tensor's ``[B,1,L,L]``, nonzero = masked) must
+    therefore BE such a mask: returns the padded-key flags ``[B,L]`` (read off the last query row, which sees every key)
+    after checking that ``mask == padded[key] | (key > query)``.  Anything else raises."""
+    m = mask
+    if m.dim() == 4:
+        if m.shape[1] != 1:
+            raise ValueError("per-head masks are not supported (expected [B,1,L,L])")
+        m = m[:, 0]
+    if m.dim() != 3 or m.shape[-1] != L or m.shape[-2] != L:
+        raise ValueError(f"mask must be [B,1,{L},{L}] (got {tuple(mask.shape)})")
+    m = m != 0
+    padded = m[:, L - 1, :]
+    future = torch.ones(L, L, dtype=torch.bool, device=m.device).triu(1)
+    if not torch.equal(m, padded[:, None, :] | future[None]):
+        raise ValueError("the MI355X attention kernels implement causal attention with key padding only: the mask must be "
+                         "the look-ahead mask of utils.get_masked_with_pad_tensor (padded keys | future keys)")
+    return padded
+
+
+def _pad_bitmap_from_flags(padded: torch.Tensor) -> torch.Tensor:
+    """bool [B,L] -> int32 [B,L/32] in mgx_pad_bitmap's layout (bit j&31 of word j>>5)"""
+    B, L = padded.shape
+    w = (padded.view(B, L // 32, 32).to(torch.int64) << torch.arange(32, device=padded.device, dtype=torch.int64)).sum(-1)
+    w = torch.where(w >= 2 ** 31, w - 2 ** 32, w)
+    return w.to(torch.int32).contiguous()
+
+
+def _need_mask(mask):
+    if mask is None:
+        raise NotImplementedError(
+            "mask=None asks for bidirectional attention (what the reference's generate() does, network.py:60); the MI355X "
+            "kernels are causal -- pass the look-ahead mask.  Sampling with training-time causal semantics is "
+            "MusicTransformer.generate / generate_cached (DESIGN.md section 5).")
+
+
 class RelativeGlobalAttention(torch.nn.Module):
-    """Parameter container with the reference's names (layers.py:47-62); compute is in EncoderLayer."""
+    """layers.py:47-133.  Holds the reference's parameters under the reference's names.  ``forward([q,k,v], mask)`` runs the
+    fused relative attention kernels on its own (projections -> mgx_rel_attn_fwd -> fc), with ordinary autograd gradients;
+    inside MusicTransformer the whole encoder block runs as one node instead (ops._EncoderLayer)."""
 
     def __init__(self, h=4, d=256, add_emb=False, max_seq=2048, **kwargs):
         super().__init__()
@@ -69,6 +108,35 @@ class RelativeGlobalAttention(torch.nn.Module):
         self.fc = torch.nn.Linear(d, d)
         self.additional = add_emb
         self.E = torch.nn.Parameter(torch.randn([self.max_seq, int(self.dh)]))
+        self.need_weights = True        # the reference always returns the [B,h,L,L] weights; set False to skip that pass
+
+    def forward(self, inputs, mask=None, **kwargs):
+        """inputs = [q, k, v], each [B,L,d] (layers.py:64-109) -> (out [B,L,d], attention_weights [B,h,L,L] or None).
+        Self-attention shapes only (len_q == len_k <= max_seq, L % 32 == 0).  Computes in bf16; returns q's dtype."""
+        q, k, v = inputs
+        if not (q.shape == k.shape == v.shape) or q.dim() != 3 or q.shape[-1] != self.d:
+            raise ValueError("expected three [B,L,d] tensors of one shape")
+        _need_mask(mask)
+        B, L, _ = q.shape
+        if L % 32 != 0 or L > self.max_seq:
+            raise ValueError(f"sequence length {L} must be a multiple of 32 and <= max_seq={self.max_seq}")
+        self.len_q = self.len_k = L
+        padbits = _pad_bitmap_from_flags(key_padding_from_mask(mask, L))
+        bf = torch.bfloat16
+        if q is k and k is v:
+            x16 = q.to(bf).contiguous()
+            qkv = ops.linear_std(x16, torch.cat([self.Wq.weight, self.Wk.weight, self.Wv.weight], 0),
+                                 torch.cat([self.Wq.bias, self.Wk.bias, self.Wv.bias], 0))
+        else:
+            qkv = torch.cat([ops.linear_std(t.to(bf).contiguous(), lin.weight, lin.bias)
+                             for t, lin in ((q, self.Wq), (k, self.Wk), (v, self.Wv))], -1)
+        att, lse = ops.rel_attn_std(qkv, self.E, padbits)          # E is cut to its last L rows inside (M >= L)
+        out = ops.linear_std(att, self.fc.weight, self.fc.bias)
+        weights = None
+        if self.need_weights:
+            with torch.no_grad():
+                weights = ops.rel_attn_weights(qkv.detach(), self.E.detach().to(bf).contiguous(), padbits, lse)
+        return out.to(q.dtype), weights
 
 
 class EncoderLayer(torch.nn.Module):
@@ -85,6 +153,22 @@ class EncoderLayer(torch.nn.Module):
         self.layernorm2 = torch.nn.LayerNorm(self.d_model, eps=1e-6)
         self.dropout1 = torch.nn.Dropout(rate)
         self.dropout2 = torch.nn.Dropout(rate)
+        self._seed_ctr = 0
+
+    def forward(self, x, mask=None, **kwargs):
+        """layers.py:152-161 on its own (see RelativeGlobalAttention.forward): -> (out2, attention weights)"""
+        attn_out, w = self.rga([x, x, x], mask)
+        bf = torch.bfloat16
+        p = self.rate if self.training else 0.0
+        self._seed_ctr += 1
+        seed = (torch.initial_seed() * 1000003 + self._seed_ctr * 64) & 0x7FFFFFFFFFFFFFFF
+        # dropout is fused into the residual + LayerNorm kernel (mask = pure function of (seed, element index))
+        out1 = ops.add_ln_std(attn_out.to(bf).contiguous(), x.to(bf).contiguous(), self.layernorm1.weight, self.layernorm1.bias,
+                              self.layernorm1.eps, p, seed + 1)
+        ffn = ops.linear_std(out1, self.FFN_pre.weight, self.FFN_pre.bias, act=1)
+        ffn = ops.linear_std(ffn, self.FFN_suf.weight, self.FFN_suf.bias)
+        out2 = ops.add_ln_std(ffn, out1, self.layernorm2.weight, self.layernorm2.bias, self.layernorm2.eps, p, seed + 2)
+        return out2.to(x.dtype), w
 
     # order of this layer's parameters inside the flat buffers (Wq|Wk|Wv adjacent!)
     FLAT_ORDER = ["rga.Wq.weight", "rga.Wk.weight", "rga.Wv.weight", "rga.Wq.bias", "rga.Wk.bias", "rga.Wv.bias",
@@ -202,3 +286,38 @@ class Encoder(torch.nn.Module):
             [EncoderLayer(d_model, rate, h=self.d_model // 64, additional=False, max_seq=max_len)
              for _ in range(num_layers)])
         self.dropout = torch.nn.Dropout(rate)
+        self._seed_ctr = 0
+
+    def forward(self, x, mask=None):
+        """layers.py:223-233 on its own: tokens [B,L] -> (hidden [B,L,d] fp32, [attention weights per layer]).
+        MusicTransformer.forward does NOT go through here (it runs the fused flat-buffer path, network._logits)."""
+        _need_mask(mask)
+        weights = []
+        tok = x.to(torch.int32).contiguous()
+        p = self.rate if self.training else 0.0
+        self._seed_ctr += 1
+        seed = (torch.initial_seed() * 1000003 + self._seed_ctr * 64) & 0x7FFFFFFFFFFFFFFF
+        gtable = torch.zeros_like(self.embedding.weight, dtype=torch.float32)
+        h = _EmbedStd.apply(tok, self.embedding.weight, self.pos_encoding.table()[: tok.shape[1]].contiguous(), p, seed)
+        for layer in self.enc_layers:
+            h, w = layer(h, mask)
+            weights.append(w)
+        return h.float(), weights
+
+
+class _EmbedStd(torch.autograd.Function):
+    """embedding * sqrt(d) + PE (+dropout) with an ordinary returned gradient (stand-alone Encoder.forward)"""
+
+    @staticmethod
+    def forward(ctx, tok, table, pe, p_drop, seed):
+        ctx.save_for_backward(tok)
+        ctx.meta = (table.shape, table.dtype, p_drop, seed)
+        return ops.embed_pe_fwd(tok, table.detach().float().contiguous(), pe, p_drop, seed)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tok,) = ctx.saved_tensors
+        shape, dt, p_drop, seed = ctx.meta
+        g = torch.zeros(shape, dtype=torch.float32, device=dout.device)
+        ops.embed_bwd(tok, dout.contiguous(), g, p_drop, seed)
+        return None, g.to(dt), None, None, None

@@ -469,6 +469,84 @@ def embed_pe(tok, table, pe, p_drop=0.0, seed=0, gtable=None, done=None):
     return _EmbedPE.apply(tok, table, pe, float(p_drop), int(seed), gtable, done)
 
 
+# --------------------------------------------------------------------------------------------------
+# Stand-alone autograd nodes: the layer-level call surface of the reference (layers.py:64-109,152-161,
+# 223-233 -- ``rga([q,k,v], mask)``, ``EncoderLayer(x, mask)``, ``Encoder(x, mask)``).  Unlike the nodes
+# above they take ordinary fp32 Parameters, round them to bf16 per call and RETURN their gradients, so a
+# layer works on its own with any torch optimizer.  Same kernels; the model's training path keeps using the
+# flat-buffer nodes above (no per-call rounding, gradients accumulated in place).
+# --------------------------------------------------------------------------------------------------
+class _LinearStd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        w16 = weight.detach().to(BF16).contiguous()
+        y = linear_fwd(x, w16, None if bias is None else bias.detach().float().contiguous(), act)
+        ctx.save_for_backward(x, w16, y if act else None)
+        ctx.meta = (weight.dtype, bias is not None, bias.dtype if bias is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16, y = ctx.saved_tensors
+        wdt, has_b, bdt = ctx.meta
+        dy = dy.contiguous()
+        gw = torch.zeros(w16.shape, dtype=torch.float32, device=dy.device)
+        gb = torch.zeros(w16.shape[0], dtype=torch.float32, device=dy.device) if has_b else None
+        if y is not None:                           # ReLU output: mask the incoming gradient once, for dx and dW alike
+            dy = torch.where(y > 0, dy, torch.zeros_like(dy))
+        dx = linear_dx(dy, w16)
+        linear_dw(dy, x, gw, gb)
+        return dx, gw.to(wdt), (gb.to(bdt) if has_b else None), None
+
+
+class _RelAttnStd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, E, padbits):
+        e16 = E.detach().to(BF16).contiguous()
+        att, lse = rel_attn_fwd(qkv, e16, padbits)
+        ctx.save_for_backward(qkv, e16, att, lse)
+        ctx.padbits, ctx.edt = padbits, E.dtype
+        ctx.mark_non_differentiable(lse)
+        return att, lse
+
+    @staticmethod
+    def backward(ctx, datt, _dlse):
+        qkv, e16, att, lse = ctx.saved_tensors
+        dE = torch.zeros(e16.shape, dtype=torch.float32, device=qkv.device)
+        dqkv = rel_attn_bwd(qkv, e16, ctx.padbits, att, datt.contiguous(), lse, dE)
+        return dqkv, dE.to(ctx.edt), None
+
+
+class _AddLNStd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, eps, p_drop, seed):
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        out, mean, rstd = add_ln_fwd(x, res, g32, b32, eps, p_drop, seed)
+        ctx.save_for_backward(x, res, g32, mean, rstd)
+        ctx.meta = (p_drop, seed, gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, res, g32, mean, rstd = ctx.saved_tensors
+        p_drop, seed, gdt, bdt = ctx.meta
+        dg, db = torch.zeros_like(g32), torch.zeros_like(g32)
+        dx, dres = add_ln_bwd(dout.contiguous(), x, res, g32, mean, rstd, dg, db, p_drop, seed)
+        return dx, dres, dg.to(gdt), db.to(bdt), None, None, None
+
+
+def linear_std(x, weight, bias=None, act=0):
+    return _LinearStd.apply(x, weight, bias, int(act))
+
+
+def rel_attn_std(qkv, E, padbits):
+    return _RelAttnStd.apply(qkv, E, padbits)
+
+
+def add_ln_std(x, res, gamma, beta, eps=1e-6, p_drop=0.0, seed=0):
+    return _AddLNStd.apply(x, res, gamma, beta, float(eps), float(p_drop), int(seed))
+
+
 def linear(x, w_master, w_shadow, bias, act, gw, gb, done=None, x_is_relu=False):
     return _Linear.apply(x, w_master, w_shadow, bias, int(act), gw, gb, done, bool(x_is_relu))
 
