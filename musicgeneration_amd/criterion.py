@@ -48,28 +48,24 @@ class SmoothCrossEntropyLoss(_Loss):
 
 
 class CustomSchedule:
-    """criterion.py:70-96 (Noam schedule driving ``optimizer.step()``)."""
+    """Noam learning-rate schedule that also drives the optimiser (criterion.py:70-96):
+    ``lr(n) = d_model^-0.5 * min(n^-0.5, n * warmup^-1.5)`` with n = number of ``step()`` calls so far."""
 
     def __init__(self, d_model, warmup_steps=4000, optimizer=None):
-        super(CustomSchedule, self).__init__()
-        self.d_model = d_model
-        self.optimizer = optimizer
-        self.warmup_steps = warmup_steps
+        self.d_model, self.warmup_steps, self.optimizer = d_model, warmup_steps, optimizer
         self._step = 0
         self._rate = 0
 
-    def step(self):
-        "Update parameters and rate"
-        self._step += 1
-        rate = self.rate()
-        for p in self.optimizer.param_groups:
-            p['lr'] = rate
-        self._rate = rate
-        self.optimizer.step()
-
     def rate(self, step=None):
-        if step is None:
-            step = self._step
-        arg1 = step ** (-0.5)
-        arg2 = step * (self.warmup_steps ** -1.5)
-        return self.d_model ** (-0.5) * min(arg1, arg2)
+        n = self._step if step is None else step
+        decay = n ** (-0.5)
+        ramp = n * (self.warmup_steps ** -1.5)
+        return self.d_model ** (-0.5) * min(decay, ramp)
+
+    def step(self):
+        """advance the schedule, set every parameter group's lr, then take the optimiser step"""
+        self._step += 1
+        self._rate = lr = self.rate()
+        for group in self.optimizer.param_groups:
+            group['lr'] = lr
+        self.optimizer.step()

@@ -163,15 +163,18 @@ class EventSeq:
         events = [Event(names[t], tm, int(v)) for t, v, tm in zip(tid, val, time) if t >= 0]
         return EventSeq(events)
 
-    def __init__(self, events=[]):
-        for event in events:
-            assert isinstance(event, Event)
-        self.events = copy.deepcopy(events)
-        time = 0
-        for event in self.events:
-            event.time = time
-            if event.type == 'time_shift':
-                time += EventSeq.time_shift_bins[event.value]
+    def __init__(self, events=()):
+        """own copies of the events; an event's time is re-derived from the time_shift events before it
+        (sequence.py:222-233) by sequential accumulation, starting from integer 0 like the reference"""
+        source = list(events)
+        if not all(isinstance(ev, Event) for ev in source):
+            raise AssertionError("EventSeq takes Event objects")
+        clock = 0
+        self.events = []
+        for ev in source:
+            self.events.append(Event(ev.type, clock, copy.deepcopy(ev.value)))
+            if ev.type == 'time_shift':
+                clock = clock + EventSeq.time_shift_bins[ev.value]
 
     def to_array(self):
         """sequence.py:283-287"""
@@ -183,55 +186,57 @@ class EventSeq:
     # ---- notes <-> events (no MIDI library needed) ---------------------------------------------------
     @staticmethod
     def from_note_seq(note_seq):
-        """sequence.py:145-183"""
-        note_events = []
-        velocity_bins = EventSeq.get_velocity_bins()
-        for note in note_seq.notes:
-            if note.pitch in EventSeq.pitch_range:
-                if USE_VELOCITY:
-                    velocity = min(max(note.velocity, EventSeq.velocity_range.start), EventSeq.velocity_range.stop - 1)
-                    note_events.append(Event('velocity', note.start, int(np.searchsorted(velocity_bins, velocity))))
-                pitch_index = note.pitch - EventSeq.pitch_range.start
-                note_events.append(Event('note_on', note.start, pitch_index))
-                note_events.append(Event('note_off', note.end, pitch_index))
-        note_events.sort(key=lambda event: event.time)
-        events = []
-        for i, event in enumerate(note_events):
-            events.append(event)
-            if event is note_events[-1]:
+        """notes -> events (sequence.py:145-183): per in-range note a velocity bin (at the onset), note_on and note_off;
+        stable sort by time; between consecutive events the gap is covered greedily by the largest time_shift bins."""
+        vbins = EventSeq.get_velocity_bins()
+        v_lo, v_hi = EventSeq.velocity_range.start, EventSeq.velocity_range.stop - 1
+        first_pitch = EventSeq.pitch_range.start
+        timeline = []                                    # (time, type, value) in emission order
+        for n in note_seq.notes:
+            if n.pitch not in EventSeq.pitch_range:
+                continue
+            key = n.pitch - first_pitch
+            if USE_VELOCITY:
+                timeline.append((n.start, 'velocity', int(np.searchsorted(vbins, min(max(n.velocity, v_lo), v_hi)))))
+            timeline.append((n.start, 'note_on', key))
+            timeline.append((n.end, 'note_off', key))
+        timeline.sort(key=lambda item: item[0])          # stable, like the reference's list.sort on Event.time
+        bins = EventSeq.time_shift_bins
+        out = []
+        for pos, (t, kind, value) in enumerate(timeline):
+            out.append(Event(kind, t, value))
+            if pos + 1 == len(timeline):
                 break
-            interval = note_events[i + 1].time - event.time
-            shift = 0
-            while interval - shift >= EventSeq.time_shift_bins[0]:
-                index = int(np.searchsorted(EventSeq.time_shift_bins, interval - shift, side='right') - 1)
-                events.append(Event('time_shift', event.time + shift, index))
-                shift += EventSeq.time_shift_bins[index]
-        return EventSeq(events)
+            gap, used = timeline[pos + 1][0] - t, 0
+            while gap - used >= bins[0]:
+                j = int(np.searchsorted(bins, gap - used, side='right')) - 1
+                out.append(Event('time_shift', t + used, j))
+                used += bins[j]
+        return EventSeq(out)
 
     def to_note_seq(self):
-        """sequence.py:235-272"""
-        time = 0
+        """events -> notes (sequence.py:235-272): a clock advanced by time_shift, the current velocity bin, and the notes
+        still sounding per pitch; a note_off closes its pitch's note (at least MIN_NOTE_LENGTH long), notes never closed
+        last DEFAULT_NOTE_LENGTH."""
+        vbins = EventSeq.get_velocity_bins()
+        first_pitch = EventSeq.pitch_range.start
+        clock, velocity = 0, DEFAULT_VELOCITY
+        sounding = {}
         notes = []
-        velocity = DEFAULT_VELOCITY
-        velocity_bins = EventSeq.get_velocity_bins()
-        last_notes = {}
-        for event in self.events:
-            if event.type == 'note_on':
-                pitch = event.value + EventSeq.pitch_range.start
-                note = Note(velocity, pitch, time, None)
+        for ev in self.events:
+            kind = ev.type
+            if kind == 'time_shift':
+                clock += EventSeq.time_shift_bins[ev.value]
+            elif kind == 'velocity':
+                velocity = vbins[min(ev.value, vbins.size - 1)]
+            elif kind == 'note_on':
+                note = Note(velocity, ev.value + first_pitch, clock, None)
                 notes.append(note)
-                last_notes[pitch] = note
-            elif event.type == 'note_off':
-                pitch = event.value + EventSeq.pitch_range.start
-                if pitch in last_notes:
-                    note = last_notes[pitch]
-                    note.end = max(time, note.start + MIN_NOTE_LENGTH)
-                    del last_notes[pitch]
-            elif event.type == 'velocity':
-                index = min(event.value, velocity_bins.size - 1)
-                velocity = velocity_bins[index]
-            elif event.type == 'time_shift':
-                time += EventSeq.time_shift_bins[event.value]
+                sounding[note.pitch] = note
+            elif kind == 'note_off':
+                note = sounding.pop(ev.value + first_pitch, None)
+                if note is not None:
+                    note.end = max(clock, note.start + MIN_NOTE_LENGTH)
         for note in notes:
             if note.end is None:
                 note.end = note.start + DEFAULT_NOTE_LENGTH

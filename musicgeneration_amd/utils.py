@@ -6,57 +6,50 @@ import os
 import torch
 
 
-def find_files_by_extensions(root, exts=[]):
-    """utils.py:10-22"""
-    def _has_ext(name):
-        if not exts:
-            return True
-        name = name.lower()
-        return any(name.endswith(ext) for ext in exts)
-    for path, _, files in os.walk(root):
-        for name in files:
-            if _has_ext(name):
-                yield os.path.join(path, name)
+def find_files_by_extensions(root, exts=()):
+    """Every file below ``root`` whose lower-cased name ends with one of ``exts`` (all files when ``exts`` is empty), in
+    os.walk order -- the order the reference's 80/10/10 split depends on (utils.py:10-22, data.py:11-17)."""
+    wanted = tuple(exts)
+    for folder, _dirs, names in os.walk(root):
+        for name in names:
+            if not wanted or name.lower().endswith(wanted):
+                yield os.path.join(folder, name)
 
 
 def dict2params(d, f=','):
-    return f.join(f'{k}={v}' for k, v in d.items())
+    return f.join('{}={}'.format(k, v) for k, v in d.items())
 
 
 def params2dict(p, f=',', e='='):
-    """utils.py:38-47, with ast.literal_eval instead of the reference's eval()."""
+    """inverse of dict2params (utils.py:38-47); values go through ast.literal_eval, not the reference's eval()"""
     import ast
-    d = {}
-    for item in p.split(f):
-        item = item.split(e)
-        if len(item) < 2:
-            continue
-        k, *v = item
-        d[k] = ast.literal_eval('='.join(v))
-    return d
+    out = {}
+    for field in p.split(f):
+        key, sep, value = field.partition(e)
+        if sep:
+            out[key] = ast.literal_eval(value)
+    return out
 
 
 def sequence_mask(length, max_length=None):
-    """utils.py:183-188"""
-    if max_length is None:
-        max_length = length.max()
-    x = torch.arange(max_length, dtype=length.dtype, device=length.device)
-    return x.unsqueeze(0) < length.unsqueeze(1)
+    """[len(length), max_length] bool, row r true on columns < length[r]  (TensorFlow's sequence_mask; utils.py:183-188)"""
+    width = length.max() if max_length is None else max_length
+    cols = torch.arange(width, dtype=length.dtype, device=length.device)
+    return cols[None, :] < length[:, None]
 
 
 def get_masked_with_pad_tensor(size, src, trg, pad_token):
-    """utils.py:58-83: (src_mask, trg_mask, look_ahead_mask).  The kernels never materialise the
-    [B,1,L,L] mask (they use a key-padding bitmap + the causal structure); this helper exists for API
-    parity and for tests."""
-    src = src[:, None, None, :]
-    trg = trg[:, None, None, :]
-    src_pad_tensor = torch.ones_like(src) * pad_token
-    src_mask = torch.equal(src, src_pad_tensor)
-    trg_mask = torch.equal(src, src_pad_tensor)
-    dec_trg_mask = trg == torch.ones_like(trg) * pad_token
-    seq_mask = ~sequence_mask(torch.arange(1, size + 1).to(trg.device), size)
-    look_ahead_mask = dec_trg_mask | seq_mask
-    return src_mask, trg_mask, look_ahead_mask
+    """-> (src_mask, trg_mask, look_ahead_mask) as the reference returns them (utils.py:58-83): the first two are the
+    Python bools of its two whole-tensor ``torch.equal`` calls (both on ``src``), the third is the [B,1,size,size] mask
+    ``trg[b,j] == pad  or  j > i``.  The kernels never materialise that mask (key-padding bitmap + causal structure);
+    this helper exists for API parity, for the layer-level ``forward(x, mask)`` and for tests."""
+    all_pad = bool((src == pad_token).all().item()) if src.numel() else True
+    if trg is None:
+        return all_pad, None, None
+    key_is_pad = (trg == pad_token)[:, None, None, :]                      # [B,1,1,L]
+    i = torch.arange(size, device=trg.device)
+    future = i[None, :] > i[:, None]                                        # [size,size]: key j after query i
+    return all_pad, all_pad, key_is_pad | future[None, None]
 
 
 def event_indeces_to_midi_file(event_indeces, midi_file_name, velocity_scale=0.8):

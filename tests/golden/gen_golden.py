@@ -428,6 +428,28 @@ def gen_mt2():
     g11["grad_norms"] = np.array([float(v.grad.double().norm()) for v in named.values()])
     np.savez_compressed(os.path.join(HERE, "g11_model_d256.npz"), **g11)
 
+    # ---- G1c: RelativeGlobalAttention.forward at the kernels' head width (dh = 64): L == M and L < M -------------
+    import layers  # noqa
+    for tag, (B1, h1, L1, M1) in {"c": (2, 2, 32, 32), "d": (2, 2, 32, 64)}.items():
+        torch.manual_seed(5)
+        dd1 = 64 * h1
+        rga = layers.RelativeGlobalAttention(h=h1, d=dd1, max_seq=M1)
+        with torch.no_grad():
+            rga.E.mul_(0.3)
+        xg = (torch.randn(B1, L1, dd1) * 0.7).requires_grad_(True)
+        tok = torch.randint(0, 5, (B1, L1))
+        tok[0, -3:] = 4                                   # pretend 4 is pad: trailing key-padding columns
+        _, _, lam = utils.get_masked_with_pad_tensor(L1, tok, tok, 4)
+        out, aw = rga([xg, xg, xg], lam)
+        wsum = torch.linspace(0.5, 1.5, out.numel()).reshape(out.shape)
+        (out * wsum).sum().backward()
+        g1 = {"x": npy(xg), "tok": npy(tok), "mask": npy(lam), "out": npy(out), "weights": npy(aw), "wsum": npy(wsum),
+              "gx": npy(xg.grad), "gE": npy(rga.E.grad), "gWq": npy(rga.Wq.weight.grad), "gfcb": npy(rga.fc.bias.grad),
+              "shape": np.array([B1, h1, L1, M1])}
+        for k, v in rga.state_dict().items():
+            g1["p." + k] = npy(v)
+        np.savez_compressed(os.path.join(HERE, f"g1{tag}_rga_dh64.npz"), **g1)
+
     # ---- G10a: Data feeder (MusicTransformer/data.py) on the synthetic corpus -----------------------------
     _legacy_torch_load()
     with tempfile.TemporaryDirectory() as root:

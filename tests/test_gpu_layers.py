@@ -1,0 +1,101 @@
+"""The reference's layer-level call surface on the kernels: ``rga([q,k,v], mask)`` (layers.py:64-109),
+``EncoderLayer(x, mask)`` (:152-161), ``Encoder(x, mask)`` (:223-233).
+G1c / G1d are outputs of the reference's own RelativeGlobalAttention at the kernels' head width (dh = 64), for
+L == M and L < M (tests/golden/gen_golden.py mt2).  Tolerances (bf16 operands, fp32 accumulation, against an fp32
+reference): output rel-L2 <= 2e-2, attention weights |err| <= 1.5e-2, gradient cosine >= 0.99."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a, b = a.float().flatten().cpu(), b.float().flatten().cpu()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def _rel(a, b):
+    a, b = a.float().flatten().cpu(), b.float().flatten().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("tag", ["c", "d"])
+def test_g1_rga_forward_matches_reference(golden_dir, tag):
+    from musicgeneration_amd.layers import RelativeGlobalAttention
+    g = dict(np.load(os.path.join(golden_dir, f"g1{tag}_rga_dh64.npz")))
+    B, h, L, M = (int(v) for v in g["shape"])
+    rga = RelativeGlobalAttention(h=h, d=64 * h, max_seq=M)
+    rga.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}, strict=True)
+    rga = rga.cuda()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    mask = torch.from_numpy(g["mask"]).cuda()
+    out, w = rga([x, x, x], mask)
+    assert out.dtype == x.dtype and out.shape == (B, L, 64 * h) and w.shape == (B, h, L, L)
+    assert _rel(out, torch.from_numpy(g["out"])) <= 2e-2
+    assert (w.cpu() - torch.from_numpy(g["weights"])).abs().max().item() <= 1.5e-2
+    (out * torch.from_numpy(g["wsum"]).cuda()).sum().backward()
+    assert _cos(x.grad, torch.from_numpy(g["gx"])) >= 0.99
+    assert _cos(rga.E.grad, torch.from_numpy(g["gE"])) >= 0.99
+    assert _cos(rga.Wq.weight.grad, torch.from_numpy(g["gWq"])) >= 0.99
+    assert _cos(rga.fc.bias.grad, torch.from_numpy(g["gfcb"])) >= 0.999
+    # rows of E above the L rows in use receive no gradient (layers.py:111-114)
+    assert rga.E.grad[: M - L].abs().max().item() == 0.0 if M > L else True
+    # separate q / k / v tensors take the three-projection route and give the same result
+    out2, _ = rga([x.detach(), x.detach().clone(), x.detach().clone()], mask)
+    assert _rel(out2, out.detach()) <= 1e-2
+
+
+def test_layer_forward_mask_contract():
+    from musicgeneration_amd.layers import RelativeGlobalAttention
+    rga = RelativeGlobalAttention(h=2, d=128, max_seq=32).cuda()
+    x = torch.randn(1, 32, 128, device="cuda")
+    with pytest.raises(NotImplementedError, match="bidirectional"):
+        rga([x, x, x], None)
+    full = torch.zeros(1, 1, 32, 32, dtype=torch.bool, device="cuda")          # nothing masked = not causal
+    with pytest.raises(ValueError, match="look-ahead"):
+        rga([x, x, x], full)
+    with pytest.raises(ValueError):
+        rga([x[:, :20], x[:, :20], x[:, :20]], full[..., :20, :20])            # L % 32 != 0
+
+
+def test_encoder_and_layer_forward_match_oracle():
+    """Encoder.forward(tokens, mask) and EncoderLayer.forward(x, mask) stand-alone (ordinary autograd), against the
+    oracle's restatement of layers.py:152-161,223-233 (pinned by G2 in tests/test_oracle_golden.py)."""
+    from musicgeneration_amd.layers import Encoder
+    from musicgeneration_amd import utils
+    from oracle import ref_cpu as R
+    V, d, nl, L, B = 90, 128, 2, 64, 2
+    pad = V - 1
+    p = R.init_params(V, d, nl, L, seed=2)
+    for k in p:
+        if k.endswith("embedding.weight") or k.endswith("rga.E"):
+            p[k] = p[k] * 0.3
+    enc = Encoder(num_layers=nl, d_model=d, input_vocab_size=V, rate=0.0, max_len=L)
+    enc.load_state_dict({k[len("Decoder."):]: v for k, v in p.items() if k.startswith("Decoder.")}, strict=True)
+    enc = enc.cuda().train()
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randint(0, V - 1, (B, L), generator=g)
+    tok[1, -7:] = pad
+    _, _, lam = utils.get_masked_with_pad_tensor(L, tok, tok, pad)
+    hid, ws = enc(tok.cuda(), lam.cuda())
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref, wref = R.decoder_stack(pr, tok, R.look_ahead_mask(tok, pad))
+    assert hid.dtype == torch.float32 and len(ws) == nl
+    assert _rel(hid, ref.detach()) <= 2e-2
+    assert (ws[1].cpu() - wref[1].detach()).abs().max().item() <= 2e-2
+    wsum = torch.linspace(-1, 1, hid.numel()).reshape(hid.shape)
+    (hid * wsum.cuda()).sum().backward()
+    (ref * wsum).sum().backward()
+    for name in ("embedding.weight", "enc_layers.0.rga.E", "enc_layers.1.FFN_pre.weight", "enc_layers.0.layernorm1.weight",
+                 "enc_layers.1.rga.fc.bias"):
+        got = dict(enc.named_parameters())[name].grad
+        assert _cos(got, pr["Decoder." + name].grad) >= 0.99, name
+    # one layer on its own
+    x = (torch.randn(B, L, d, generator=g) * 0.5)
+    out, w = enc.enc_layers[0](x.cuda(), lam.cuda())
+    o_ref, _ = R.encoder_layer({k: v.detach() for k, v in p.items()}, "Decoder.enc_layers.0.", x, R.look_ahead_mask(tok, pad),
+                               d // 64, 0.0, False)
+    assert _rel(out, o_ref) <= 2e-2
