@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-decode", action="store_true", help="skip the cfg5 decode block (N=1 only)")
+    ap.add_argument("--decode-len", type=int, default=8192)
+    ap.add_argument("--decode-batch", type=int, default=32)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "rehearsing the data-parallel path with several ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks use cuda:0 (rehearsal with --backend gloo)")
@@ -86,75 +89,132 @@ def time_kernels(B, L, d, M, reps=10):
     ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, ws)
     torch.cuda.synchronize()
 
-    def timed(fn):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    out = {"rel_attn_fwd_kernel": timed(lambda: ops.rel_attn_fwd(qkv, E, None))}
+    # The four kernels are timed the way a layer runs them -- interleaved, one after the other -- not as ten back-to-back
+    # launches of the same MFMA-dense kernel (the chip then holds a lower clock than inside the training step and the
+    # per-kernel times read 15-30 % long against the rocprofv3 trace of the step).
+    calls = [("rel_attn_fwd_kernel", lambda: ops.rel_attn_fwd(qkv, E, None))]
     # parts bits of mgx_rel_attn_bwd_parts; the dE kernel streams the dS tiles the dQ kernel left in `ws`
-    # (the dQ entry is timed as the real call runs it: with the E-transpose pre-pass and computing delta itself)
+    # (the dQ entry is timed as the real call runs it: with the E re-layout pre-pass and computing delta itself)
     for name, bit in (("rel_attn_dq_kernel", 1 | 2), ("rel_attn_dkv_kernel", 4), ("rel_attn_de_stream_kernel", 8)):
-        out[name] = timed(lambda bit=bit: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, bit, dqkv, ws))
+        calls.append((name, lambda bit=bit: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, bit, dqkv, ws)))
+    for _, fn in calls:
+        fn()
+    evs = {name: [] for name, _ in calls}
+    for _ in range(reps):
+        for name, fn in calls:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            evs[name].append((e0, e1))
+    torch.cuda.synchronize()
+    out = {name: sum(a.elapsed_time(b) for a, b in pairs) / len(pairs) for name, pairs in evs.items()}
     return out
 
 
-def cpu_baseline(args):
-    """The oracle's eager-PyTorch fp32 CPU restatement of the same training step (reference semantics:
-    materialised L x L attention, dropout 0.2, Adam + Noam), bounded to ~10-30 s of CPU work."""
-    from oracle import ref_cpu as R
-    # a 1-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
+def _cpu_model():
     try:
-        avail = len(os.sched_getaffinity(0))
-    except Exception:
-        avail = os.cpu_count() or 1
-    ncores = max(1, min(16, avail))
-    torch.set_num_threads(ncores)
-    V, d, nl, L = args.vocab, args.d_model, args.layers, args.seq_len
-    Bc = args.cpu_batch
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def _time_cpu_trainer(V, d, nl, L, Bc, dropout, seconds, max_steps):
+    from oracle import ref_cpu as R
     p = R.init_params(V, d, nl, L, seed=0)
-    tr = R.CpuTrainer(p, pad=V - 1, d_cfg=d, dropout=args.dropout, accum=1)
+    tr = R.CpuTrainer(p, pad=V - 1, d_cfg=d, dropout=dropout, accum=1)
     gen = torch.Generator().manual_seed(1234)
     nsteps, t_used = 0, 0.0
-    while nsteps < 1 or (t_used < args.cpu_seconds and nsteps < 3):
+    while nsteps < 1 or (t_used < seconds and nsteps < max_steps):
         xf = torch.randint(0, V - 1, (Bc, L + 1), generator=gen)
         t0 = time.time()
         tr.step(xf[:, :-1].to(torch.int32), xf[:, 1:].to(torch.int32))
         t_used += time.time() - t0
         nsteps += 1
-    return {"value": Bc * L * nsteps / t_used, "unit": "events/s", "cores": ncores, "kind": "port",
-            "sample": f"{nsteps} step(s) of the same cfg2 training step at batch {Bc} x L {L} "
-                      f"(oracle/ref_cpu.py CpuTrainer, eager PyTorch fp32, {ncores} threads, {t_used:.1f} s)"}
+    return Bc * L * nsteps / t_used, nsteps, t_used
 
 
-def pmc_traffic(dom, B, L, d):
-    """HBM bytes per launch of the dominant op from the committed PMC passes (tools/traffic.sh: separate
+def cpu_baseline(args):
+    """The oracle's eager-PyTorch fp32 CPU restatement of the same training step (reference semantics:
+    materialised L x L attention, dropout 0.2, Adam + Noam), bounded to ~10-30 s of CPU work: the bench workload
+    (cfg2) at batch 2, and BASELINE cfg1 (the reference's own CPU-runnable case: MIDI-like V=309, 2 layers, d=256,
+    L=512, batch 8) beside it."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    # threads: a 1-GPU box is handed a 16-core share of its host (gpurun: "size worker pools to the box's CPU share (16
+    # for one GPU)"); more threads than that share only oversubscribe it and slow the eager ops down
+    ncores = max(1, min(16, avail))
+    torch.set_num_threads(ncores)
+    V, d, nl, L = args.vocab, args.d_model, args.layers, args.seq_len
+    Bc = args.cpu_batch
+    v2, n2, t2 = _time_cpu_trainer(V, d, nl, L, Bc, args.dropout, args.cpu_seconds, 3)
+    v1, n1, t1 = _time_cpu_trainer(309, 256, 2, 512, 8, args.dropout, 4.0, 20)
+    return {"value": v2, "unit": "events/s", "cores": ncores, "kind": "port", "cpu_model": _cpu_model(),
+            "host_cpus_visible": avail,
+            "sample": f"{n2} step(s) of the same cfg2 training step at batch {Bc} x L {L} "
+                      f"(oracle/ref_cpu.py CpuTrainer, eager PyTorch fp32, {ncores} threads, {t2:.1f} s)",
+            "cfg1": {"value": v1, "unit": "events/s",
+                     "sample": f"{n1} step(s) of BASELINE cfg1 (V=309, 2 layers, d=256, L=512, batch 8, fp32) in {t1:.1f} s, "
+                               f"{ncores} threads"}}
+
+
+def decode_bench(args):
+    """BASELINE cfg5: autoregressive sampling to seq_len 8192 at batch 32, top-p 0.9, hipGraph-captured KV-cache decode
+    (prior length 1, cfg2-shaped model).  HBM-bound: per step the K and V caches of every layer are read once."""
+    from musicgeneration_amd.network import MusicTransformer
+    Ld, Bd, d, nl, V = args.decode_len, args.decode_batch, args.d_model, args.layers, args.vocab
+    torch.manual_seed(0)
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=Ld, dropout=0.0).cuda().eval()
+    prior = torch.randint(0, V - 1, (Bd, 1), device="cuda")
+    mt.generate_cached(prior, 64, top_p=0.9, seed=1)          # warm-up (graph capture path)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = mt.generate_cached(prior, Ld - 1, top_p=0.9, seed=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = Ld - 1
+    assert out.shape == (Bd, Ld) and int(out.max()) < V
+    kv_bytes = nl * 2 * Bd * d * 2 * (steps * (steps + 1) / 2)          # K and V rows read over the whole run
+    w_bytes = steps * 2 * sum(p.numel() for p in mt.parameters())       # bf16 weights once per step
+    last_step_bytes = nl * 2 * Bd * d * 2 * Ld + 2 * sum(p.numel() for p in mt.parameters())
+    return {"workload": f"cfg5: sampling to seq_len {Ld}, batch {Bd}, top-p 0.9, graph-captured KV-cache decode, "
+                        f"V={V} layers={nl} d_model={d}",
+            "tokens_per_s": Bd * steps / dt, "ms_per_step": 1e3 * dt / steps, "seconds": dt,
+            "algorithmic_bytes_per_step_mean": (kv_bytes + w_bytes) / steps,
+            "algorithmic_bytes_last_step": last_step_bytes,
+            "achieved_gbs": (kv_bytes + w_bytes) / dt / 1e9, "peak_gbs": PEAK_HBM_GBS,
+            "frac": (kv_bytes + w_bytes) / dt / 1e9 / PEAK_HBM_GBS, "bound": "hbm"}
+
+
+def pmc_traffic(kernel, B, L, d):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
     Only reported when this run has the shape the counters were collected on (cfg2, per-GPU batch 32)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic_cfg2_b32.json")
-    if not os.path.exists(path) or (B, L, d) != (32, 2048, 512):
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((os.path.join(prof, f) for f in ("r02_traffic_cfg2_b32.json", "r01_traffic_cfg2_b32.json")
+                 if os.path.exists(os.path.join(prof, f))), None)
+    if path is None or (B, L, d) != (32, 2048, 512):
         return {"traffic": None}
     k = json.load(open(path))["kernels"]
-    names = (["er_transpose_kernel", "void rel_attn_dq_kernel<true, true>", "rel_attn_dkv_kernel", "rel_attn_de_stream_kernel"]
-             if dom.startswith("mgx_rel_attn_bwd") else ["void rel_attn_fwd_kernel<false>"])
-    if any(n not in k for n in names):
+    match = [n for n in k if kernel in n]
+    if not match:
         return {"traffic": None}
-    tr = sum(k[n]["hbm_bytes_per_launch"] for n in names)
-    # algorithmic bytes: bf16 Q,K,V,O(,dO) in + O (or dQ,dK,dV) out, E and dE are 256 KiB and ignored.  (The backward
-    # additionally moves the dS tiles through HBM by design: 2 x B*h*L*L/2 * 2 bytes, see DESIGN.md)
-    nbuf = 8 if dom.startswith("mgx_rel_attn_bwd") else 4
-    out = {"traffic": tr, "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_cfg2_b32.json)",
-           "algorithmic_bytes_per_launch": nbuf * B * L * d * 2}
-    if dom.startswith("mgx_rel_attn_bwd"):
-        # deliberate: the dQ kernel stores the bf16 dS tiles (causal half) and the dE kernel streams them back, instead
-        # of recomputing S/P/dP a third time (DESIGN.md 2.2)
-        out["traffic_by_design_ds_roundtrip"] = 2 * (B * (d // 64) * L * L // 2) * 2
-    return out
+    heads = d // 64
+    ds_half = B * heads * (L // 32) * (L // 32 + 1) // 2 * 2048          # causal half of dS, bf16 32x32 tiles
+    io = B * L * d * 2                                                   # one bf16 [B,L,d] tensor
+    algo = {"rel_attn_fwd_kernel": 4 * io,                               # q,k,v in, ctx out
+            "rel_attn_dq_kernel": 6 * io + ds_half,                      # q,k,v,dO,O in, dq out + the dS export (by design)
+            "rel_attn_dkv_kernel": 6 * io,                               # q,k,v,dO in, dk,dv out
+            "rel_attn_de_stream_kernel": io + ds_half}[kernel]           # q in, dS in
+    tr = sum(k[n]["hbm_bytes_per_launch"] for n in match)
+    return {"traffic": tr, "traffic_unit": f"bytes/launch (PMC, {os.path.basename(path)})",
+            "algorithmic_bytes_per_launch": algo}
 
 
 def _free_port():
@@ -308,25 +368,36 @@ def main():
         per_kernel = {k: {"ms": kt[k], "credited_tflops": attn_flops_per_launch(B, L, d, credited[k]) / (kt[k] * 1e-3) / 1e12,
                           "executed_tflops": attn_flops_per_launch(B, L, d, executed[k]) / (kt[k] * 1e-3) / 1e12}
                       for k in credited}
-        # the dominant launch of the step is the attention backward (ONE C-ABI call, mgx_rel_attn_bwd =
-        # delta/transposed-E pre-pass + dQ + dK/dV + dE kernels): 6 credited units per launch
+        # roofline: the single dominant KERNEL of the step by time (6 launches per step each).  Credited units are the
+        # algorithmic share of the products it computes (no credit for recomputing S/P/dP or for the second Q.Er^T
+        # chunk); executed units count every MFMA product it runs.  The op it belongs to (ONE C-ABI call,
+        # mgx_rel_attn_bwd = E re-layout + dQ + dK/dV + dE kernels, 6 credited units) is reported beside it.
+        kernel_symbol = {"rel_attn_fwd_kernel": "rel_attn_fwd_kernel<false>", "rel_attn_dq_kernel": "rel_attn_dq_kernel<true, true>",
+                         "rel_attn_dkv_kernel": "rel_attn_dkv_kernel", "rel_attn_de_stream_kernel": "rel_attn_de_stream_kernel"}
+        dom_k = max(kt, key=lambda k: kt[k])
+        dom_ms = kt[dom_k]
+        ach = attn_flops_per_launch(B, L, d, credited[dom_k]) / (dom_ms * 1e-3) / 1e12
+        exe = attn_flops_per_launch(B, L, d, executed[dom_k]) / (dom_ms * 1e-3) / 1e12
         bwd_ms = kt["rel_attn_dq_kernel"] + kt["rel_attn_dkv_kernel"] + kt["rel_attn_de_stream_kernel"]
-        fwd_ms = kt["rel_attn_fwd_kernel"]
-        dom, dom_ms, dom_units, dom_exec = (("mgx_rel_attn_bwd (E transpose + dq + dkv + de kernels)", bwd_ms, 6.0, 12.0)
-                                            if bwd_ms >= fwd_ms else ("rel_attn_fwd_kernel", fwd_ms, 3.0, 3.0))
-        ach = attn_flops_per_launch(B, L, d, dom_units) / (dom_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
+        out["roofline"] = {"bound": "mfma", "kernel": kernel_symbol[dom_k], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                           "launch_ms": dom_ms, "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, dom_units),
-                           "executed_tflops": attn_flops_per_launch(B, L, d, dom_exec) / (dom_ms * 1e-3) / 1e12,
-                           "executed_frac": attn_flops_per_launch(B, L, d, dom_exec) / (dom_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
-        out["roofline"].update(pmc_traffic(dom, B, L, d))
+                           "launch_ms": dom_ms, "credited_units": credited[dom_k], "executed_units": executed[dom_k],
+                           "unit_flops": attn_flops_per_launch(B, L, d, 1.0),
+                           "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, credited[dom_k]),
+                           "executed_tflops": exe, "executed_frac": exe / PEAK_BF16_TFLOPS,
+                           "op": {"name": "mgx_rel_attn_bwd (E re-layout + dq + dkv + de kernels)", "launch_ms": bwd_ms,
+                                  "credited_units": 6.0, "executed_units": 12.0,
+                                  "achieved": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12,
+                                  "frac": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}}
+        out["roofline"].update(pmc_traffic(dom_k, B, L, d))
         out["kernel_ms"] = kt
         out["attention_kernels"] = per_kernel
         out["attention_all_kernels"] = {
             "ms_per_layer": sum(kt.values()),
             "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12,
             "executed_tflops": attn_flops_per_launch(B, L, d, 15.0) / (sum(kt.values()) * 1e-3) / 1e12}
+    if rank == 0 and world == 1 and not args.no_decode:
+        out["decode"] = decode_bench(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

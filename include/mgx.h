@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace */
-#define MGX_ABI_VERSION 8
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K) */
+#define MGX_ABI_VERSION 9
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -79,8 +79,9 @@ int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t*
 /* backward of the above (autograd of layers.py:86-106).  dctx bf16 [B,L,d] -> dqkv bf16 [B,L,3d];
  * dE f32 [M,64] is ACCUMULATED into (caller zeroes it once per optimiser step).
  * workspace: caller-provided scratch, 256-byte aligned, >= mgx_rel_attn_bwd_workspace(B,L,d) bytes
- * (rowsum(dctx*ctx) [B,h,L] f32, a transposed bf16 copy of E, and dS by (query, relative distance)
- * bf16 [B,h,L,L] that the dQ kernel leaves for the dE kernel -- 2*B*h*L*L bytes, 1.07 GB at cfg2/B=16). */
+ * (rowsum(dctx*ctx) [B,h,L] f32, two lane-ordered bf16 copies of E, and the causal half of dS by (query, relative
+ * distance) in 32x32 bf16 tiles that the dQ kernel leaves for the dE kernel -- B*h*(L/32)(L/32+1)/2 * 2 KB,
+ * 0.55 GB at cfg2/B=16). */
 size_t mgx_rel_attn_bwd_workspace(int B, int L, int d);
 int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                      const uint16_t* ctx, const uint16_t* dctx, const float* lse,
@@ -178,8 +179,12 @@ int mgx_decode_embed(const int32_t* tok, const float* table, const float* pe, co
 /* qkv_new bf16 [B,3d] (projection of the token at position t): k_t, v_t are appended to
  * kcache/vcache bf16 [B,Lmax,d] at row t, then ctx bf16 [B,d] = softmax_j((q.k_j + q.E[M-1-(t-j)])/8) v_j
  * over j = 0..t.  t < Lmax <= M.                                                                      */
+/* Long caches are split over several workgroups per (b,h) whose partial results a second kernel merges: workspace =
+ * caller scratch >= mgx_rel_attn_decode_workspace(B, Lmax, d) bytes (0 for short caches: NULL is accepted then).      */
+size_t mgx_rel_attn_decode_workspace(int B, int Lmax, int d);
 int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, uint16_t* vcache, const uint16_t* E,
-                        const int32_t* pos_dev, uint16_t* ctx, int B, int Lmax, int d, int M, void* stream);
+                        const int32_t* pos_dev, uint16_t* ctx, void* workspace, size_t ws_bytes,
+                        int B, int Lmax, int d, int M, void* stream);
 /* logits bf16 [B,ld] -> next_tok int32 [B] drawn from softmax(logits/temperature) restricted to the top_k
  * most likely ids (0 = all) and then to the smallest set whose mass reaches top_p (1 = all).
  * out_tokens int32 [B,out_ld] (or NULL): column t+1 receives the token; probs_out f32 [B,V] (or NULL)

@@ -35,41 +35,55 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const int32_t* __rest
     *(u32x4*)(out + (size_t)r * d + c) = pack8(f);
 }
 
-// One workgroup (8 waves) per (batch, head).  lane = (key slot ks = lane>>3, dim group dg = lane&7): a wave
+// One workgroup (8 waves) per (batch, head, key split).  lane = (key slot ks = lane>>3, dim group dg = lane&7): a wave
 // handles 8 keys per iteration, each lane 8 of the 64 dims (16-byte loads: a key row is one 128-byte line).
 // Every (wave, key slot) runs its own online softmax stream; the 64 streams are merged at the end.
+// Split-K: with one workgroup per (b,h) a batch-32, 8-head decode step has 256 workgroups = 8 waves per CU, and the
+// bytes those waves keep in flight bound the cache stream at ~4.3 TB/s.  NSPLIT workgroups per (b,h) each take a
+// contiguous, 64-key aligned share of the keys 0..t (balanced from the device-side position), write an unnormalised
+// partial (m, l, acc[64]) and a tiny second kernel merges them by their maxima.  The new row t is taken from qkv_new by
+// whichever split covers it (another workgroup appends it to the cache in the same launch).
 constexpr int DEC_WAVES = 8;
+constexpr int DEC_PART = 66;                                   // floats per partial: m, l, acc[64]
 __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
     const uint16_t* __restrict__ qkv_new, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
-    const uint16_t* __restrict__ E, const int32_t* __restrict__ pos_dev, uint16_t* __restrict__ ctx, int Lmax, int d,
-    int M) {
+    const uint16_t* __restrict__ E, const int32_t* __restrict__ pos_dev, uint16_t* __restrict__ ctx,
+    float* __restrict__ partial, int Lmax, int d, int M) {
     const int heads = d >> 6;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int nsplit = gridDim.y, sp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ks = lane >> 3, dg = lane & 7;
     const int t = pos_dev[0];                                   // current position; keys 0..t
     const uint16_t* qrow = qkv_new + (size_t)b * 3 * d + hd * 64;
     uint16_t* kc = kcache + (size_t)b * Lmax * d + hd * 64;
     uint16_t* vc = vcache + (size_t)b * Lmax * d + hd * 64;
-    // append this step's key/value (each workgroup owns its head's 64 columns)
-    if (tid < 8) *(u32x4*)(kc + (size_t)t * d + tid * 8) = *(const u32x4*)(qrow + d + tid * 8);
-    else if (tid < 16) *(u32x4*)(vc + (size_t)t * d + (tid - 8) * 8) = *(const u32x4*)(qrow + 2 * d + (tid - 8) * 8);
+    // append this step's key/value for the following steps (split 0 of each head owns the head's 64 columns); in THIS
+    // step row t is read from qkv_new, so no workgroup depends on another one's store
+    if (sp == 0) {
+        if (tid < 8) *(u32x4*)(kc + (size_t)t * d + tid * 8) = *(const u32x4*)(qrow + d + tid * 8);
+        else if (tid < 16) *(u32x4*)(vc + (size_t)t * d + (tid - 8) * 8) = *(const u32x4*)(qrow + 2 * d + (tid - 8) * 8);
+    }
     float q[8];
     unpack8(*(const u32x4*)(qrow + dg * 8), q);
 #pragma unroll
     for (int k = 0; k < 8; ++k) q[k] *= 0.125f * LOG2E;         // logits in log2 units
-    __syncthreads();                                            // the appended row is visible to this workgroup
+    // this split's keys: [lo, hi), shares of ceil((t+1)/nsplit) keys rounded up to the workgroup's 64-key stride
+    const int share = ((t + nsplit) / nsplit + 63) & ~63;
+    const int lo = sp * share, hi = min(t + 1, lo + share);
 
     float m = -INFINITY, l = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint16_t* Eb = E + (size_t)(M - 1 - t) * 64;           // E row of key j is Eb + j*64
-    for (int j0 = (w * 8); j0 <= t; j0 += DEC_WAVES * 8) {
+    for (int j0 = lo + (w * 8); j0 < hi; j0 += DEC_WAVES * 8) {
         const int j = j0 + ks;
-        const bool valid = j <= t;
-        const int jc = valid ? j : t;
+        const bool valid = j < hi;
+        const int jc = valid ? j : hi - 1;
+        const uint16_t* kp = (jc == t) ? qrow + d : kc + (size_t)jc * d;
+        const uint16_t* vp = (jc == t) ? qrow + 2 * d : vc + (size_t)jc * d;
         float kf[8], ef[8], vf[8];
-        unpack8(*(const u32x4*)(kc + (size_t)jc * d + dg * 8), kf);
+        unpack8(*(const u32x4*)(kp + dg * 8), kf);
         unpack8(*(const u32x4*)(Eb + (size_t)jc * 64 + dg * 8), ef);
-        unpack8(*(const u32x4*)(vc + (size_t)jc * d + dg * 8), vf);
+        unpack8(*(const u32x4*)(vp + dg * 8), vf);
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += q[k] * (kf[k] + ef[k]);
@@ -88,11 +102,11 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
     // merge the 8 key slots of the wave (lanes with equal dg), then the 8 waves through LDS
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
-        const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+        const float mo = __shfl_xor(m, o, 64), lo2 = __shfl_xor(l, o, 64);
         const float mn = fmaxf(m, mo);
         const float a0 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
         const float a1 = (mo == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mo - mn);
-        l = l * a0 + lo * a1;
+        l = l * a0 + lo2 * a1;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = acc[k] * a0 + __shfl_xor(acc[k], o, 64) * a1;
         m = mn;
@@ -115,8 +129,32 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
             ll += sl[i] * a;
             o += sacc[i][tid] * a;
         }
-        ctx[(size_t)b * d + hd * 64 + tid] = f32_to_bf16(o / ll);
+        if (nsplit == 1) {
+            ctx[(size_t)b * d + hd * 64 + tid] = f32_to_bf16(o / ll);
+        } else {                                                // an empty split leaves (m = -inf, l = 0, acc = 0)
+            float* pp = partial + ((size_t)blockIdx.x * nsplit + sp) * DEC_PART;
+            if (tid == 0) { pp[0] = mm; pp[1] = ll; }
+            pp[2 + tid] = o;
+        }
     }
+}
+
+// ctx[b, hd*64 + c] = sum_s acc_s[c] 2^(m_s - m) / sum_s l_s 2^(m_s - m): one wave per (b,h)
+__global__ __launch_bounds__(64) void rel_attn_decode_merge_kernel(const float* __restrict__ partial, uint16_t* __restrict__ ctx,
+                                                                   int nsplit, int d) {
+    const int heads = d >> 6;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = threadIdx.x;
+    const float* pp = partial + (size_t)blockIdx.x * nsplit * DEC_PART;
+    float mm = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, pp[s * DEC_PART]);
+    float ll = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = pp[s * DEC_PART];
+        const float a = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - mm);
+        ll += pp[s * DEC_PART + 1] * a;
+        o += pp[s * DEC_PART + 2 + c] * a;
+    }
+    ctx[(size_t)b * d + hd * 64 + c] = f32_to_bf16(o / ll);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -262,13 +300,37 @@ extern "C" int mgx_decode_embed(const int32_t* tok, const float* table, const fl
     return MGX_OK;
 }
 
+// key splits per (b,h): enough workgroups to keep ~4 per CU (32 waves) streaming once the cache is long; short caches
+// keep one workgroup (the merge launch would cost more than it saves)
+static int decode_splits(int B, int Lmax, int d) {
+    const int wgs = B * (d / 64);
+    if (Lmax < 1024) return 1;
+    int s = 1;
+    while (s < 8 && wgs * s < 1024 && Lmax / (2 * s) >= 512) s *= 2;
+    return s;
+}
+
+extern "C" size_t mgx_rel_attn_decode_workspace(int B, int Lmax, int d) {
+    if (B <= 0 || d <= 0 || Lmax <= 0) return 0;
+    const int s = decode_splits(B, Lmax, d);
+    return s == 1 ? 0 : (size_t)B * (d / 64) * s * DEC_PART * sizeof(float);
+}
+
 extern "C" int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, uint16_t* vcache, const uint16_t* E,
-                                   const int32_t* pos_dev, uint16_t* ctx, int B, int Lmax, int d, int M, void* stream) {
+                                   const int32_t* pos_dev, uint16_t* ctx, void* workspace, size_t ws_bytes, int B, int Lmax,
+                                   int d, int M, void* stream) {
     MGX_REQUIRE(qkv_new && kcache && vcache && E && pos_dev && ctx, MGX_ERR_NULL, "mgx_rel_attn_decode: NULL pointer");
     MGX_REQUIRE(B > 0 && d > 0 && d % 64 == 0 && Lmax > 0 && M >= Lmax, MGX_ERR_SHAPE,
                 "mgx_rel_attn_decode: need d%%64==0 and M>=Lmax (B=%d Lmax=%d d=%d M=%d)", B, Lmax, d, M);
-    hipLaunchKernelGGL(rel_attn_decode_kernel, dim3(B * (d / 64)), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream, qkv_new,
-                       kcache, vcache, E, pos_dev, ctx, Lmax, d, M);
+    const int ns = decode_splits(B, Lmax, d);
+    MGX_REQUIRE(ns == 1 || (workspace && ws_bytes >= mgx_rel_attn_decode_workspace(B, Lmax, d)), MGX_ERR_SHAPE,
+                "mgx_rel_attn_decode: workspace must hold mgx_rel_attn_decode_workspace() = %zu bytes (got %zu)",
+                mgx_rel_attn_decode_workspace(B, Lmax, d), ws_bytes);
+    hipLaunchKernelGGL(rel_attn_decode_kernel, dim3(B * (d / 64), ns), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream, qkv_new,
+                       kcache, vcache, E, pos_dev, ctx, (float*)workspace, Lmax, d, M);
+    if (ns > 1)
+        hipLaunchKernelGGL(rel_attn_decode_merge_kernel, dim3(B * (d / 64)), dim3(64), 0, (hipStream_t)stream,
+                           (const float*)workspace, ctx, ns, d);
     MGX_CHECK_LAUNCH("mgx_rel_attn_decode");
     return MGX_OK;
 }

@@ -262,18 +262,15 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(q0 - 1, ks);    // new chunk of step 0
     }
     f32x16 dq0 = zero16(), dq1 = zero16();
-    // dS by (query, relative distance) for the dE kernel, tile-blocked: tile (b,h, query block i0/32, chunk q) is 2 KB at
-    // ((bh*nchunk + i0/32)*nchunk + q)*1024 elements; inside, the 16-byte unit of (row a, columns 16ks+8hh..+7) sits at
-    // ks*512 + a*16 + hh*8 elements -- each wave store instruction below writes 1 KB contiguously.
+    // dS by (query, relative distance) for the dE kernel, tile-blocked and PACKED to the causal half: query block I = i0/32
+    // only has chunks q <= I, so tile (b,h, I, q) is 2 KB at ((bh*T + I(I+1)/2 + q)*1024 elements, T = nchunk(nchunk+1)/2
+    // (half the memory of a full [I][q] grid; the consumer treats q > I as zeros).  Inside a tile the 16-byte unit of
+    // (row a, columns 16ks+8hh..+7) sits at ks*512 + a*16 + hh*8 elements -- each wave store instruction writes 1 KB
+    // contiguously.
     uint16_t* dsp = nullptr;
-    if (EXPORT_DS) {   // chunks above the diagonal chunk inside this 128-row block read as zeros downstream
-        dsp = dsrel + (((size_t)b * heads + hd) * nchunk + (i0 >> 5)) * nchunk * 1024 + a * 16 + hh * 8;
-        if (wave_on) {
-            for (int q = q0 + 1; q < min(Q0 + 4, nchunk); ++q) {
-                *(u32x4*)(dsp + (size_t)q * 1024) = u32x4{0, 0, 0, 0};
-                *(u32x4*)(dsp + (size_t)q * 1024 + 512) = u32x4{0, 0, 0, 0};
-            }
-        }
+    if (EXPORT_DS) {
+        const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
+        dsp = dsrel + (((size_t)b * heads + hd) * ntri + (size_t)q0 * (q0 + 1) / 2) * 1024 + a * 16 + hh * 8;
     }
     const int am = a - 4 * hh;                           // key crow(r,hh) is in the future of query a  <=>  crow(r,0) > am
 
@@ -879,30 +876,38 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
     // = (ks, row a, half hh) as the dQ kernel wrote them.  q: rows of 128 B (8 lanes x 16 B).
     const int nchunk = L >> 5;
     const int qrow = tid >> 3, qch = tid & 7;              // rows qrow + 32 i
-    int a_src[4], a_dst[4];
+    int a_src[4], a_dst[4], a_qq[4];
     bool a_colok[4];
+    const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int u = tid + 256 * i;
         const int tt = u >> 7, v = u & 127;
         const int rb = tt >> 2, qq = tt & 3;               // query block (of 2), chunk (of 4) inside the step
         const int ks = v >> 6, ar = (v >> 1) & 31, h2 = v & 1;
-        a_src[i] = (rb * nchunk + qq) * 1024 + v * 8;      // elements, relative to tile (bh, i0/32, d0/32)
+        a_src[i] = qq * 1024 + v * 8;                      // elements, relative to tile (bh, I0 + rb, d0/32) of the packed grid
         const int ch16 = 4 * qq + 2 * ks + h2;             // 16-byte column chunk 0..15 of the 128 distances
         a_dst[i] = (rb * 2 + (ch16 >> 3)) * TILE_BYTES + imgT_off(ar, ch16 & 7);
         a_colok[i] = (d0 >> 5) + qq < nchunk;
+        a_qq[i] = qq;
     }
     u32x4 areg[4], qreg[2];
     auto load_tiles = [&](int g) {
         const int bh = g / ns, i0 = d0 + (g - bh * ns) * RS;
         const int bb = bh / heads, hd = bh - bb * heads;
-        const uint16_t* ap = dsrel + (((size_t)bh * nchunk + (i0 >> 5)) * nchunk + (d0 >> 5)) * 1024;
+        // packed causal grid: row block I holds chunks 0..I at (bh*T + I(I+1)/2 + q) * 1024; chunks q > I are zeros
+        const int I0 = i0 >> 5;
+        const uint16_t* ap = dsrel + ((size_t)bh * ntri + (size_t)I0 * (I0 + 1) / 2 + (d0 >> 5)) * 1024;
+        const size_t rb1 = (size_t)(I0 + 1) * 1024;        // row block I0+1 starts I0+1 tiles further
         const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + qch * 8;
         const bool second = i0 + 32 < L;                   // L % 64 may be 32: the step's second query block is absent
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            areg[i] = (a_colok[i] && (i < 2 || second)) ? __builtin_nontemporal_load((const u32x4*)(ap + a_src[i]))
-                                                         : u32x4{0, 0, 0, 0};       // read once: do not displace q in L2
+        for (int i = 0; i < 4; ++i) {
+            const int rb = i >> 1;                         // units 0,1 -> first query block, 2,3 -> second (u = tid + 256 i)
+            const bool ok = a_colok[i] && (rb == 0 || second) && ((d0 >> 5) + a_qq[i] <= I0 + rb);
+            areg[i] = ok ? __builtin_nontemporal_load((const u32x4*)(ap + a_src[i] + (rb ? rb1 : 0)))
+                         : u32x4{0, 0, 0, 0};              // read once: do not displace q in L2
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = qrow + 32 * i;
@@ -959,8 +964,9 @@ static size_t ws_ert_bytes(int L) { return 2 * er_frag_bytes(L); }   // EfA | Ef
 
 extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
     if (B <= 0 || L <= 0 || d <= 0) return 0;
-    // delta f32 [B,h,L] | fragment-ordered Er (EfA, EfT) | dS by (query, distance) bf16 [B,h,L,L]
-    return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * L * L * 2;
+    // delta f32 [B,h,L] | fragment-ordered Er (EfA, EfT) | causal half of dS by (query, distance) bf16 [B,h,L,L]
+    const size_t nchunk = (size_t)L / 32;
+    return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * (nchunk * (nchunk + 1) / 2) * 2048;
 }
 
 // parts: 1 pre-pass (delta, E transpose) | 2 dQ (also leaves dS for 8) | 4 dK/dV | 8 dE streamed from the dS the dQ

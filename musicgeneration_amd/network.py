@@ -228,6 +228,7 @@ class MusicTransformer(torch.nn.Module):
         probs_step = torch.zeros(B, V, dtype=torch.float32, device=dev) if return_probs else None
         hbuf = torch.empty(B, d, dtype=bf, device=dev)
         ctxbuf = torch.empty(B, d, dtype=bf, device=dev)
+        attn_ws = ops.rel_attn_decode_workspace(B, total, d, dev)       # split-K partials (long caches only)
         pe = self.Decoder.pos_encoding.table()
         Pm = st.params
         layers = []
@@ -257,7 +258,7 @@ class MusicTransformer(torch.nn.Module):
             h = ops.decode_embed(tok, Pm["Decoder.embedding.weight"].data, pe, pos, hbuf)
             qkv = ops.linear_fwd(h, layers[0]["wqkv"], layers[0]["bqkv"], 0)
             for i, ly in enumerate(layers):
-                ops.rel_attn_decode(qkv, kc[i], vc[i], ly["E"], pos, ctxbuf)
+                ops.rel_attn_decode(qkv, kc[i], vc[i], ly["E"], pos, ctxbuf, attn_ws)
                 a = ops.linear_fwd(ctxbuf, ly["wfc"], ly["bfc"], 0)
                 nxt = layers[i + 1] if i + 1 < nl else None
                 if fuse_ln:

@@ -309,11 +309,19 @@ def decode_embed(tok, table, pe, pos_dev, out):
     return out
 
 
-def rel_attn_decode(qkv_new, kcache, vcache, E, pos_dev, ctx):
-    _need_cuda(qkv_new, kcache, vcache, E, pos_dev, ctx)
+def rel_attn_decode_workspace(B, Lmax, d, device):
+    """scratch for the split-K partials of mgx_rel_attn_decode (None when the cache is short enough for one workgroup per
+    (b,h)); allocate once per generation: the decode step is graph-captured, so the buffer must outlive the graph"""
+    n = _lib.load().mgx_rel_attn_decode_workspace(B, Lmax, d)
+    return torch.empty(n, dtype=torch.uint8, device=device) if n else None
+
+
+def rel_attn_decode(qkv_new, kcache, vcache, E, pos_dev, ctx, workspace=None):
+    _need_cuda(qkv_new, kcache, vcache, E, pos_dev, ctx, workspace)
     B, Lmax, d = kcache.shape
-    check(_lib.load().mgx_rel_attn_decode(ptr(qkv_new), ptr(kcache), ptr(vcache), ptr(E), ptr(pos_dev), ptr(ctx), B, Lmax,
-                                          d, E.shape[0], stream_ptr()), "mgx_rel_attn_decode")
+    check(_lib.load().mgx_rel_attn_decode(ptr(qkv_new), ptr(kcache), ptr(vcache), ptr(E), ptr(pos_dev), ptr(ctx), ptr(workspace),
+                                          0 if workspace is None else workspace.numel(), B, Lmax, d, E.shape[0], stream_ptr()),
+          "mgx_rel_attn_decode")
     return ctx
 
 

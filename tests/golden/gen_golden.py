@@ -437,8 +437,8 @@ def gen_mt2():
         with torch.no_grad():
             rga.E.mul_(0.3)
         xg = (torch.randn(B1, L1, dd1) * 0.7).requires_grad_(True)
-        tok = torch.randint(0, 5, (B1, L1))
-        tok[0, -3:] = 4                                   # pretend 4 is pad: trailing key-padding columns
+        tok = torch.randint(0, 4, (B1, L1))               # 4 is the pad id: no accidental (leading) pads
+        tok[0, -3:] = 4                                   # trailing key-padding columns, as a real batch has them
         _, _, lam = utils.get_masked_with_pad_tensor(L1, tok, tok, 4)
         out, aw = rga([xg, xg, xg], lam)
         wsum = torch.linspace(0.5, 1.5, out.numel()).reshape(out.shape)

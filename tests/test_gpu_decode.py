@@ -270,3 +270,24 @@ def test_gru_beam_search_is_exact_when_the_beam_is_wide_enough():
     s1 = net.beam_search(init, steps, beam_size=3, stochastic=True, seed=4)
     s2 = net.beam_search(init, steps, beam_size=3, stochastic=True, seed=4)
     assert torch.equal(s1, s2) and s1.shape == (steps, B) and int(s1.max()) < V
+
+
+def test_cfg5_sized_cached_decode_matches_training_forward():
+    """BASELINE cfg5's size (seq_len 8192, batch 32, cfg2-shaped model): the KV-cache decode path, teacher-forced over the
+    whole sequence, gives the same next-token distributions as the training forward on the same prefix -- checked at
+    positions 1, 4095 and 8191 (cache of 1, 4096 and 8192 rows) for every batch row."""
+    mt, _ = _model(d=512, nl=6, L=8192, V=337, seed=5)
+    V, L, B = 337, 8192, 32
+    g = torch.Generator().manual_seed(55)
+    x = torch.randint(0, V - 1, (B, L), generator=g).cuda()
+    toks, probs = mt.generate_cached(x, 0, return_probs=True)
+    torch.cuda.synchronize()
+    assert (toks == x).all()
+    with torch.no_grad():
+        logits = mt(x.to(torch.int32))[0]
+    for pos in (1, 4095, 8191):
+        fwd = torch.softmax(logits[:, pos].float(), -1)
+        got = probs[:, pos]
+        assert torch.isfinite(got).all() and abs(got.sum(-1) - 1).max().item() < 1e-3
+        assert (got - fwd).abs().max().item() < 1e-2, pos
+        assert (got.argmax(-1) == fwd.argmax(-1)).float().mean().item() >= 0.9, pos

@@ -148,3 +148,49 @@ def test_full_size_dE_two_ways_and_grouped_dW():
         assert _rel(gw, gw2) < 1e-5
         if gb is not None:
             assert _rel(gb, gb2) < 1e-5
+
+
+def test_cfg4_shaped_model_step():
+    """BASELINE cfg4 as a MODEL (MuMIDI V=486, 12 layers, d=768 = 12 heads, L=4096), batch 1:
+    (a) one cfg4-shaped layer + vocabulary projection against the oracle's fp32 forward on the same tokens (trailing pads),
+    (b) the full 12-layer model takes optimiser steps with finite, decreasing loss."""
+    from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
+    from musicgeneration_amd.network import MusicTransformer
+    from musicgeneration_amd.optim import FusedAdam
+    from oracle import ref_cpu as R
+    V, d, L = 486, 768, 4096
+    pad = V - 1
+    p1 = R.init_params(V, d, 1, L, seed=4)
+    for k in p1:
+        if k.endswith("embedding.weight") or k.endswith("rga.E"):
+            p1[k] = p1[k] * 0.2
+    g = torch.Generator().manual_seed(44)
+    x = torch.randint(0, V - 1, (1, L), generator=g)
+    x[0, L - 300:] = pad
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = R.model_forward(p1, x, pad)[0]
+    mt1 = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=1, max_seq=L, dropout=0.0)
+    mt1.load_state_dict(p1)
+    mt1 = mt1.cuda().train()
+    with torch.no_grad():
+        got = mt1(x.to(torch.int32).cuda()).float().cpu()
+    assert torch.isfinite(got).all()
+    assert _rel(got, ref) <= 2e-2 and (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    del mt1
+    torch.manual_seed(0)
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=12, max_seq=L, dropout=0.0).cuda().train()
+    opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9)
+    sch = CustomSchedule(d, warmup_steps=20, optimizer=opt)
+    lossf = SmoothCrossEntropyLoss(0.1, V, pad)
+    xf = torch.randint(0, V - 1, (1, L + 1), device="cuda")
+    xi, yi = xf[:, :-1].to(torch.int32), xf[:, 1:].to(torch.int32)
+    losses = []
+    for _ in range(8):
+        loss = lossf(mt(xi), yi)
+        loss.backward()
+        sch.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(losses))), losses
+    assert losses[-1] < losses[0] - 0.1, losses

@@ -9,7 +9,7 @@ cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- \
-      python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /tmp/pmc_$c.log 2>&1 || { tail -5 /tmp/pmc_$c.log; exit 1; }
+      python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-decode > /tmp/pmc_$c.log 2>&1 || { tail -5 /tmp/pmc_$c.log; exit 1; }
 done
 cd $ROOT
 python3 - "$OUT" <<'PY'
