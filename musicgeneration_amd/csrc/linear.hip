@@ -189,13 +189,22 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
 
     const int srow = tid >> 3, sch = tid & 7;
     u32x4 areg[4], wreg[4];
+    // Loads are unconditional: rows beyond M / N are clamped into range (their products land in accumulator rows / columns
+    // that the epilogue never stores).  A load under a per-lane condition costs an exec-mask branch and a zero-fill per
+    // load and makes the compiler wait for the whole VMEM queue where the paths rejoin.
+    const uint16_t* ap[4];
+    const uint16_t* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        ap[i] = A + (size_t)min(m0 + row, M - 1) * K + sch * 8;
+        wp[i] = W + (size_t)min(n0 + row, N - 1) * K + sch * 8;
+    }
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
-            const int gm = m0 + row, gn = n0 + row;
-            areg[i] = (gm < M) ? *(const u32x4*)(A + (size_t)gm * K + k0 + sch * 8) : u32x4{0, 0, 0, 0};
-            wreg[i] = (gn < N) ? *(const u32x4*)(W + (size_t)gn * K + k0 + sch * 8) : u32x4{0, 0, 0, 0};
+            areg[i] = *(const u32x4*)(ap[i] + k0);
+            wreg[i] = *(const u32x4*)(wp[i] + k0);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -210,13 +219,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
     };
     f32x16 acc[2][2];
     zero_acc(acc);
-    const int nk = K / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = DBUF ? (kt & 1) : 0;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    auto multiply = [&](int cur) {
         const char* at = smem + cur * 2 * IMG;
         const char* wt = at + IMG;
 #pragma unroll
@@ -232,10 +235,23 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
             acc[1][0] = mfma(b0, a1, acc[1][0]);
             acc[1][1] = mfma(b1, a1, acc[1][1]);
         }
+    };
+    const int nk = K / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    // all reduction tiles but the last: branch-free body (prefetch the next tile, multiply the current one, publish)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int cur = DBUF ? (kt & 1) : 0;
+        load_tiles((kt + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch AHEAD of the MFMAs (the scheduler sinks it to the barrier)
+        multiply(cur);
         if (!DBUF) __syncthreads();                 // single buffer: everyone has read the tile before it is replaced
-        if (kt + 1 < nk) store_tiles(DBUF ? (cur ^ 1) : 0);
+        store_tiles(DBUF ? (cur ^ 1) : 0);
         __syncthreads();
     }
+    multiply(DBUF ? ((nk - 1) & 1) : 0);
+    __syncthreads();
     // (the loop's last barrier has passed: no wave reads the tile buffers any more)
     if ((N & 7) == 0)
         store_tile_lds(C, nullptr, nullptr, acc, bias, act, m0 + 64 * wm, n0 + 64 * wn, M, N, lane, smem + w * EPI_PATCH);
@@ -249,7 +265,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
 //   LDS:  dY tile [128 m][64 n] image R;  W tile [64 n][128 k'] as 4 sub-tiles (2 n-blocks x 2 col halves)
 //         of [32][64] image T
 // =================================================================================================
-template <bool DBUF>
+template <bool DBUF, bool EXACT>
 __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_dx_kernel(const uint16_t* __restrict__ dY,
                                                            const uint16_t* __restrict__ W,
                                                            const uint16_t* __restrict__ relu_y,
@@ -270,14 +286,29 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_dx_kernel(const uint
     const int srow = tid >> 3, sch = tid & 7;
     const int wrow = tid >> 4, wch = tid & 15;           // W rows wrow + 16 i, 16 lanes per 256-byte row (see dW)
     u32x4 areg[4], wreg[4];
+    // EXACT (N % 64 == 0, the case of every model shape): every load is unconditional -- rows beyond M and columns beyond
+    // K are clamped into range (they only feed accumulator entries that are never stored), and no reduction tile is
+    // partial.  Otherwise the reduction tail must be zero-filled: guarded loads.
+    const uint16_t* ap[4];
+    const uint16_t* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ap[i] = dY + (size_t)min(m0 + srow + 32 * i, M - 1) * N + sch * 8;
+        wp[i] = W + (size_t)(wrow + 16 * i) * K + min(k0 + wch * 8, K - 8);
+    }
     auto load_tiles = [&](int n0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int gm = m0 + srow + 32 * i;
-            const int gn = n0 + sch * 8;                                  // N % 8 == 0 (host-checked)
-            areg[i] = (gm < M && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
-            const int wn_ = n0 + wrow + 16 * i, wk = k0 + wch * 8;
-            wreg[i] = (wn_ < N && wk < K) ? *(const u32x4*)(W + (size_t)wn_ * K + wk) : u32x4{0, 0, 0, 0};
+            if (EXACT) {
+                areg[i] = *(const u32x4*)(ap[i] + n0);
+                wreg[i] = *(const u32x4*)(wp[i] + (size_t)n0 * K);
+            } else {
+                const int gm = m0 + srow + 32 * i;
+                const int gn = n0 + sch * 8;                                  // N % 8 == 0 (host-checked)
+                areg[i] = (gm < M && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
+                const int wn_ = n0 + wrow + 16 * i, wk = k0 + wch * 8;
+                wreg[i] = (wn_ < N && wk < K) ? *(const u32x4*)(W + (size_t)wn_ * K + wk) : u32x4{0, 0, 0, 0};
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -293,13 +324,7 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_dx_kernel(const uint
     };
     f32x16 acc[2][2];
     zero_acc(acc);
-    const int nn = (N + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int nt = 0; nt < nn; ++nt) {
-        const int cur = DBUF ? (nt & 1) : 0;
-        if (nt + 1 < nn) load_tiles((nt + 1) * BK);
+    auto multiply = [&](int cur) {
         const char* at = smem + cur * 2 * IMG;
         const char* wt = at + IMG;
 #pragma unroll
@@ -314,10 +339,22 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_dx_kernel(const uint
             acc[1][0] = mfma(b0, a1, acc[1][0]);
             acc[1][1] = mfma(b1, a1, acc[1][1]);
         }
+    };
+    const int nn = (N + BK - 1) / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int nt = 0; nt + 1 < nn; ++nt) {
+        const int cur = DBUF ? (nt & 1) : 0;
+        load_tiles((nt + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch AHEAD of the MFMAs (the scheduler sinks it to the barrier)
+        multiply(cur);
         if (!DBUF) __syncthreads();                 // single buffer: everyone has read the tile before it is replaced
-        if (nt + 1 < nn) store_tiles(DBUF ? (cur ^ 1) : 0);
+        store_tiles(DBUF ? (cur ^ 1) : 0);
         __syncthreads();
     }
+    multiply(DBUF ? ((nn - 1) & 1) : 0);
+    __syncthreads();
     store_tile_lds(dX, relu_y, addend, acc, nullptr, 0, m0 + 64 * wm, k0 + 64 * wn, M, K, lane, smem + w * EPI_PATCH);   // K % 8 == 0
 }
 
@@ -326,6 +363,9 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_dx_kernel(const uint
 //   tile: 128 rows n x 128 cols k, reduction over m in steps of 64
 //   LDS:  dY tile [64 m][128 n] and X tile [64 m][128 k], each as 4 sub-tiles [32][64] image T
 // =================================================================================================
+// EXACT: the row range [mbeg, mend) is a whole number of 64-row reduction tiles (every model shape): all loads are
+// unconditional, columns beyond N / K clamped into range (they only feed accumulator entries that are never added).
+template <bool EXACT>
 MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ gW,
                      float* __restrict__ gb, int M, int N, int K, int tile, int mbeg, int mend, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -341,17 +381,24 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
     const int wrow = tid >> 4, ch = tid & 15;            // rows wrow + 16 i
     const int sub_c = ch >> 3, slot = ch & 7;
     u32x4 areg[4], breg[4];
+    const uint16_t* ap = dY + (size_t)wrow * N + min(n0 + ch * 8, N - 8);
+    const uint16_t* bp = X + (size_t)wrow * K + min(k0 + ch * 8, K - 8);
     auto load_tiles = [&](int mm) {
         const int gn = n0 + ch * 8, gk = k0 + ch * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int gm = mm + wrow + 16 * i;
-            areg[i] = (gm < mend && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
-            breg[i] = (gm < mend && gk < K) ? *(const u32x4*)(X + (size_t)gm * K + gk) : u32x4{0, 0, 0, 0};
+            if (EXACT) {
+                areg[i] = *(const u32x4*)(ap + (size_t)(mm + 16 * i) * N);
+                breg[i] = *(const u32x4*)(bp + (size_t)(mm + 16 * i) * K);
+            } else {
+                const int gm = mm + wrow + 16 * i;
+                areg[i] = (gm < mend && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
+                breg[i] = (gm < mend && gk < K) ? *(const u32x4*)(X + (size_t)gm * K + gk) : u32x4{0, 0, 0, 0};
+            }
         }
     };
     // bias gradient gb[n] += sum_m dY[m][n]: the workgroups of the first k-tile column add up the dY rows they stage anyway
-    const bool do_bias = (gb != nullptr) && (tk == 0);
+    const bool do_bias = (gb != nullptr) && (tk == 0) && (!EXACT || n0 + ch * 8 < N);
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto store_tiles = [&](int buf) {
         char* at = smem + buf * 2 * IMG;
@@ -381,9 +428,7 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
         store_tiles(0);
     }
     __syncthreads();
-    for (int mt = 0; mt < nm; ++mt) {
-        const int cur = mt & 1;
-        if (mt + 1 < nm) load_tiles(mbeg + (mt + 1) * BK);
+    auto multiply = [&](int cur) {
         const char* at = smem + cur * 2 * IMG;
         const char* bt = at + IMG;
 #pragma unroll
@@ -399,9 +444,16 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
             acc[1][0] = mfma(a1, b0, acc[1][0]);
             acc[1][1] = mfma(a1, b1, acc[1][1]);
         }
-        if (mt + 1 < nm) store_tiles(cur ^ 1);
+    };
+    for (int mt = 0; mt + 1 < nm; ++mt) {                // all reduction tiles but the last: branch-free body
+        const int cur = mt & 1;
+        load_tiles(mbeg + (mt + 1) * BK);
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch AHEAD of the MFMAs
+        multiply(cur);
+        store_tiles(cur ^ 1);
         __syncthreads();
     }
+    if (nm > 0) multiply((nm - 1) & 1);
     if (do_bias) {      // lanes with equal (tid & 15) hold the same 8 columns: fold lane bits 4,5, then one atomic per wave
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -438,7 +490,8 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __res
     // (mostly) the tiles of ONE row chunk: the dY / X blocks those tiles share are fetched into that XCD's L2 once
     const int u = xcd_remap(blockIdx.x, gridDim.x);
     const int mbeg = (u / tiles) * mchunk;
-    dw_tile(dY, X, gW, gb, M, N, K, u % tiles, mbeg, min(M, mbeg + mchunk), smem);
+    if (M % mchunk == 0 && mchunk % BK == 0) dw_tile<true>(dY, X, gW, gb, M, N, K, u % tiles, mbeg, mbeg + mchunk, smem);
+    else dw_tile<false>(dY, X, gW, gb, M, N, K, u % tiles, mbeg, min(M, mbeg + mchunk), smem);
 }
 
 // Several weight gradients that share the row count M (one encoder block's QKV / fc / FFN projections) in ONE launch:
@@ -462,7 +515,10 @@ __global__ __launch_bounds__(256, 2) void linear_dw_grouped_kernel(const DwGroup
     int p = 0;
     while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
     const int mbeg = (u / tiles) * mchunk;
-    dw_tile(g.dY[p], g.X[p], g.gW[p], g.gb[p], M, g.N[p], g.K[p], t - g.first_tile[p], mbeg, min(M, mbeg + mchunk), smem);
+    if (M % mchunk == 0 && mchunk % BK == 0)
+        dw_tile<true>(g.dY[p], g.X[p], g.gW[p], g.gb[p], M, g.N[p], g.K[p], t - g.first_tile[p], mbeg, mbeg + mchunk, smem);
+    else
+        dw_tile<false>(g.dY[p], g.X[p], g.gW[p], g.gb[p], M, g.N[p], g.K[p], t - g.first_tile[p], mbeg, min(M, mbeg + mchunk), smem);
 }
 
 // =================================================================================================
@@ -609,7 +665,8 @@ static bool g_attr_set = false;
 static void set_attrs() {
     if (g_attr_set) return;
     hipFuncSetAttribute((const void*)linear_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)linear_dx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_dx_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_dx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     g_attr_set = true;
@@ -654,12 +711,12 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
     static int sbuf_env = -2;
     if (sbuf_env == -2) { const char* e = getenv("MGX_GEMM_SINGLE_BUF"); sbuf_env = e ? atoi(e) : -1; }
     const bool sbuf = sbuf_env >= 0 ? (sbuf_env != 0) : (nwg >= 768);      // as in the forward: 3 workgroups / CU for big grids
-    if (sbuf)
-        hipLaunchKernelGGL(linear_dx_kernel<false>, dim3(nwg), dim3(256), LDS_BYTES / 2, (hipStream_t)stream, dY, W, relu_y,
-                           addend, dX, M, N, K);
-    else
-        hipLaunchKernelGGL(linear_dx_kernel<true>, dim3(nwg), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, W, relu_y,
-                           addend, dX, M, N, K);
+    const bool exact = (N % BK == 0);          // no partial reduction tile: the branch-free load path
+#define MGX_DX_LAUNCH(DB, EX, LDS) hipLaunchKernelGGL((linear_dx_kernel<DB, EX>), dim3(nwg), dim3(256), LDS, (hipStream_t)stream, \
+                                                      dY, W, relu_y, addend, dX, M, N, K)
+    if (sbuf) { if (exact) MGX_DX_LAUNCH(false, true, LDS_BYTES / 2); else MGX_DX_LAUNCH(false, false, LDS_BYTES / 2); }
+    else      { if (exact) MGX_DX_LAUNCH(true, true, LDS_BYTES); else MGX_DX_LAUNCH(true, false, LDS_BYTES); }
+#undef MGX_DX_LAUNCH
     MGX_CHECK_LAUNCH("mgx_linear_dx");
     return MGX_OK;
 }

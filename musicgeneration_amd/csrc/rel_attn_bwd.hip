@@ -358,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(dq - 2, ks);      // Er chunk of the next step
+        __builtin_amdgcn_sched_barrier(0x78F);             // VMEM may not sink below: the fragments are needed at the top of the next step
         tile_tail(c, dq, cur, 0u, std::false_type{}, et);
         *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
         *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         // the lo slot is free now: fetch the next step's hi chunk into it
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
+        if (!MASKED) __builtin_amdgcn_sched_barrier(0x78F);    // VMEM may not sink below: needed at the top of the next step
         wave_lds_fence();
         f32x16 c;
         {

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) e[ks] = ef(dq - 2, ks);          // chunk of the next step
+        __builtin_amdgcn_sched_barrier(0x78F);             // VMEM may not sink below: the fragments are needed at the top of the next step
         const char* kt = smem + OFF_K + cur * TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
