@@ -108,6 +108,14 @@ class Data:
 # --------------------------------------------------------------------------------------------------
 # GRU feeder: mirror of mg/model/utils/data.py:23-47 (SeqBatchify, MyDataset) and :49-123 (Event_Dataset)
 # --------------------------------------------------------------------------------------------------
+def flatten_padded_sequences(outs, lengths):
+    """[B, mx, V] batch-first outputs -> the rows that have a label, concatenated: outs[i, :lengths[i]-1] for every i
+    (utils/data.py:14-21); pairs with SeqBatchify's Y."""
+    if lengths is None:
+        return outs.contiguous().view(-1, outs.shape[-1])
+    return torch.cat([outs[i, :int(lengths[i]) - 1] for i in range(outs.shape[0])], 0)
+
+
 def SeqBatchify(inputs):
     """sort by length (desc), zero-pad to the longest -> (X int16 [B,Tmax], Y = concat of X[i,1:len_i], lengths)"""
     inputs = sorted(inputs, key=lambda i: len(i), reverse=True)

@@ -34,6 +34,9 @@ def get_options(argv=None):
     parser.add_option('--grammar', dest='grammar', action='store_true', default=False,
                       help='constrain sampling to the REMI / MuMIDI event grammar (KV-cache decode, mask inside the sampler)')
     parser.add_option('-M', '--max_seq', dest='max_seq', type='int', default=config.max_seq)
+    parser.add_option('-c', '--condition-file', dest='condition_file', type='string', default=getattr(config, 'condition_file', None),
+                      help='MIDI file to continue (the reference reads config.condition_file, generate.py:101-105): its '
+                           'first 500 MIDI-like events become the prior of every sample')
     return parser.parse_args(argv)[0]
 
 
@@ -58,6 +61,16 @@ def main(argv=None):
             print('Test >>>> Loss: {:6.6}, Accuracy: {}'.format(m['loss'], m['accuracy']))
     mt.test()
     prior = torch.tensor([[24, 28, 31]] * o.batch_size, dtype=torch.long, device=device)
+    if o.condition_file is not None:
+        # generate.py:101-105: MIDI -> notes -> MIDI-like events -> the first 500 indices, repeated for the batch
+        if o.repr != 'midi_like':
+            raise SystemExit('--condition-file continues a MIDI-like (EventSeq) prompt: use --repr midi_like')
+        from .sequence import EventSeq, NoteSeq
+        ids = EventSeq.from_note_seq(NoteSeq.from_midi_file(o.condition_file)).to_array()[:500]
+        if len(ids) == 0:
+            raise SystemExit(f'{o.condition_file}: no notes in the MIDI-like pitch range')
+        prior = torch.from_numpy(np.array([ids] * o.batch_size, dtype=np.int64)).to(device)
+        print('Prompt: {} events from {}'.format(len(ids), o.condition_file))
     if o.grammar:
         if o.repr == 'remi':
             from .REMI import REMI_EventSeq as Codec

@@ -206,9 +206,28 @@ class Event_Melody_RNN(nn.Module):
     def Train(self, init, events, lengths=None):
         """Teacher-forced logits [T+1,B,V] (network.py:63-84,109-116): the primary event, then ``events``, through the
         GRU from ``init_to_hidden(init)``; differentiable (backward-through-time on the libmgx kernels), with nn.GRU's
-        inter-layer dropout in training mode."""
+        inter-layer dropout in training mode.
+
+        ``lengths`` (the reference's ``sequence`` mode, train.py:263-287): ``events`` is then SeqBatchify's BATCH-FIRST
+        ``X [B,Tmax]`` (rows sorted by length, zero padded) and the result is batch-first ``[B, Tmax+1, V]``: the
+        primary-event step followed by one step per event, where steps past a row's length hold ``output_fc(0)`` --
+        exactly what ``pack_padded_sequence`` -> GRU -> ``pad_packed_sequence`` -> ``output_fc`` gives (a GRU is causal
+        per batch row, so running the padded rows and overwriting the steps past the end is the packed computation;
+        the padded steps send no gradient into the recurrence).  The reference's own call mixes the batch and time axes
+        (network.py:64,71 take ``events.shape[1]`` as the batch size of a batch-first tensor) and cannot run; this is the
+        computation its loss (``flatten_padded_sequences`` + concatenated labels, utils/data.py:14-36) is written for."""
         if lengths is not None:
-            raise NotImplementedError("packed variable-length batches are not built")
+            ev = torch.as_tensor(events)
+            if ev.dim() != 2 or ev.shape[0] != init.shape[0] or len(lengths) != ev.shape[0]:
+                raise ValueError("with lengths, events must be batch-first [B,Tmax] (SeqBatchify's X) and len(lengths) == B")
+            lens = torch.as_tensor(lengths, dtype=torch.int64)
+            if int(lens.max()) > ev.shape[1] or int(lens.min()) < 1:
+                raise ValueError("lengths must lie in [1, Tmax]")
+            full = self.Train(init, ev.t().contiguous())                     # [Tmax+1, B, V], padded steps included
+            steps = torch.arange(full.shape[0], device=full.device)[:, None]
+            valid = steps <= lens.to(full.device)[None, :]                   # step 0 = primary event, steps 1..len = events
+            fill = self.output_fc.bias.to(full.dtype)                        # output_fc applied to a zero (padded) GRU output
+            return torch.where(valid[..., None], full, fill.expand_as(full)).transpose(0, 1)
         pk = self._pack()
         hidden = self.init_to_hidden(init).float().contiguous()
         B = init.shape[0]

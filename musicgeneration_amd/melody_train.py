@@ -2,8 +2,11 @@
 ``segment`` mode (train.py:327-362, the reference's configured mode) and for ``window`` with teacher forcing 1.0
 (train.py:217-262, where ``generate(..., output_type='logit')`` equals ``Train``): random init vector -> ``Train`` ->
 cross-entropy -> ``clip_grad_norm_`` -> Adam, one ``state_dict`` checkpoint per epoch
-(``{mode}_512_3_1_epoch_{n}.pth``, train.py:188-195).  Not built: the ``sequence`` mode (packed variable-length
-batches) and teacher forcing < 1 (sampling inside the training graph)."""
+(``{mode}_512_3_1_epoch_{n}.pth``, train.py:188-195).  ``sequence`` mode (train.py:263-287): whole variable-length
+sequences, ``SeqBatchify`` collate (sorted, zero-padded ``X [B,Tmax]``, concatenated labels ``X[i,1:len_i]``),
+``Train(init, X, lengths)`` and the loss over ``flatten_padded_sequences`` -- the computation the reference's loop is
+written for (its own ``SeqForward`` mixes the batch and time axes and cannot run).  Not built: teacher forcing < 1
+(sampling inside the training graph)."""
 from __future__ import annotations
 
 import optparse
@@ -15,7 +18,7 @@ import torch
 from torch import nn, optim
 
 from . import utils
-from .data import Event_Dataset, MyDataset
+from .data import Event_Dataset, MyDataset, SeqBatchify, flatten_padded_sequences
 from .melody_rnn import Event_Melody_RNN
 from .sequence import EventSeq
 
@@ -46,14 +49,14 @@ def get_options(argv=None):
     parser.add_option('-r', '--reset-optimizer', dest='reset_optimizer', action='store_true', default=False)
     parser.add_option('-L', '--enable-logging', dest='enable_logging', action='store_true', default=False)
     parser.add_option('-q', '--limit-length', dest='limlen', type='int', default=LIMLEN)
-    parser.add_option('--mode', dest='mode', type='string', default=TRAIN_MODE, help="segment | window (config.train_mode)")
+    parser.add_option('--mode', dest='mode', type='string', default=TRAIN_MODE, help="segment | window | sequence (config.train_mode)")
     return parser.parse_args(argv)[0]
 
 
 def main(argv=None):
     o = get_options(argv)
-    if o.mode not in ('segment', 'window'):
-        raise NotImplementedError("train_mode 'sequence' (packed variable-length batches) is not built")
+    if o.mode not in ('segment', 'window', 'sequence'):
+        raise ValueError("--mode must be segment, window or sequence")
     if o.mode == 'window' and o.teacher_forcing_ratio != 1.0:
         raise NotImplementedError("teacher forcing < 1 samples inside the training graph: not built")
     model_config = dict(MODEL)
@@ -79,10 +82,15 @@ def main(argv=None):
         stride = max(1, window // 3)
         print(f'Window Size = {window}')
         print(f'Stride = {stride}')
-    windows = dataset.batches(o.batch_size, window, stride)
-    print(f'Iteration={len(windows) // o.batch_size}')
-    loader = torch.utils.data.DataLoader(MyDataset(windows), o.batch_size, collate_fn=dataset.SegBatchify, shuffle=True,
-                                         drop_last=True, num_workers=0)
+    if o.mode == 'sequence':                                  # train.py:263-272: whole sequences, packed by length
+        loader = torch.utils.data.DataLoader(MyDataset(dataset.samples), o.batch_size, collate_fn=SeqBatchify, shuffle=True,
+                                             drop_last=True, num_workers=0)
+        print(f'Iteration={len(dataset.samples) // o.batch_size}')
+    else:
+        windows = dataset.batches(o.batch_size, window, stride)
+        print(f'Iteration={len(windows) // o.batch_size}')
+        loader = torch.utils.data.DataLoader(MyDataset(windows), o.batch_size, collate_fn=dataset.SegBatchify, shuffle=True,
+                                             drop_last=True, num_workers=0)
     loss_function = nn.CrossEntropyLoss()
     os.makedirs(o.save_path, exist_ok=True)
 
@@ -97,11 +105,19 @@ def main(argv=None):
     for epoch in range(o.epochs):
         try:
             l_sum, n = 0.0, 0
-            for iteration, events in enumerate(loader):
-                events = torch.from_numpy(np.ascontiguousarray(events).astype(np.int64)).to(device)     # [T, B]
+            for iteration, batch in enumerate(loader):
                 init = torch.randn(o.batch_size, model.init_dim, device=device)
-                outputs = model.Train(init, events=events[:-1])
-                loss = loss_function(outputs.view(-1, event_dim), events.view(-1))
+                if o.mode == 'sequence':
+                    X, label, lengths = batch                                                         # [B,Tmax], [sum(len-1)], [B]
+                    X = torch.from_numpy(np.ascontiguousarray(X).astype(np.int64)).to(device)
+                    label = torch.from_numpy(np.ascontiguousarray(label).astype(np.int64)).to(device)
+                    outputs = model.Train(init, events=X, lengths=lengths)                            # [B, Tmax+1, V]
+                    # step t+1 has consumed X[i, 0..t] and predicts X[i, t+1]: rows 1..len-1 of each sample carry a label
+                    loss = loss_function(flatten_padded_sequences(outputs[:, 1:], lengths), label)
+                else:
+                    events = torch.from_numpy(np.ascontiguousarray(batch).astype(np.int64)).to(device)     # [T, B]
+                    outputs = model.Train(init, events=events[:-1])
+                    loss = loss_function(outputs.view(-1, event_dim), events.view(-1))
                 model.zero_grad()
                 loss.backward()
                 l_sum += loss.item()

@@ -78,6 +78,14 @@ def test_melody_rnn_train_cli(tmp_path, capsys):
     assert set(sd) >= {"event_embedding.weight", "rnn.weight_ih_l0", "rnn.weight_hh_l1", "output_fc.weight", "inithid_fc.bias"}
     net = Event_Melody_RNN(init_dim=8, event_dim=sd["output_fc.weight"].shape[0], hidden_dim=64, rnn_layers=2, dropout=0.0)
     net.load_state_dict(sd)
+    # the `sequence` mode (train.py:263-287): whole variable-length sequences, SeqBatchify + Train(lengths=...)
+    out2 = str(tmp_path / "save_seq") + "/"
+    melody_train.main(["-d", str(data), "-s", out2, "-e", "3", "-b", "3", "-q", "100", "-l", "0.01", "--mode", "sequence",
+                       "-p", "hidden_dim=64,rnn_layers=2,dropout=0.0,init_dim=8"])
+    log = capsys.readouterr().out
+    losses = [float(v) for v in re.findall(r"ave-loss: ([0-9.]+)", log)]
+    assert len(losses) == 3 and losses[-1] < 0.8 * losses[0], losses
+    assert len(glob.glob(out2 + "sequence_512_3_1_epoch_*.pth")) == 3
 
 
 def test_generate_cli_remi_grammar_writes_midi(tmp_path, capsys):
@@ -94,3 +102,24 @@ def test_generate_cli_remi_grammar_writes_midi(tmp_path, capsys):
         assert back["resolution"] == 480
         total += len(back["notes"])
     assert total > 0          # with the grammar even an untrained model emits complete (position, velocity, pitch, duration) groups
+
+
+def test_generate_cli_continues_a_prompt_midi(tmp_path, capsys):
+    """generate.py -c prompt.mid (the reference's config.condition_file branch, generate.py:101-105): MIDI -> notes ->
+    MIDI-like events -> prior; the written sample starts with the prompt's notes."""
+    from musicgeneration_amd import generate, smf
+    from musicgeneration_amd.sequence import EventSeq, Note, NoteSeq
+    prompt = str(tmp_path / "prompt.mid")
+    notes = [Note(80, 60 + 2 * k, 0.25 * k, 0.25 * k + 0.2) for k in range(6)]
+    NoteSeq(notes).to_midi_file(prompt)
+    ids = EventSeq.from_note_seq(NoteSeq.from_midi_file(prompt)).to_array()
+    assert 10 < len(ids) < 500
+    out = str(tmp_path / "g") + "/"
+    generate.main(["-o", out, "-b", "2", "-l", "24", "--num-layers", "1", "--d-model", "128", "-M", "128", "-c", prompt,
+                   "-d", str(tmp_path / "none")])
+    log = capsys.readouterr().out
+    assert f"Prompt: {len(ids)} events" in log
+    files = sorted(glob.glob(out + "gen-*.mid"))
+    assert len(files) == 2
+    back = NoteSeq.from_midi_file(files[0]).notes
+    assert [n.pitch for n in back[:6]] == [60 + 2 * k for k in range(6)]            # the prompt's notes come first

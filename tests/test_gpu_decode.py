@@ -291,3 +291,63 @@ def test_cfg5_sized_cached_decode_matches_training_forward():
         assert torch.isfinite(got).all() and abs(got.sum(-1) - 1).max().item() < 1e-3
         assert (got - fwd).abs().max().item() < 1e-2, pos
         assert (got.argmax(-1) == fwd.argmax(-1)).float().mean().item() >= 0.9, pos
+
+
+def test_gru_train_packed_lengths_matches_torch_packed_gru():
+    """Event_Melody_RNN.Train(init, X, lengths) -- the reference's `sequence` mode (network.py:63-84, train.py:263-287):
+    against torch's own pack_padded_sequence -> nn.GRU -> pad_packed_sequence -> output_fc on the CPU in fp32, with the
+    same weights: valid steps match, steps past a row's end hold output_fc(0), the flattened rows pair with SeqBatchify's
+    labels, and every parameter gradient of the label loss agrees."""
+    from musicgeneration_amd.data import SeqBatchify, flatten_padded_sequences
+    from musicgeneration_amd.melody_rnn import Event_Melody_RNN
+    torch.manual_seed(8)
+    V, init_dim, H, nl = 52, 8, 64, 2
+    net = Event_Melody_RNN(init_dim=init_dim, event_dim=V, hidden_dim=H, rnn_layers=nl, dropout=0.0)
+    g = np.random.RandomState(8)
+    seqs = [g.randint(0, V - 1, size=n) for n in (11, 7, 11, 3, 9)]
+    X, Y, lengths = SeqBatchify(seqs)
+    B, Tmax = X.shape
+    init = torch.randn(B, init_dim)
+    # ---- torch reference (CPU, fp32), same parameters
+    ref = Event_Melody_RNN(init_dim=init_dim, event_dim=V, hidden_dim=H, rnn_layers=nl, dropout=0.0)
+    ref.load_state_dict(net.state_dict())
+    gru = torch.nn.GRU(V, H, num_layers=nl)
+    gru.load_state_dict({k[len("rnn."):]: v for k, v in ref.state_dict().items() if k.startswith("rnn.")})
+    for p in list(gru.parameters()) + [ref.event_embedding.weight, ref.output_fc.weight, ref.output_fc.bias,
+                                       ref.inithid_fc.weight, ref.inithid_fc.bias]:
+        p.requires_grad_(True)
+    hid0 = torch.tanh(torch.nn.functional.linear(init, ref.inithid_fc.weight, ref.inithid_fc.bias)).view(nl, B, H)
+    prim = torch.full((1, B), ref.primary_event, dtype=torch.long)
+    out1, hid1 = gru(ref.event_embedding(prim), hid0)
+    emb = ref.event_embedding(torch.from_numpy(X.astype(np.int64)).t())                 # [Tmax, B, E]
+    packed = torch.nn.utils.rnn.pack_padded_sequence(emb, torch.as_tensor(lengths), batch_first=False)
+    outp, _ = gru(packed, hid1)
+    outp, _ = torch.nn.utils.rnn.pad_packed_sequence(outp, total_length=Tmax)              # zero past each row's end
+    want = torch.nn.functional.linear(torch.cat([out1, outp], 0), ref.output_fc.weight, ref.output_fc.bias).transpose(0, 1)
+    # ---- the kernels
+    net = net.cuda().train()
+    got = net.Train(init.cuda(), torch.from_numpy(X.astype(np.int64)).cuda(), lengths)
+    assert got.shape == want.shape == (B, Tmax + 1, V)
+    assert (got.detach().cpu() - want.detach()).abs().max().item() < 3e-2
+    for i, n in enumerate(lengths):                       # steps past the end: exactly output_fc(0) = the bias
+        if n < Tmax:
+            assert torch.equal(got[i, n + 1:].detach().cpu(), net.output_fc.bias.detach().cpu().to(got.dtype).expand(Tmax - n, V))
+    # loss as the reference's sequence mode pairs it: row t of sample i (after consuming X[i, :t]) predicts X[i, t] ...
+    # the label vector of SeqBatchify is X[i, 1:len_i]: logits after the primary event and X[i, 0..t-1] -> steps 1..len-1
+    lab = torch.from_numpy(Y.astype(np.int64))
+    lw = flatten_padded_sequences(want[:, 1:], lengths)
+    lg = flatten_padded_sequences(got[:, 1:], lengths)
+    assert lw.shape == lg.shape == (int(sum(lengths) - B), V) and lab.numel() == lw.shape[0]
+    torch.nn.functional.cross_entropy(lw, lab).backward()
+    torch.nn.functional.cross_entropy(lg, lab.cuda()).backward()
+    refg = {"event_embedding.weight": ref.event_embedding.weight.grad, "output_fc.weight": ref.output_fc.weight.grad,
+            "output_fc.bias": ref.output_fc.bias.grad, "inithid_fc.weight": ref.inithid_fc.weight.grad}
+    refg.update({"rnn." + k: v.grad for k, v in gru.named_parameters()})
+    for name, prm in net.named_parameters():
+        if name not in refg:
+            continue
+        a, b = prm.grad.detach().cpu().flatten().double(), refg[name].flatten().double()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.99, f"{name}: cos {cos}"
+    with pytest.raises(ValueError):
+        net.Train(init.cuda(), torch.from_numpy(X.astype(np.int64)).t().cuda(), lengths)     # time-major + lengths: refused
