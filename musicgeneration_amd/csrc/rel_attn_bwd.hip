@@ -411,8 +411,9 @@ constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
 constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K  dO image R
 constexpr int OFF_OT = OFF_OR + 2 * TILE_BYTES;            // 2 x 4K  dO image T
-constexpr int OFF_ST = OFF_OT + 2 * TILE_BYTES;            // 2 x 256 B: lse2[32], delta[32]
-constexpr int OFF_BAND = OFF_ST + 2 * 256;                 // 4 x 8K fp32 [32][64]
+constexpr int ST_BYTES = 1024;                             // per buffer: lse2[32], delta[32] (+ 192 unread duplicates, see publish)
+constexpr int OFF_ST = OFF_OT + 2 * TILE_BYTES;            // 2 x 1 KB
+constexpr int OFF_BAND = OFF_ST + 2 * ST_BYTES;            // 4 x 8K fp32 [32][64]
 constexpr int OFF_FLAG = OFF_BAND + WAVES * 8192;          // "a key of this workgroup is padded" flag
 constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 66,064 B -> 2 workgroups per CU
 // The Er chunks (B operand of Q.Er^T: column t = lane&31, 16 contiguous bytes of row L-1-32q-t) are
@@ -451,10 +452,12 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     auto e_frag = [&](int q, int ks) {
         return __builtin_bit_cast(bf16x8, EfA[(size_t)(min(max(q, 0), nchunk - 1) * 4 + ks) * 64 + lane]);
     };
-    auto stat_src = [&](int t) {   // tid < 64: lse (0..31) / delta (32..63) of query tile t
-        const int i = J0 + 32 * min(t, nT - 1) + (tid & 31);
-        return (tid < 32) ? lse[stat_base + i] * LOG2E : delta[stat_base + i];
-    };
+    // lse (threads with tid&32 == 0) / delta (tid&32 != 0) of row (tid&31) of query tile t.  EVERY thread loads (threads
+    // 0..63 publish): a load under `if (tid < 64)` is a branch around VMEM, and where it rejoins the compiler drains the
+    // whole VMEM queue -- i.e. waits for the tile prefetch issued two instructions earlier, on every step.
+    const float* stat_ptr = ((tid & 32) ? delta : lse) + stat_base + (tid & 31);
+    const float stat_mul = (tid & 32) ? 1.f : LOG2E;
+    auto stat_src = [&](int t) { return stat_ptr[J0 + 32 * min(t, nT - 1)]; };     // raw; scaled by stat_mul when published
 
     {
         const u32x4 qq = scale8(*(const u32x4*)qg, 0.125f);
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         *(u32x4*)(smem + OFF_QT + st_offT) = qq;
         *(u32x4*)(smem + OFF_OR + st_offR) = oo;
         *(u32x4*)(smem + OFF_OT + st_offT) = oo;
-        if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0);
+        if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0) * stat_mul;
     }
     // E chunk fragments: a step's "hi" chunk (t - wk) sits in e[PAR], the "lo" chunk (t - wk - 1) in e[PAR^1]; the slot of
     // the lo chunk receives chunk t - wk + 1 once it has been used, which is the next step's hi chunk.  The main loop
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
                 for (int r = 0; r < 16; ++r) c[r] = -INFINITY;
             }
         }
-        const char* st = smem + OFF_ST + cur * 256;
+        const char* st = smem + OFF_ST + cur * ST_BYTES;
         f32x16 dp = zero16();
         const char* orr = smem + OFF_OR + cur * TILE_BYTES;
 #pragma unroll
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         const int tn = min(t + 1, nT - 1);
         qreg = *(const u32x4*)(qg + (size_t)tn * 32 * ld);
         oreg = *(const u32x4*)(og + (size_t)tn * 32 * d);
-        if (tid < 64) streg = stat_src(tn);
+        streg = stat_src(tn);
     };
     auto publish = [&](int nxt) {
         const u32x4 qq = scale8(qreg, 0.125f);
@@ -596,7 +599,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         *(u32x4*)(smem + OFF_QT + nxt * TILE_BYTES + st_offT) = qq;
         *(u32x4*)(smem + OFF_OR + nxt * TILE_BYTES + st_offR) = oreg;
         *(u32x4*)(smem + OFF_OT + nxt * TILE_BYTES + st_offT) = oreg;
-        if (tid < 64) *(float*)(smem + OFF_ST + nxt * 256 + tid * 4) = streg;
+        // every thread stores (threads >= 64 write duplicates nobody reads): a store under `tid < 64` pulls the load above
+        // into the branch, and the join then drains the VMEM queue behind the tile prefetch on every step
+        *(float*)(smem + OFF_ST + nxt * ST_BYTES + tid * 4) = streg * stat_mul;
     };
 
     // ---- general body: the diagonal 128 x 128 block (t < 4: a wave is not started / on its diagonal / full), every
@@ -894,6 +899,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
         a_qq[i] = qq;
     }
     u32x4 areg[4], qreg[2];
+    bool a_ok[4], q_ok[2];
     auto load_tiles = [&](int g) {
         const int bh = g / ns, i0 = d0 + (g - bh * ns) * RS;
         const int bb = bh / heads, hd = bh - bb * heads;
@@ -903,28 +909,33 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
         const size_t rb1 = (size_t)(I0 + 1) * 1024;        // row block I0+1 starts I0+1 tiles further
         const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + qch * 8;
         const bool second = i0 + 32 < L;                   // L % 64 may be 32: the step's second query block is absent
+        // Every load is unconditional (a guarded load is an exec-mask branch, and where it rejoins the compiler drains the
+        // VMEM queue): units that do not exist -- chunk above the row block's diagonal, second query block beyond L -- read a
+        // valid address instead (the step's first tile / the last row) and are zeroed when they are written to LDS.
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rb = i >> 1;                         // units 0,1 -> first query block, 2,3 -> second (u = tid + 256 i)
-            const bool ok = a_colok[i] && (rb == 0 || second) && ((d0 >> 5) + a_qq[i] <= I0 + rb);
-            areg[i] = ok ? __builtin_nontemporal_load((const u32x4*)(ap + a_src[i] + (rb ? rb1 : 0)))
-                         : u32x4{0, 0, 0, 0};              // read once: do not displace q in L2
+            a_ok[i] = a_colok[i] && (rb == 0 || second) && ((d0 >> 5) + a_qq[i] <= I0 + rb);
+            const size_t off = a_ok[i] ? (size_t)a_src[i] + (rb ? rb1 : 0) : (size_t)(a_src[i] & 1023);
+            areg[i] = __builtin_nontemporal_load((const u32x4*)(ap + off));      // read once: do not displace q in L2
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = qrow + 32 * i;
-            qreg[i] = (i0 + r < L) ? *(const u32x4*)(qp + (size_t)r * ld) : u32x4{0, 0, 0, 0};
+            q_ok[i] = i0 + r < L;
+            qreg[i] = *(const u32x4*)(qp + (size_t)min(r, L - 1 - i0) * ld);
         }
     };
     auto store_tiles = [&](int buf) {
         char* at = smem + OFF_A + buf * 4 * TILE_BYTES;
         char* qt = smem + OFF_Q + buf * 2 * TILE_BYTES;
+        const u32x4 zero = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(at + a_dst[i]) = areg[i];
+        for (int i = 0; i < 4; ++i) *(u32x4*)(at + a_dst[i]) = a_ok[i] ? areg[i] : zero;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = qrow + 32 * i;
-            *(u32x4*)(qt + (r >> 5) * TILE_BYTES + imgT_off(r & 31, qch)) = qreg[i];
+            *(u32x4*)(qt + (r >> 5) * TILE_BYTES + imgT_off(r & 31, qch)) = q_ok[i] ? qreg[i] : zero;
         }
     };
     f32x16 de0 = zero16(), de1 = zero16();
@@ -933,9 +944,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
         store_tiles(0);
     }
     __syncthreads();
-    for (int g = first; g < last; ++g) {
-        const int cur = (g - first) & 1;
-        if (g + 1 < last) load_tiles(g + 1);
+    auto multiply = [&](int cur) {
         const char* at = smem + OFF_A + cur * 4 * TILE_BYTES;
         const char* qt = smem + OFF_Q + cur * 2 * TILE_BYTES;
 #pragma unroll
@@ -945,9 +954,17 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
             de0 = mfma(af, frag_Tn(qs, lane, ks & 1, 0), de0);
             de1 = mfma(af, frag_Tn(qs, lane, ks & 1, 1), de1);
         }
-        if (g + 1 < last) store_tiles(cur ^ 1);
+    };
+    // all steps but the last: branch-free body (prefetch the next step's tiles first, multiply, publish)
+    for (int g = first; g + 1 < last; ++g) {
+        const int cur = (g - first) & 1;
+        load_tiles(g + 1);
+        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the products
+        multiply(cur);
+        store_tiles(cur ^ 1);
         __syncthreads();
     }
+    if (first < last) multiply((last - 1 - first) & 1);
     // flush: rows = distances 32w + crow(r,hh) of the tile, columns on lanes; q was not pre-scaled -> 1/8 here
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
