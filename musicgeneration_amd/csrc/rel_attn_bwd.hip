@@ -124,15 +124,18 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const u32x4* __restrict__ EfT,
     const uint32_t* __restrict__ padbits, const uint16_t* __restrict__ dctx, const float* __restrict__ lse,
     float* __restrict__ delta, uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel,
-    const uint16_t* __restrict__ ctx, int L, int d) {
+    const uint16_t* __restrict__ ctx, int L, int d, int bgroup) {
     using namespace k1;
     extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band stores XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;   // x = (b,h) fast, y = heaviness rank slow
-    const int qb = gridDim.y - 1 - blockIdx.y;
+    // x = (b,h) of one batch group [fast], y = (batch group, heaviness rank) [slow]: one group's tensors (~100 MB) stay
+    // inside the Infinity Cache while its workgroups run (see rel_attn_fwd.hip)
+    const int nqb = (L + 127) >> 7;
+    const int b = (blockIdx.y / nqb) * bgroup + blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int qb = nqb - 1 - (blockIdx.y % nqb);
     const int I0 = qb * 128, Q0 = I0 >> 5;
     const int nchunk = L >> 5;
     const bool wave_on = I0 + w * 32 < L;
@@ -424,15 +427,16 @@ constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 66,064 B -> 2 work
 __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
-    uint16_t* __restrict__ dqkv, int L, int d) {
+    uint16_t* __restrict__ dqkv, int L, int d, int bgroup) {
     using namespace k2;
     extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band reads XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bl = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
-    const int J0 = blockIdx.y * 128;                       // small J0 = longest sweep = dispatched first
+    const int nkb = (L + 127) >> 7;                        // y = (batch group, key block): groups as in the dQ kernel
+    const int b = (blockIdx.y / nkb) * bgroup + blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int J0 = (blockIdx.y % nkb) * 128;               // small J0 = longest sweep = dispatched first
     const int nchunk = L >> 5;
     const int nT = (L - J0) >> 5;                          // query tiles i0 = J0 + 32 t
     const bool wave_on = J0 + w * 32 < L;
@@ -852,18 +856,21 @@ constexpr int LDS_BYTES = OFF_Q + 2 * 2 * TILE_BYTES;      // 49,152 B -> 3 work
 
 __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dsrel, float* __restrict__ dEr /* = dE + (M-L)*64 */,
-    int B, int L, int d) {
+    int bgroup, int wg_per_group, int L, int d) {
     using namespace k3s;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int heads = d >> 6, nbh = B * heads;
+    const int heads = d >> 6, nbh = bgroup * heads;        // (b,h) pairs of ONE batch group
     const size_t ld = (size_t)3 * d;
-    // which distance tile, which slice of its flattened (bh, row-block) sweep: tiles are laid out heaviest first
+    // workgroup -> (batch group, distance tile, slice of the tile's flattened (bh, row-block) sweep).  Groups outermost:
+    // the 16 distance tiles of a group re-read that group's q rows (33 MB at cfg2) in quick succession instead of
+    // sweeping the whole batch's q once per distance tile; inside a group tiles are laid out heaviest first.
     int t = 0, first = 0, ns = 0;
+    const int grp = blockIdx.x / wg_per_group;
     {
-        int rest = blockIdx.x;
+        int rest = blockIdx.x - grp * wg_per_group;
         const int ntile = (L + DT - 1) / DT;
         for (t = 0; t < ntile; ++t) {
             ns = (L - t * DT + RS - 1) / RS;               // row blocks i0 = t*DT, +64, ... < L
@@ -901,7 +908,8 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
     u32x4 areg[4], qreg[2];
     bool a_ok[4], q_ok[2];
     auto load_tiles = [&](int g) {
-        const int bh = g / ns, i0 = d0 + (g - bh * ns) * RS;
+        const int bhl = g / ns, i0 = d0 + (g - bhl * ns) * RS;
+        const int bh = grp * nbh + bhl;                    // (b,h) index in the whole batch
         const int bb = bh / heads, hd = bh - bb * heads;
         // packed causal grid: row block I holds chunks 0..I at (bh*T + I(I+1)/2 + q) * 1024; chunks q > I are zeros
         const int I0 = i0 >> 5;
@@ -977,6 +985,14 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
     }
 }
 
+// batch rows per grid group: the largest divisor of B whose q/k/v/dO/ctx bytes stay near 100 MB (rel_attn_fwd.hip)
+static int bwd_batch_group(int B, int L, int d) {
+    const double per_row = (double)L * d * 2 * 5;
+    int g = B;
+    while (g > 1 && (g * per_row > 110e6 || B % g != 0)) --g;
+    return g;
+}
+
 static size_t ws_delta_bytes(int B, int L, int d) { return (((size_t)B * (d / 64) * L * 4) + 255) / 256 * 256; }
 
 static size_t ws_ert_bytes(int L) { return 2 * er_frag_bytes(L); }   // EfA | EfT
@@ -997,7 +1013,6 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     MGX_REQUIRE(qkv && E && ctx && dctx && lse && dqkv && dE && workspace, MGX_ERR_NULL, "mgx_rel_attn_bwd: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
                 "mgx_rel_attn_bwd: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", B, L, d, M);
-    MGX_REQUIRE((L + 127) / 128 <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L too large");
     MGX_REQUIRE(ws_bytes >= mgx_rel_attn_bwd_workspace(B, L, d) && ((uintptr_t)workspace & 255) == 0, MGX_ERR_SHAPE,
                 "mgx_rel_attn_bwd: workspace must be 256-byte aligned and >= mgx_rel_attn_bwd_workspace() = %zu bytes (got %zu)",
                 mgx_rel_attn_bwd_workspace(B, L, d), ws_bytes);
@@ -1029,23 +1044,25 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
         }
         launch_er_frag(Er, EfA, EfT, L, s);
     }
-    const dim3 gq(B * heads, (L + 127) / 128);
+    const int bg = bwd_batch_group(B, L, d);
+    MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
+    const dim3 gq(bg * heads, ((L + 127) / 128) * (B / bg));
     const bool export_ds = (parts & 8) || !(parts & 16);
     if (parts & 2) {
 #define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, \
-                                                   padbits, dctx, lse, delta, dqkv, dsrel, ctx, L, d)
+                                                   padbits, dctx, lse, delta, dqkv, dsrel, ctx, L, d, bg)
         if (export_ds) { if (dq_makes_delta) MGX_DQ_LAUNCH(true, true); else MGX_DQ_LAUNCH(true, false); }
         else           { if (dq_makes_delta) MGX_DQ_LAUNCH(false, true); else MGX_DQ_LAUNCH(false, false); }
 #undef MGX_DQ_LAUNCH
     }
-    if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, L, d);
+    if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, L, d, bg);
     if (parts & 8) {
-        long nwg = 0;
+        long nwg = 0;                                   // workgroups of ONE batch group
         for (int t = 0; t < (L + k3s::DT - 1) / k3s::DT; ++t)
-            nwg += ((long)B * heads * ((L - t * k3s::DT + k3s::RS - 1) / k3s::RS) + k3s::STEPS - 1) / k3s::STEPS;
-        MGX_REQUIRE(nwg < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
-        hipLaunchKernelGGL(rel_attn_de_stream_kernel, dim3((unsigned)nwg), dim3(256), k3s::LDS_BYTES, s, qkv, dsrel,
-                           dE + (size_t)(M - L) * 64, B, L, d);
+            nwg += ((long)bg * heads * ((L - t * k3s::DT + k3s::RS - 1) / k3s::RS) + k3s::STEPS - 1) / k3s::STEPS;
+        MGX_REQUIRE(nwg * (B / bg) < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
+        hipLaunchKernelGGL(rel_attn_de_stream_kernel, dim3((unsigned)(nwg * (B / bg))), dim3(256), k3s::LDS_BYTES, s, qkv, dsrel,
+                           dE + (size_t)(M - L) * 64, bg, (int)nwg, L, d);
     }
     if (parts & 16) {
         const dim3 ge(B * heads, ((L >> 5) + k3::W3 - 1) / k3::W3);

@@ -54,7 +54,7 @@ template <bool WRITE_W>
 __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ Ef /* fragment-ordered Er, see er_frag_kernel */,
     const uint32_t* __restrict__ padbits, uint16_t* __restrict__ ctx, float* __restrict__ lse_out,
-    const float* __restrict__ lse_in, float* __restrict__ weights, int L, int d) {
+    const float* __restrict__ lse_in, float* __restrict__ weights, int L, int d, int bgroup) {
     extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band stores XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,8 +63,12 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const int heads = d >> 6;
     // grid: x = (batch, head) [fast], y = query-block rank [slow], heaviest (latest) blocks first, so the
     // whole grid is dispatched longest-job-first; blocks of one (b,h) share an XCD when B*h % 8 == 0.
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
-    const int qb = gridDim.y - 1 - blockIdx.y;
+    // Batch groups: the grid's slow axis is (group of `bgroup` batch rows, query-block rank): one group's q, k, v and ctx
+    // (~100 MB) stay inside the 256 MB Infinity Cache while its workgroups run; with the whole cfg2 batch of 32 in one
+    // sweep (268 MB) the K/V re-reads of the 16 query blocks of a (b,h) fall through to HBM.
+    const int nqb = (L + 127) >> 7;
+    const int b = (blockIdx.y / nqb) * bgroup + blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int qb = nqb - 1 - (blockIdx.y % nqb);
     const int I0 = qb * 128, Q0 = I0 >> 5;
     const int nchunk = L >> 5;                           // number of 32-row chunks / key tiles
     const bool wave_on = I0 + w * 32 < L;
@@ -319,10 +323,18 @@ static void set_fwd_attrs() {
 
 extern "C" size_t mgx_rel_attn_fwd_workspace(int L) { return L > 0 ? er_frag_bytes(L) : 0; }
 
+// batch rows per grid group: the largest divisor of B whose q/k/v/ctx bytes stay near 100 MB (see the kernel)
+static int batch_group(int B, int L, int d) {
+    const double per_row = (double)L * d * 2 * 4;
+    int g = B;
+    while (g > 1 && (g * per_row > 110e6 || B % g != 0)) --g;
+    return g;
+}
+
 static int fwd_common_checks(const char* who, const void* ws, size_t ws_bytes, int B, int L, int d, int M) {
     MGX_REQUIRE(B > 0 && L > 0 && d > 0 && d % 64 == 0 && L % 32 == 0 && M >= L, MGX_ERR_SHAPE,
                 "%s: need d%%64==0, L%%32==0, M>=L (got B=%d L=%d d=%d M=%d)", who, B, L, d, M);
-    MGX_REQUIRE((L + 127) / 128 <= 65535, MGX_ERR_SHAPE, "%s: L too large", who);
+    MGX_REQUIRE((long)((L + 127) / 128) * B <= 65535, MGX_ERR_SHAPE, "%s: L/128 * B too large for the grid", who);
     MGX_REQUIRE(ws && ws_bytes >= er_frag_bytes(L) && ((uintptr_t)ws & 255) == 0, MGX_ERR_SHAPE,
                 "%s: workspace must be 256-byte aligned and >= mgx_rel_attn_fwd_workspace(L) = %zu bytes (got %zu)", who,
                 er_frag_bytes(L), ws_bytes);
@@ -335,9 +347,10 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
     if (int rc = fwd_common_checks("mgx_rel_attn_fwd", workspace, ws_bytes, B, L, d, M)) return rc;
     set_fwd_attrs();
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
-    dim3 grid(B * (d / 64), (L + 127) / 128);
+    const int bg = batch_group(B, L, d);
+    dim3 grid(bg * (d / 64), ((L + 127) / 128) * (B / bg));
     hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
-                       (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d);
+                       (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d, bg);
     MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");
     return MGX_OK;
 }
@@ -351,7 +364,7 @@ extern "C" int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, cons
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
     dim3 grid(B * (d / 64), (L + 127) / 128);
     hipLaunchKernelGGL(rel_attn_fwd_kernel<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
-                       (const u32x4*)workspace, padbits, (uint16_t*)nullptr, (float*)nullptr, lse, weights, L, d);
+                       (const u32x4*)workspace, padbits, (uint16_t*)nullptr, (float*)nullptr, lse, weights, L, d, B);
     MGX_CHECK_LAUNCH("mgx_rel_attn_weights");
     return MGX_OK;
 }
