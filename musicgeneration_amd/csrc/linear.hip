@@ -13,6 +13,7 @@
 //                                        buffer -- gradient accumulation across micro-batches for free.
 //   bias     gb += column sums of dY, folded into the dW kernel (its first k-tile column stages those rows anyway).
 #include <stdlib.h>
+#include <type_traits>
 #include "rel_attn_common.hpp"
 #include "mgx.h"
 
@@ -260,6 +261,309 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_fwd_kernel(const uin
 }
 
 // =================================================================================================
+// Ring kernel: C[M,NO] = A[M,R] . B^T  for the big projections (forward: B = W [NO,R]; dX: B = W [R,NO], BTRANS).
+//   * 256 x 256 output tile per workgroup, 8 waves (2 x 4), wave tile 128 x 64 (8 accumulator tiles): half the operand
+//     bytes per flop of the 128 x 128 kernels above.  Measured on the QKV projection (M = 65,536): those kernels spend
+//     108 of their 145 us just moving 1.6 GB of operand tiles from L2 into LDS.
+//   * operands go global -> LDS by DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR staging, no ds_write).
+//     The LDS destination of a DMA instruction is linear in the lane, so the bank swizzle of an image is applied on the
+//     SOURCE side: lane l of piece p fetches the 16 bytes that belong in slot 64 p + l.
+//   * reduction steps of 32, a ring of 4 stages (A 256 rows x 64 B + B 16 KB = 32 KB each): the request for step g+4 is
+//     made when step g's stage is released and is waited for three steps later with a COUNTED s_waitcnt (never 0 in the
+//     steady state) -- with two 64-wide stages the request had one step to land and the waves waited 1,400 cycles per step.
+//   * persistent workgroups (one per CU) walk their tiles as ONE stream of reduction steps: the DMA ring runs across tile
+//     boundaries, so a tile's epilogue overlaps the next tile's first requests.
+//   * inside a step every MFMA is followed by one fragment read of the NEXT block or one DMA piece (a wave issues in
+//     order: a group of reads or DMA issues ahead of the MFMAs holds them back for ~100-300 cycles per block).
+//   LDS: 4 x 32 KB stages + 8 x 4 KB epilogue patches = 160 KB.
+// =================================================================================================
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+MGX_DEV void glds16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)lds_wave_base, 16, 0, 0);
+}
+MGX_DEV void glds4(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)lds_wave_base, 4, 0, 0);
+}
+template <int N> MGX_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int RG_STAGE = 32768, RG_NST = 4, RG_PATCH = 4096;
+constexpr int RG_LDS = RG_NST * RG_STAGE + 8 * RG_PATCH;
+// image H (64-byte rows): 16-byte chunk c of row r at r*64 + ((c ^ ((r >> 2) & 3)) << 4): conflict-free ds_read_b128 of
+// (row = lane & 31, chunk = 2 ks + hh), and one DMA wave instruction = 16 whole rows.
+MGX_DEV int imgH_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// Epilogue of one wave: the C^T accumulators (n on registers, m on lanes) of its 128 (m) x 64 (n) block -> row-major bf16
+// through a 4 KB swizzled patch (32 rows x 128 B, 16-byte chunk c of row r at chunk c ^ (r & 7)): every global store
+// instruction writes 8 full 128-byte row segments.  bias / ReLU on the accumulator side; ReLU-backward mask and residual
+// addend on the row-major side (coalesced loads).  The block lies inside the matrix: 16 unconditional stores.
+MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restrict__ relu_y,
+                              const uint16_t* __restrict__ addend, f32x16 (&acc)[4][2], bool bias, int act, int mb,
+                              int nb, int N, int lane, char* patch) {
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int rr = lane >> 3, ch = lane & 7;
+    // bias: the wave's 64 values were put into its patch by DMA a tile ago (a vector load here would be waited for with
+    // the whole DMA ring ahead of it in the in-order VMEM queue); added in place before the patch is reused
+    if (bias) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 b = *(const f32x4*)(patch + (32 * ct + 8 * g4 + 4 * hh) * 4);
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt) {
+                    acc[rt][ct][4 * g4 + 0] += b.x; acc[rt][ct][4 * g4 + 1] += b.y;
+                    acc[rt][ct][4 * g4 + 2] += b.z; acc[rt][ct][4 * g4 + 3] += b.w;
+                }
+            }
+        wave_lds_fence();
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = acc[rt][ct][4 * g4 + k];
+                    if (act == 1) v[k] = fmaxf(v[k], 0.f);
+                }
+                *(u32x2*)(patch + l31 * 128 + (((4 * ct + g4) ^ (l31 & 7)) << 4) + 8 * hh) =
+                    u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        wave_lds_fence();
+        u32x4 o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rr + 8 * i;
+            o[i] = *(const u32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
+        }
+        if (relu_y || addend) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const size_t off = (size_t)(mb + 32 * rt + rr + 8 * i) * N + nb + ch * 8;
+                float f[8];
+                unpack8(o[i], f);
+                if (relu_y) {
+                    float y[8];
+                    unpack8(*(const u32x4*)(relu_y + off), y);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] = (y[k] > 0.f) ? f[k] : 0.f;
+                }
+                if (addend) {
+                    float a[8];
+                    unpack8(*(const u32x4*)(addend + off), a);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] += a[k];
+                }
+                o[i] = pack8(f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)(C + (size_t)(mb + 32 * rt + rr + 8 * i) * N + nb + ch * 8) = o[i];
+        }
+        wave_lds_fence();
+    }
+}
+
+#define MGX_SB() __builtin_amdgcn_sched_barrier(0)
+template <bool BTRANS>
+__global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                            const float* __restrict__ bias,
+                                                            const uint16_t* __restrict__ relu_y,
+                                                            const uint16_t* __restrict__ addend,
+                                                            uint16_t* __restrict__ C, int M, int NO, int R, int act) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ntn = (NO + 255) / 256, ntm = (M + 255) / 256, ntiles = ntm * ntn;
+    const int nh = R / 32;                                   // reduction steps per tile
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int G = my_tiles * nh;                             // steps of this workgroup, over all its tiles
+    char* patch = smem + RG_NST * RG_STAGE + w * RG_PATCH;
+    if (G <= 0) return;
+    auto tile_origin = [&](int i, int& m0, int& n0) {        // i-th tile of this workgroup
+        const int t = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles);
+        m0 = (t / ntn) * 256; n0 = (t % ntn) * 256;
+    };
+
+    // ---- DMA stream: wave w stages pieces 2w, 2w+1 of the A image and of the B image of every step ----
+    //  A piece p: rows 16p .. 16p+15 of the tile (64 bytes each).
+    //  B piece p, !BTRANS: the same for the rows of B;  BTRANS: the step's B tile is [32 r][256 n] = 4 sub-tiles [32][64]
+    //  (image T, 128-byte rows): piece p = rows 8 (p & 3) .. +7 of sub-tile p >> 2.
+    const uint16_t* ap[2];
+    const uint16_t* bp[2];
+    int d_i = -1, d_h = 0, d_st = 0, d_k0 = 0;
+    char* d_at = nullptr;
+    auto dma_begin = [&]() {                                 // addresses of the next request
+        if (d_h == 0) {
+            ++d_i;
+            int m0, n0;
+            tile_origin(d_i, m0, n0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = 2 * w + j;
+                const int row = 16 * p + (lane >> 2);
+                ap[j] = A + (size_t)min(m0 + row, M - 1) * R + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+                if (!BTRANS) {
+                    bp[j] = B + (size_t)min(n0 + row, NO - 1) * R + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+                } else {
+                    const int r = 8 * (p & 3) + (lane >> 3);
+                    const int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+                    bp[j] = B + (size_t)r * NO + min(n0 + 64 * (p >> 2) + chunk * 8, NO - 8);
+                }
+            }
+        }
+        d_at = smem + d_st * RG_STAGE + (2 * w) * 1024;
+        d_k0 = d_h * 32;
+        d_h = (d_h + 1 == nh) ? 0 : d_h + 1;
+        d_st = (d_st + 1) & 3;
+    };
+    auto b_src = [&](int j) { return BTRANS ? bp[j] + (size_t)d_k0 * NO : bp[j] + d_k0; };
+    auto dma_all = [&]() {
+        dma_begin();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(ap[j] + d_k0, d_at + j * 1024);
+            glds16(b_src(j), d_at + 16384 + j * 1024);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = zero16(); acc[i][1] = zero16(); }
+    bf16x8 fa[2][4], fb[2][2];
+    auto rd_a = [&](int stg, int ks, int i) {
+        return *(const bf16x8*)(smem + stg * RG_STAGE + imgH_off(128 * wm + 32 * i + l31, 2 * ks + hh));
+    };
+    auto rd_b = [&](int stg, int ks, int i) {      // !BTRANS
+        return *(const bf16x8*)(smem + stg * RG_STAGE + 16384 + imgH_off(64 * wn + 32 * i + l31, 2 * ks + hh));
+    };
+    // BTRANS: the B fragments are transposed reads (ds_read_b64_tr_b16 x 2) of sub-tile wn of the step's [32 r][256 n] tile.
+    // Through the builtin the compiler puts s_waitcnt vmcnt(0) in front of every such read while a DMA is in flight (it
+    // cannot tell the read from the DMA's LDS destination), which drains the ring twice per block: the reads are issued
+    // from inline asm instead.  The compiler does not count them, so (a) every block ends with an explicit
+    // s_waitcnt lgkmcnt(0) -- before any control flow, where register copies could be placed -- and (b) the two 64-bit halves
+    // are only joined into an operand after that wait.  tb[ct]: the lane's byte address of fragTn(sub-tile wn, ks = 0,
+    // column half ct) in stage 0 (see fragTn: row = 16 ks + 8 hh + 4 jq + rq; ks and jq are the immediate offset).
+    uint32_t tb[2] = {0u, 0u};
+    u32x2 hb[2][2][2];                                        // [set][ct][jq]
+    if (BTRANS) {
+        const int i15 = lane & 15, gq = lane >> 4, rq = i15 >> 2;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int chunk = 4 * ct + 2 * (gq & 1) + ((i15 & 3) >> 1);
+            tb[ct] = lds_addr_of(smem) + 16384 + wn * TILE_BYTES + (8 * hh + rq) * 128 +
+                     ((chunk ^ (((rq >> 1) & 1) << 2)) << 4) + 8 * (i15 & 1);
+        }
+    }
+    auto rd_bt = [&](int stg, auto ks_tag, int ct, u32x2 (&h)[2]) {
+        constexpr int KS = decltype(ks_tag)::value;
+        const uint32_t addr = tb[ct] + stg * RG_STAGE;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h[0]) : "v"(addr), "n"(2048 * KS));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h[1]) : "v"(addr), "n"(2048 * KS + 512));
+    };
+    auto join = [&](const u32x2 (&h)[2]) { return __builtin_bit_cast(bf16x8, u32x4{h[0].x, h[0].y, h[1].x, h[1].y}); };
+    // one block: the 8 MFMAs of fragment set `cur`; each gap carries one fragment read of the NEXT block (into set cur ^ 1)
+    // or one DMA piece
+    auto block = [&](auto cur_tag, int nstg, auto nks_tag, const uint16_t* g0, char* l0, const uint16_t* g1, char* l1, bool on) {
+        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1, NKS = decltype(nks_tag)::value;
+        const bf16x8(&a)[4] = fa[CUR];
+        bf16x8(&na)[4] = fa[NXT];
+        bf16x8 b[2];
+        if (BTRANS) { b[0] = join(hb[CUR][0]); b[1] = join(hb[CUR][1]); }
+        else { b[0] = fb[CUR][0]; b[1] = fb[CUR][1]; }
+        MGX_SB();
+        acc[0][0] = mfma(b[0], a[0], acc[0][0]); MGX_SB();
+        na[0] = rd_a(nstg, NKS, 0); MGX_SB();
+        acc[0][1] = mfma(b[1], a[0], acc[0][1]); MGX_SB();
+        if (BTRANS) rd_bt(nstg, nks_tag, 0, hb[NXT][0]); else fb[NXT][0] = rd_b(nstg, NKS, 0);
+        MGX_SB();
+        acc[1][0] = mfma(b[0], a[1], acc[1][0]); MGX_SB();
+        na[1] = rd_a(nstg, NKS, 1); MGX_SB();
+        if (on) glds16(g0, l0);
+        MGX_SB();
+        acc[1][1] = mfma(b[1], a[1], acc[1][1]); MGX_SB();
+        if (BTRANS) rd_bt(nstg, nks_tag, 1, hb[NXT][1]); else fb[NXT][1] = rd_b(nstg, NKS, 1);
+        MGX_SB();
+        acc[2][0] = mfma(b[0], a[2], acc[2][0]); MGX_SB();
+        na[2] = rd_a(nstg, NKS, 2); MGX_SB();
+        acc[2][1] = mfma(b[1], a[2], acc[2][1]); MGX_SB();
+        na[3] = rd_a(nstg, NKS, 3); MGX_SB();
+        if (on) glds16(g1, l1);
+        MGX_SB();
+        acc[3][0] = mfma(b[0], a[3], acc[3][0]); MGX_SB();
+        acc[3][1] = mfma(b[1], a[3], acc[3][1]); MGX_SB();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of the block has returned (asm reads included)
+        MGX_SB();
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+
+    // bias of tile i -> the wave's patch (64 floats): one more entry in the in-order VMEM queue, issued when the patch is
+    // free (right after the previous tile's epilogue); the counted waits below then leave at most one operation fewer
+    // outstanding than they could, which is always safe
+    auto dma_bias = [&](int i) {
+        int m0, n0;
+        tile_origin(i, m0, n0);
+        glds4(bias + min(n0 + 64 * wn + lane, NO - 1), patch);
+    };
+    // prologue: requests 0..3 (a stream shorter than that simply waits for everything)
+    if (bias) dma_bias(0);
+    dma_all();
+    if (G > 1) dma_all();
+    if (G > 2) dma_all();
+    if (G > 3) dma_all();
+    if (G > 3) wait_vmcnt<12>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[0][i] = rd_a(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (BTRANS) rd_bt(0, T0{}, i, hb[0][i]); else fb[0][i] = rd_b(0, 0, i);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MGX_SB();
+    int h = 0, ti = 0, since_epi = 2, cs = 0;
+    bool pend = false;                                       // the B pieces of the newest request are still to be issued
+    for (int g = 0; g < G; ++g) {
+        const int ns = (cs + 1) & 3;
+        // block 1: multiply (stage cs, k 0..15); its gaps read (cs, k 16..31) and issue the B pieces of the request made at
+        // the last barrier
+        block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend);
+        // (the block ended with lgkmcnt(0): this wave has read everything it needs from stage cs)
+        // step g+1 has landed once at most the younger operations are outstanding: requests g+2 and g+3 (4 each) and,
+        // for two steps after a tile's epilogue, its 16 stores
+        if (g + 3 < G) { if (since_epi < 2) wait_vmcnt<24>(); else wait_vmcnt<8>(); }
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        pend = (g + 4 < G);
+        if (pend) dma_begin();                                // request g+4 goes into the stage everyone has just left
+        // block 2: multiply (cs, k 16..31); its gaps read (ns, k 0..15) and issue the A pieces of the new request
+        block(T1{}, ns, T0{}, ap[0] + d_k0, d_at, ap[1] + d_k0, d_at + 1024, pend);
+        ++since_epi;
+        if (h == nh - 1) {
+            int m0, n0;
+            tile_origin(ti, m0, n0);
+            // (the host only takes this kernel for M % 256 == 0 and NO % 256 == 0: every tile is whole, 16 unconditional
+            //  stores per wave -- the count the waits above rely on)
+            store_wave_block(C, relu_y, addend, acc, bias != nullptr, act, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+            since_epi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[i][0] = zero16(); acc[i][1] = zero16(); }
+            ++ti;
+            if (bias && ti < my_tiles) dma_bias(ti);
+        }
+        h = (h + 1 == nh) ? 0 : h + 1;
+        cs = ns;
+    }
+}
+
+// =================================================================================================
 // dX = dY W   (NN; optional epilogue: dX *= (relu_y > 0), the backward of a fused ReLU; then dX += addend)
 //   tile: 128 rows m x 128 cols k', reduction over n in steps of 64
 //   LDS:  dY tile [128 m][64 n] image R;  W tile [64 n][128 k'] as 4 sub-tiles (2 n-blocks x 2 col halves)
@@ -380,41 +684,48 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
     // 8 distinct 16-byte slots of one sub-tile row (conflict-free), and global reads are 256-byte segments
     const int wrow = tid >> 4, ch = tid & 15;            // rows wrow + 16 i
     const int sub_c = ch >> 3, slot = ch & 7;
-    u32x4 areg[4], breg[4];
+    // Register staging, DEPTH tiles deep (EXACT path): a reduction step is 32 KB of operands for 512 MFMA cycles, and a load
+    // takes ~3,500 cycles to come back from beyond L2 with the chip streaming; with one tile in flight per workgroup and two
+    // workgroups per CU the step time WAS the load latency (3,650 cycles per step measured = 14 % MFMA-busy per workgroup).
+    // Three register sets keep three tiles in flight per workgroup while a fourth is multiplied out of LDS.
+    constexpr int DEPTH = EXACT ? 3 : 1;
+    u32x4 areg[DEPTH][4], breg[DEPTH][4];
     const uint16_t* ap = dY + (size_t)wrow * N + min(n0 + ch * 8, N - 8);
     const uint16_t* bp = X + (size_t)wrow * K + min(k0 + ch * 8, K - 8);
-    auto load_tiles = [&](int mm) {
+    auto load_tiles = [&](int mm, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
         const int gn = n0 + ch * 8, gk = k0 + ch * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (EXACT) {
-                areg[i] = *(const u32x4*)(ap + (size_t)(mm + 16 * i) * N);
-                breg[i] = *(const u32x4*)(bp + (size_t)(mm + 16 * i) * K);
+                areg[S][i] = *(const u32x4*)(ap + (size_t)(mm + 16 * i) * N);
+                breg[S][i] = *(const u32x4*)(bp + (size_t)(mm + 16 * i) * K);
             } else {
                 const int gm = mm + wrow + 16 * i;
-                areg[i] = (gm < mend && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
-                breg[i] = (gm < mend && gk < K) ? *(const u32x4*)(X + (size_t)gm * K + gk) : u32x4{0, 0, 0, 0};
+                areg[S][i] = (gm < mend && gn < N) ? *(const u32x4*)(dY + (size_t)gm * N + gn) : u32x4{0, 0, 0, 0};
+                breg[S][i] = (gm < mend && gk < K) ? *(const u32x4*)(X + (size_t)gm * K + gk) : u32x4{0, 0, 0, 0};
             }
         }
     };
     // bias gradient gb[n] += sum_m dY[m][n]: the workgroups of the first k-tile column add up the dY rows they stage anyway
     const bool do_bias = (gb != nullptr) && (tk == 0) && (!EXACT || n0 + ch * 8 < N);
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
         char* at = smem + buf * 2 * IMG;
         char* bt = at + IMG;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = wrow + 16 * i;
             const int off = ((row >> 5) * 2 + sub_c) * TILE_BYTES + imgT_off(row & 31, slot);
-            *(u32x4*)(at + off) = areg[i];
-            *(u32x4*)(bt + off) = breg[i];
+            *(u32x4*)(at + off) = areg[S][i];
+            *(u32x4*)(bt + off) = breg[S][i];
         }
         if (do_bias) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float f[8];
-                unpack8(areg[i], f);
+                unpack8(areg[S][i], f);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) bsum[k] += f[k];
             }
@@ -423,11 +734,6 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
     f32x16 acc[2][2];
     zero_acc(acc);
     const int nm = (mend - mbeg + BK - 1) / BK;
-    if (nm > 0) {
-        load_tiles(mbeg);
-        store_tiles(0);
-    }
-    __syncthreads();
     auto multiply = [&](int cur) {
         const char* at = smem + cur * 2 * IMG;
         const char* bt = at + IMG;
@@ -445,15 +751,57 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
             acc[1][1] = mfma(a1, b1, acc[1][1]);
         }
     };
-    for (int mt = 0; mt + 1 < nm; ++mt) {                // all reduction tiles but the last: branch-free body
-        const int cur = mt & 1;
-        load_tiles(mbeg + (mt + 1) * BK);
-        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch AHEAD of the MFMAs
-        multiply(cur);
-        store_tiles(cur ^ 1);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, (DEPTH > 1 ? 1 : 0)>;
+    using S2 = std::integral_constant<int, (DEPTH > 2 ? 2 : 0)>;
+    if (EXACT) {
+        // tile t lives in register set t % 3 until it is written to LDS buffer t & 1.  Loads are clamped to the last tile
+        // (the surplus ones are never stored).
+        auto tile_row = [&](int t) { return mbeg + min(t, nm - 1) * BK; };
+        if (nm > 0) {
+            load_tiles(tile_row(0), S0{});
+            load_tiles(tile_row(1), S1{});
+            load_tiles(tile_row(2), S2{});
+            store_tiles(0, S0{});
+            load_tiles(tile_row(3), S0{});
+        }
         __syncthreads();
+        // one reduction step: multiply tile t, publish tile t+1 (its set has arrived: two younger tiles stay in flight),
+        // refill that set with tile t+4
+        auto step = [&](int t, auto set_tag) {
+            multiply(t & 1);
+            store_tiles((t + 1) & 1, set_tag);
+            __syncthreads();
+            load_tiles(tile_row(t + 4), set_tag);
+        };
+        int t = 0;
+        for (; t + 3 <= nm - 1; t += 3) {                // branch-free: the set of tile t+1 is (t+1) % 3 = 1, 2, 0
+            step(t, S1{});
+            step(t + 1, S2{});
+            step(t + 2, S0{});
+        }
+        if (t < nm - 1) {
+            step(t, S1{});
+            ++t;
+            if (t < nm - 1) { step(t, S2{}); ++t; }
+        }
+        if (nm > 0) multiply((nm - 1) & 1);
+    } else {
+        if (nm > 0) {
+            load_tiles(mbeg, S0{});
+            store_tiles(0, S0{});
+        }
+        __syncthreads();
+        for (int mt = 0; mt + 1 < nm; ++mt) {
+            const int cur = mt & 1;
+            load_tiles(mbeg + (mt + 1) * BK, S0{});
+            __builtin_amdgcn_sched_barrier(0);               // keep the prefetch AHEAD of the MFMAs
+            multiply(cur);
+            store_tiles(cur ^ 1, S0{});
+            __syncthreads();
+        }
+        if (nm > 0) multiply((nm - 1) & 1);
     }
-    if (nm > 0) multiply((nm - 1) & 1);
     if (do_bias) {      // lanes with equal (tid & 15) hold the same 8 columns: fold lane bits 4,5, then one atomic per wave
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -665,11 +1013,34 @@ static bool g_attr_set = false;
 static void set_attrs() {
     if (g_attr_set) return;
     hipFuncSetAttribute((const void*)linear_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipFuncSetAttribute((const void*)linear_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+    hipFuncSetAttribute((const void*)linear_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     g_attr_set = true;
+}
+
+// The ring kernel pays when its 256 x 256 tiles fill the chip (one persistent workgroup per CU) without much padding.
+// MGX_GEMM_RING=0 / 1 forces it off / on where the shape allows (A/B timing).
+static int ring_grid(int M, int NO, int R) {
+    static int cus = 0, env = -2;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        hipGetDevice(&dev);
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        const char* e = getenv("MGX_GEMM_RING");
+        env = e ? atoi(e) : -1;
+    }
+    if (env == 0 || R % 32 != 0 || R < 128 || M % 256 != 0 || NO % 256 != 0) return 0;     // whole tiles only
+    const long ntm = (M + 255) / 256, ntn = (NO + 255) / 256;
+    const long ntiles = ntm * ntn;
+    if (env != 1) {
+        if (ntiles * 4 < (long)cus * 3) return 0;                                    // < 3/4 of the CUs busy
+    }
+    return (int)(ntiles < cus ? ntiles : cus);
 }
 
 extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C, int M, int N,
@@ -682,6 +1053,12 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
     if (M <= 32) {      // decode-size batches: weight-streaming skinny kernel
         hipLaunchKernelGGL(linear_skinny_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, W, bias, C, M, N,
                            K, act);
+        MGX_CHECK_LAUNCH("mgx_linear_fwd");
+        return MGX_OK;
+    }
+    if (const int rg = ring_grid(M, N, K)) {
+        hipLaunchKernelGGL(linear_ring_kernel<false>, dim3(rg), dim3(512), RG_LDS, (hipStream_t)stream, A, W, bias,
+                           (const uint16_t*)nullptr, (const uint16_t*)nullptr, C, M, N, K, act);
         MGX_CHECK_LAUNCH("mgx_linear_fwd");
         return MGX_OK;
     }
@@ -707,6 +1084,12 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
     MGX_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, MGX_ERR_SHAPE,
                 "mgx_linear_dx: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
     set_attrs();
+    if (const int rg = ring_grid(M, K, N)) {          // dX [M,K] = dY [M,N] . W [N,K]: reduction over N, W read transposed
+        hipLaunchKernelGGL(linear_ring_kernel<true>, dim3(rg), dim3(512), RG_LDS, (hipStream_t)stream, dY, W,
+                           (const float*)nullptr, relu_y, addend, dX, M, K, N, 0);
+        MGX_CHECK_LAUNCH("mgx_linear_dx");
+        return MGX_OK;
+    }
     const int nwg = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
     static int sbuf_env = -2;
     if (sbuf_env == -2) { const char* e = getenv("MGX_GEMM_SINGLE_BUF"); sbuf_env = e ? atoi(e) : -1; }

@@ -231,8 +231,27 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
             gg[c][k] = (col < d) ? gamma[col + k] : 0.f;
         }
     }
+    // The rows of a wave are a dependent chain of (load 3 x 16 B per lane, two wave reductions, store): with one row in
+    // flight per wave the kernel ran at half the HBM rate.  The next row's operands are requested before the current row
+    // is reduced (clamped index, unconditional: a load under a branch would be waited for at the join).
+    u32x4 ra[NC], rb[NC], rd[NC];
+    float mean = 0.f, rstd = 0.f;
+    auto fetch = [&](int r, u32x4 (&a)[NC], u32x4 (&b)[NC], u32x4 (&dy)[NC], float& mn, float& rs) {
+        const int rc = min(r, rows - 1);
+        mn = mean_i[rc]; rs = rstd_i[rc];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = min(c * 512 + lane * 8, d - 8);
+            a[c] = *(const u32x4*)(x + (size_t)rc * d + col);
+            b[c] = *(const u32x4*)(res + (size_t)rc * d + col);
+            dy[c] = *(const u32x4*)(dout + (size_t)rc * d + col);
+        }
+    };
+    if (wave < rows) fetch(wave, ra, rb, rd, mean, rstd);
     for (int r = wave; r < rows; r += nwave) {
-        const float mean = mean_i[r], rstd = rstd_i[r];
+        u32x4 na[NC], nb[NC], nd[NC];
+        float nmean, nrstd;
+        fetch(r + nwave, na, nb, nd, nmean, nrstd);
         float xh[NC][8], g[NC][8], mult[NC][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -240,9 +259,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
             const int col = c * 512 + lane * 8;
             if (col < d) {
                 float a[8], b[8], dy[8];
-                unpack8(*(const u32x4*)(x + (size_t)r * d + col), a);
-                unpack8(*(const u32x4*)(res + (size_t)r * d + col), b);
-                unpack8(*(const u32x4*)(dout + (size_t)r * d + col), dy);
+                unpack8(ra[c], a);
+                unpack8(rb[c], b);
+                unpack8(rd[c], dy);
                 if (dc.thr16) drop_mult8(dc, (uint32_t)((size_t)r * gpr + (col >> 3)), mult[c]);
                 else {
 #pragma unroll
@@ -285,6 +304,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(
                 }
             }
         }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ra[c] = na[c]; rb[c] = nb[c]; rd[c] = nd[c]; }
+        mean = nmean; rstd = nrstd;
     }
     // block reduce of the column partials over the 4 waves, one plain store per column
     __shared__ float red[4][512];
@@ -346,7 +368,7 @@ static void launch_ln_fwd(const uint16_t* x, const uint16_t* res, const float* g
     hipLaunchKernelGGL(add_ln_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, x, res, gamma, beta, out, mean, rstd,
                        rows, d, eps, dc);
 }
-constexpr int LN_BWD_BLOCKS = 512;
+constexpr int LN_BWD_BLOCKS = 1024;
 
 template <int NC>
 static void launch_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,

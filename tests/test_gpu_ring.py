@@ -1,0 +1,79 @@
+"""The 256 x 256 ring GEMM (linear.hip: linear_ring_kernel) against the 128 x 128 kernels it replaces for the big projections:
+same inputs through both paths in two child processes (the path is chosen once per process, MGX_GEMM_RING), outputs
+compared BIT FOR BIT (both accumulate the reduction in the same order), and against an fp32 torch reference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, os, torch, numpy as np
+sys.path.insert(0, sys.argv[1])
+from musicgeneration_amd import _lib
+from musicgeneration_amd.ops import ptr, stream_ptr, check
+lib = _lib.load()
+dev = "cuda:0"
+out = {}
+g = torch.Generator(device="cpu").manual_seed(7)
+def rnd(*s): return (torch.randn(*s, generator=g) * 0.5).to(dev).bfloat16()
+# forward: (M, N, K, bias, act)
+for i, (M, N, K, use_b, act) in enumerate([(512, 256, 128, True, 0), (768, 512, 256, True, 1), (1024, 256, 512, False, 0),
+                                           (2048, 1536, 512, True, 0), (256, 256, 192, True, 0)]):
+    A, W = rnd(M, K), rnd(N, K)
+    b = (torch.randn(N, generator=g)).to(dev) if use_b else None
+    C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    check(lib.mgx_linear_fwd(ptr(A), ptr(W), ptr(b), ptr(C), M, N, K, act, stream_ptr()), "fwd")
+    ref = A.float() @ W.float().t() + (b if use_b else 0)
+    if act: ref = ref.relu()
+    out[f"fwd{i}"] = C.view(torch.int16).cpu().numpy()
+    out[f"fwd{i}_ref"] = ref.cpu().numpy()
+# dX: (M, N(reduction), K(out), relu mask, addend)
+for i, (M, N, K, use_y, use_add) in enumerate([(512, 128, 256, False, False), (768, 256, 512, True, False),
+                                               (1024, 1536, 512, False, True), (512, 512, 256, True, True)]):
+    dY, W = rnd(M, N), rnd(N, K)
+    y = rnd(M, K) if use_y else None
+    add = rnd(M, K) if use_add else None
+    dX = torch.empty(M, K, device=dev, dtype=torch.bfloat16)
+    check(lib.mgx_linear_dx(ptr(dY), ptr(W), ptr(y), ptr(add), ptr(dX), M, N, K, stream_ptr()), "dx")
+    ref = dY.float() @ W.float()
+    if use_y: ref = ref * (y.float() > 0)
+    if use_add: ref = ref.bfloat16().float() * 0 + (dY.float() @ W.float()) * ((y.float() > 0) if use_y else 1.0)  # mask first
+    out[f"dx{i}"] = dX.view(torch.int16).cpu().numpy()
+    out[f"dx{i}_ref"] = ref.cpu().numpy()
+    if use_add: out[f"dx{i}_add"] = add.float().cpu().numpy()
+torch.cuda.synchronize()
+np.savez(sys.argv[2], **out)
+'''
+
+
+def _run(ring, path):
+    env = dict(os.environ, MGX_GEMM_RING=str(ring))
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, path], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(path)
+
+
+def _bf16(a):
+    return (a.astype(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def test_ring_matches_tiled_kernels_bitwise(tmp_path):
+    old = _run(0, str(tmp_path / "old.npz"))
+    new = _run(1, str(tmp_path / "new.npz"))
+    for k in old.files:
+        if k.endswith("_ref") or k.endswith("_add"):
+            continue
+        assert np.array_equal(old[k], new[k]), f"{k}: ring kernel differs from the 128x128 kernel"
+        got = _bf16(new[k].view(np.uint16))
+        ref = new[k + "_ref"]
+        if k + "_add" in new.files:
+            # the kernel rounds the (masked) product to bf16 and adds the bf16 addend in fp32, then rounds once more
+            ref = ref + new[k + "_add"]
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-6)
+        assert err < 2e-2, f"{k}: relative error {err:.3e} vs fp32 reference"
