@@ -69,7 +69,7 @@ def test_shape_errors_have_messages():
     # delta f32 [B,h,L] + two fragment-ordered bf16 copies of E [L,64] + the causal half of dS by (query, distance):
     # 64*65/2 tiles of 32x32 bf16 per (b,h)
     assert lib.mgx_rel_attn_bwd_workspace(8, 2048, 512) == 8 * 8 * 2048 * 4 + 2 * 64 * 2048 * 2 + 8 * 8 * (64 * 65 // 2) * 2048
-    assert lib.mgx_add_ln_bwd_workspace(100, 512) == 512 * 3 * 512 * 4
+    assert lib.mgx_add_ln_bwd_workspace(100, 512) == 1024 * 3 * 512 * 4      # 1,024 blocks of column partials
     rc = lib.mgx_add_ln_bwd(one, one, one, one, one, one, one, one, one, one, None, one, 16, 8, 512, 0.0, 0, None)
     assert rc == -1 and b"workspace" in lib.mgx_last_error()
 
