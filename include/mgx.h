@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K) */
-#define MGX_ABI_VERSION 9
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace */
+#define MGX_ABI_VERSION 10
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -168,7 +168,11 @@ typedef struct mgx_dw_problem {
     float* gb;            /* f32 [N], accumulated, or NULL */
     int N, K;
 } mgx_dw_problem;
-int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* stream);
+/* workspace: caller scratch >= mgx_linear_dw_grouped_workspace(problems, count, M) bytes, 16-byte aligned (fp32 partial
+ * tiles of the M-splits; 0 when the group runs on the tiled kernel, NULL is accepted then).                             */
+size_t mgx_linear_dw_grouped_workspace(const mgx_dw_problem* problems, int count, int M);
+int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* workspace, size_t ws_bytes,
+                          void* stream);
 
 /* ---- K12: autoregressive decode with a KV cache (replaces the per-token full-window recompute of
  * network.py:52-77; causal semantics).  The current position t lives in device memory

@@ -478,22 +478,25 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         if (BTRANS) { b[0] = join(hb[CUR][0]); b[1] = join(hb[CUR][1]); }
         else { b[0] = fb[CUR][0]; b[1] = fb[CUR][1]; }
         MGX_SB();
+        // reads in the first three gaps (two per gap), DMA pieces in gaps 3 and 5: by the end of the block the reads have had
+        // five MFMAs to return
         acc[0][0] = mfma(b[0], a[0], acc[0][0]); MGX_SB();
-        na[0] = rd_a(nstg, NKS, 0); MGX_SB();
-        acc[0][1] = mfma(b[1], a[0], acc[0][1]); MGX_SB();
+        na[0] = rd_a(nstg, NKS, 0);
         if (BTRANS) rd_bt(nstg, nks_tag, 0, hb[NXT][0]); else fb[NXT][0] = rd_b(nstg, NKS, 0);
         MGX_SB();
-        acc[1][0] = mfma(b[0], a[1], acc[1][0]); MGX_SB();
-        na[1] = rd_a(nstg, NKS, 1); MGX_SB();
-        if (on) glds16(g0, l0);
-        MGX_SB();
-        acc[1][1] = mfma(b[1], a[1], acc[1][1]); MGX_SB();
+        acc[0][1] = mfma(b[1], a[0], acc[0][1]); MGX_SB();
+        na[1] = rd_a(nstg, NKS, 1);
         if (BTRANS) rd_bt(nstg, nks_tag, 1, hb[NXT][1]); else fb[NXT][1] = rd_b(nstg, NKS, 1);
         MGX_SB();
+        acc[1][0] = mfma(b[0], a[1], acc[1][0]); MGX_SB();
+        na[2] = rd_a(nstg, NKS, 2);
+        na[3] = rd_a(nstg, NKS, 3);
+        MGX_SB();
+        acc[1][1] = mfma(b[1], a[1], acc[1][1]); MGX_SB();
+        if (on) glds16(g0, l0);
+        MGX_SB();
         acc[2][0] = mfma(b[0], a[2], acc[2][0]); MGX_SB();
-        na[2] = rd_a(nstg, NKS, 2); MGX_SB();
         acc[2][1] = mfma(b[1], a[2], acc[2][1]); MGX_SB();
-        na[3] = rd_a(nstg, NKS, 3); MGX_SB();
         if (on) glds16(g1, l1);
         MGX_SB();
         acc[3][0] = mfma(b[0], a[3], acc[3][0]); MGX_SB();
@@ -870,6 +873,234 @@ __global__ __launch_bounds__(256, 2) void linear_dw_grouped_kernel(const DwGroup
 }
 
 // =================================================================================================
+// Ring kernel for the weight gradients of one encoder block:  gW[N,K] += dY^T X  (TN), same structure as
+// linear_ring_kernel (256 x 256 tile, 8 waves, 4-stage DMA ring, reduction steps of 32 rows m), one (tile, M-split) unit per
+// workgroup.  Both operand tiles of a step are [32 m][256 cols] = 4 sub-tiles [32][64] (image T), and every fragment
+// is a transposed read (ds_read_b64_tr_b16 x 2, issued from inline asm: see linear_ring_kernel).
+// A unit leaves its 256 x 256 fp32 partial in the workspace with plain stores (row-major, through the wave's LDS patch);
+// dw_fixup_kernel then adds the splits of a tile into gW.  (fp32 atomics run at ~1.3 TB/s chip-wide and stall the issuing
+// waves: 63 MB of partials per block would cost ~48 us of every CU's time, plain stores + the fix-up pass ~20.)
+// Bias gradient gb[n] += sum_m dY[m][n]: the waves of the first k-tile column with wn == 0 add up the dY fragments they
+// hold anyway (v_dot2c_f32_bf16 against (1, 1)).
+// =================================================================================================
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+struct DwRing {
+    const uint16_t* dY[MGX_DW_MAX_GROUP];
+    const uint16_t* X[MGX_DW_MAX_GROUP];
+    float* gW[MGX_DW_MAX_GROUP];
+    float* gb[MGX_DW_MAX_GROUP];
+    int N[MGX_DW_MAX_GROUP], K[MGX_DW_MAX_GROUP];
+    int first_tile[MGX_DW_MAX_GROUP + 1];                  // prefix sums of the 256 x 256 tile counts
+    int n, splits, steps_per_split;
+};
+
+__global__ __launch_bounds__(512, 1) void linear_dw_ring_kernel(const DwRing g, int M, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int unit = blockIdx.x;
+    const int t = unit / g.splits, sp = unit % g.splits;
+    int p = 0;
+    while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
+    const int N = g.N[p], K = g.K[p];
+    const int ntk = K >> 8, tl = t - g.first_tile[p];
+    const int n0 = (tl / ntk) << 8, k0 = (tl % ntk) << 8;
+    const int total = M >> 5;
+    const int s0 = sp * g.steps_per_split;
+    const int G = min(total, s0 + g.steps_per_split) - s0;   // >= 1 (host)
+    char* patch = smem + RG_NST * RG_STAGE + w * RG_PATCH;
+
+    // ---- DMA stream: piece q = 2w + j of an operand image = rows 8 (q & 3) .. +7 of sub-tile q >> 2 ----
+    const uint16_t* ap[2];
+    const uint16_t* bp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = 2 * w + j;
+        const int r = 8 * (q & 3) + (lane >> 3);
+        const int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+        ap[j] = g.dY[p] + (size_t)(s0 * 32 + r) * N + n0 + 64 * (q >> 2) + chunk * 8;
+        bp[j] = g.X[p] + (size_t)(s0 * 32 + r) * K + k0 + 64 * (q >> 2) + chunk * 8;
+    }
+    int d_st = 0;
+    char* d_at = nullptr;
+    const uint16_t* da[2] = {nullptr, nullptr};
+    const uint16_t* db[2] = {nullptr, nullptr};
+    auto dma_begin = [&]() {                                 // addresses of the next request, pointers move one step on
+        d_at = smem + d_st * RG_STAGE + (2 * w) * 1024;
+        d_st = (d_st + 1) & 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            da[j] = ap[j]; db[j] = bp[j];
+            ap[j] += (size_t)32 * N; bp[j] += (size_t)32 * K;
+        }
+    };
+    auto dma_all = [&]() {
+        dma_begin();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            glds16(da[j], d_at + j * 1024);
+            glds16(db[j], d_at + 16384 + j * 1024);
+        }
+    };
+    // ---- fragments: transposed reads; ta[ct] / tbb[ct] = the lane's address of fragTn(first sub-tile of the wave, ks = 0,
+    //      column half ct) in stage 0; the immediate offset adds ks, jq and (for the A operand) the second sub-tile ----
+    uint32_t ta[2], tbb[2];
+    {
+        const int i15 = lane & 15, gq = lane >> 4, rq = i15 >> 2;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int chunk = 4 * ct + 2 * (gq & 1) + ((i15 & 3) >> 1);
+            const uint32_t in_tile = (8 * hh + rq) * 128 + ((chunk ^ (((rq >> 1) & 1) << 2)) << 4) + 8 * (i15 & 1);
+            ta[ct] = lds_addr_of(smem) + 2 * wm * TILE_BYTES + in_tile;
+            tbb[ct] = lds_addr_of(smem) + 16384 + wn * TILE_BYTES + in_tile;
+        }
+    }
+    u32x2 ha[2][4][2], hb[2][2][2];                           // [set][fragment][jq]
+    auto rd_at = [&](int stg, auto ks_tag, auto i_tag, u32x2 (&h)[2]) {
+        constexpr int KS = decltype(ks_tag)::value, I = decltype(i_tag)::value;
+        const uint32_t addr = ta[I & 1] + stg * RG_STAGE;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h[0]) : "v"(addr), "n"(2048 * KS + 4096 * (I >> 1)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h[1]) : "v"(addr), "n"(2048 * KS + 4096 * (I >> 1) + 512));
+    };
+    auto rd_bt = [&](int stg, auto ks_tag, int ct, u32x2 (&h)[2]) {
+        constexpr int KS = decltype(ks_tag)::value;
+        const uint32_t addr = tbb[ct] + stg * RG_STAGE;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h[0]) : "v"(addr), "n"(2048 * KS));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h[1]) : "v"(addr), "n"(2048 * KS + 512));
+    };
+    auto join = [&](const u32x2 (&h)[2]) { return __builtin_bit_cast(bf16x8, u32x4{h[0].x, h[0].y, h[1].x, h[1].y}); };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = zero16(); acc[i][1] = zero16(); }
+    const bool do_bias = __builtin_amdgcn_readfirstlane((g.gb[p] != nullptr) && k0 == 0 && wn == 0);
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using T2 = std::integral_constant<int, 2>;
+    using T3 = std::integral_constant<int, 3>;
+    auto block = [&](auto cur_tag, int nstg, auto nks_tag, const uint16_t* g0, char* l0, const uint16_t* g1, char* l1, bool on) {
+        constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1;
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = join(ha[CUR][i]);
+        b[0] = join(hb[CUR][0]); b[1] = join(hb[CUR][1]);
+        MGX_SB();
+        acc[0][0] = mfma(b[0], a[0], acc[0][0]); MGX_SB();
+        rd_at(nstg, nks_tag, T0{}, ha[NXT][0]);
+        rd_bt(nstg, nks_tag, 0, hb[NXT][0]);
+        MGX_SB();
+        acc[0][1] = mfma(b[1], a[0], acc[0][1]); MGX_SB();
+        rd_at(nstg, nks_tag, T1{}, ha[NXT][1]);
+        rd_bt(nstg, nks_tag, 1, hb[NXT][1]);
+        MGX_SB();
+        acc[1][0] = mfma(b[0], a[1], acc[1][0]); MGX_SB();
+        rd_at(nstg, nks_tag, T2{}, ha[NXT][2]);
+        rd_at(nstg, nks_tag, T3{}, ha[NXT][3]);
+        MGX_SB();
+        acc[1][1] = mfma(b[1], a[1], acc[1][1]); MGX_SB();
+        if (on) glds16(g0, l0);
+        MGX_SB();
+        acc[2][0] = mfma(b[0], a[2], acc[2][0]); MGX_SB();
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // (element pairs by shufflevector: indexing a u32x4 view of the fragment inside an unrolled loop made
+                //  hipcc 7.2 feed the FIRST dword to all four dot products)
+                const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+                gsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 0, 1), one, gsum[i], false);
+                gsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 2, 3), one, gsum[i], false);
+                gsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 4, 5), one, gsum[i], false);
+                gsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a[i], a[i], 6, 7), one, gsum[i], false);
+            }
+        }
+        MGX_SB();
+        acc[2][1] = mfma(b[1], a[2], acc[2][1]); MGX_SB();
+        if (on) glds16(g1, l1);
+        MGX_SB();
+        acc[3][0] = mfma(b[0], a[3], acc[3][0]); MGX_SB();
+        acc[3][1] = mfma(b[1], a[3], acc[3][1]); MGX_SB();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every transposed read of the block has returned
+        MGX_SB();
+    };
+
+    dma_all();
+    if (G > 1) dma_all();
+    if (G > 2) dma_all();
+    if (G > 3) dma_all();
+    if (G > 3) wait_vmcnt<12>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    rd_at(0, T0{}, T0{}, ha[0][0]); rd_at(0, T0{}, T1{}, ha[0][1]); rd_at(0, T0{}, T2{}, ha[0][2]); rd_at(0, T0{}, T3{}, ha[0][3]);
+    rd_bt(0, T0{}, 0, hb[0][0]); rd_bt(0, T0{}, 1, hb[0][1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MGX_SB();
+    int cs = 0;
+    bool pend = false;
+    for (int s = 0; s < G; ++s) {
+        const int ns = (cs + 1) & 3;
+        block(T0{}, cs, T1{}, db[0], d_at + 16384, db[1], d_at + 16384 + 1024, pend);
+        if (s + 3 < G) wait_vmcnt<8>(); else wait_vmcnt<0>();   // step s+1 has landed (requests s+2, s+3 may be outstanding)
+        __builtin_amdgcn_s_barrier();
+        pend = (s + 4 < G);
+        if (pend) dma_begin();
+        block(T1{}, ns, T0{}, da[0], d_at, da[1], d_at + 1024, pend);
+        cs = ns;
+    }
+
+    // ---- epilogue: fp32 partial tile -> workspace, row-major [n][k], 128-byte row segments per 8 lanes ----
+    float* wsu = ws + (size_t)unit * 65536;
+    const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *(f32x4*)(patch + l31 * 128 + (((2 * g4 + hh) ^ (l31 & 7)) << 4)) =
+                    f32x4{acc[rt][ct][4 * g4], acc[rt][ct][4 * g4 + 1], acc[rt][ct][4 * g4 + 2], acc[rt][ct][4 * g4 + 3]};
+            wave_lds_fence();
+            f32x4 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rr + 8 * i;
+                o[i] = *(const f32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(f32x4*)(wsu + (size_t)(128 * wm + 32 * rt + rr + 8 * i) * 256 + 64 * wn + 32 * ct + 4 * ch) = o[i];
+            wave_lds_fence();
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = gsum[i] + __shfl_xor(gsum[i], 32, 64);
+            if (hh == 0) atomicAdd(g.gb[p] + n0 + 128 * wm + 32 * i + l31, v);
+        }
+    }
+}
+
+// gW tile += sum over the M-splits of its partial tiles (fp32, 16 bytes per thread, fully coalesced)
+__global__ __launch_bounds__(256) void dw_fixup_kernel(const DwRing g, const float* __restrict__ ws) {
+    const int t = blockIdx.y;
+    int p = 0;
+    while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
+    const int K = g.K[p], ntk = K >> 8, tl = t - g.first_tile[p];
+    const int n0 = (tl / ntk) << 8, k0 = (tl % ntk) << 8;
+    const int e4 = blockIdx.x * 256 + threadIdx.x;           // float4 index inside the tile: 0 .. 16383
+    const float* src = ws + (size_t)t * g.splits * 65536 + (size_t)e4 * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.splits; ++s) {
+        const f32x4 v = *(const f32x4*)(src + (size_t)s * 65536);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    float* dst = g.gW[p] + (size_t)(n0 + (e4 >> 6)) * K + k0 + 4 * (e4 & 63);
+    f32x4 o = *(f32x4*)dst;
+    o.x += sum.x; o.y += sum.y; o.z += sum.z; o.w += sum.w;
+    *(f32x4*)dst = o;
+}
+
+// =================================================================================================
 // skinny forward (M <= 32: the decode path's projections).  The weights are streamed exactly once:
 // workgroup = 32 output columns, its 4 waves split K; W rows and x rows go straight from global/L2 into
 // MFMA fragments (no LDS staging, no barriers in the loop); the four partial tiles are combined in LDS.
@@ -1015,6 +1246,7 @@ static void set_attrs() {
     hipFuncSetAttribute((const void*)linear_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+    hipFuncSetAttribute((const void*)linear_dw_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1132,7 +1364,47 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     return MGX_OK;
 }
 
-extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* stream) {
+// The ring kernel takes a group whose weights all tile into whole 256 x 256 tiles (every encoder-block projection does).
+// plan: number of M-splits so that tiles x splits fills the CUs once; every split gets at least one 32-row step.
+static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRing* out) {
+    static int env = -2;
+    if (env == -2) { const char* e = getenv("MGX_GEMM_RING"); env = e ? atoi(e) : -1; }
+    if (env == 0 || M % 32 != 0 || M < 4096) return false;
+    DwRing g;
+    g.n = count;
+    g.first_tile[0] = 0;
+    for (int i = 0; i < count; ++i) {
+        const mgx_dw_problem& q = problems[i];
+        if (q.N % 256 != 0 || q.K % 256 != 0) return false;
+        g.dY[i] = q.dY; g.X[i] = q.X; g.gW[i] = q.gW; g.gb[i] = q.gb; g.N[i] = q.N; g.K[i] = q.K;
+        g.first_tile[i + 1] = g.first_tile[i] + (q.N / 256) * (q.K / 256);
+    }
+    const int tiles = g.first_tile[count];
+    int cus = 256;
+    {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    }
+    if (tiles > cus) return false;
+    const int total = M / 32;
+    int splits = cus / tiles;
+    if (splits > total) splits = total;
+    g.steps_per_split = (total + splits - 1) / splits;
+    g.splits = (total + g.steps_per_split - 1) / g.steps_per_split;
+    if (out) *out = g;
+    return true;
+}
+
+extern "C" size_t mgx_linear_dw_grouped_workspace(const mgx_dw_problem* problems, int count, int M) {
+    DwRing g;
+    if (!problems || count <= 0 || count > MGX_DW_MAX_GROUP || !dw_ring_plan(problems, count, M, &g)) return 0;
+    return (size_t)g.first_tile[g.n] * g.splits * 65536 * sizeof(float);
+}
+
+extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* workspace, size_t ws_bytes,
+                                     void* stream) {
     MGX_REQUIRE(problems && count > 0 && count <= MGX_DW_MAX_GROUP && M > 0, MGX_ERR_SHAPE,
                 "mgx_linear_dw_grouped: need 1..%d problems and M > 0 (got %d, M=%d)", MGX_DW_MAX_GROUP, count, M);
     DwGroup g;
@@ -1147,6 +1419,19 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, 
         g.first_tile[i + 1] = g.first_tile[i] + ((q.N + BM - 1) / BM) * ((q.K + BN - 1) / BN);
     }
     set_attrs();
+    DwRing rg;
+    if (dw_ring_plan(problems, count, M, &rg)) {
+        const size_t need = (size_t)rg.first_tile[rg.n] * rg.splits * 65536 * sizeof(float);
+        MGX_REQUIRE(workspace && ws_bytes >= need && ((uintptr_t)workspace & 15) == 0, MGX_ERR_SHAPE,
+                    "mgx_linear_dw_grouped: workspace must be 16-byte aligned and >= mgx_linear_dw_grouped_workspace() = %zu bytes "
+                    "(got %zu)", need, ws_bytes);
+        const int tiles = rg.first_tile[rg.n];
+        hipLaunchKernelGGL(linear_dw_ring_kernel, dim3(tiles * rg.splits), dim3(512), RG_LDS, (hipStream_t)stream, rg, M,
+                           (float*)workspace);
+        hipLaunchKernelGGL(dw_fixup_kernel, dim3(64, tiles), dim3(256), 0, (hipStream_t)stream, rg, (const float*)workspace);
+        MGX_CHECK_LAUNCH("mgx_linear_dw_grouped");
+        return MGX_OK;
+    }
     const int tiles = g.first_tile[count];
     static int target = -1;
     if (target < 0) {

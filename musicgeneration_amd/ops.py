@@ -277,6 +277,9 @@ def scatter_add_rows(idx, src, dst):
     check(_lib.load().mgx_scatter_add_rows(ptr(idx), ptr(src), ptr(dst), n, ld, cols, V, stream_ptr()), "mgx_scatter_add_rows")
 
 
+_DW_WS = {}
+
+
 class _DwProblem(ctypes.Structure):          # mirrors mgx_dw_problem (include/mgx.h)
     _fields_ = [("dY", ctypes.c_void_p), ("X", ctypes.c_void_p), ("gW", ctypes.c_void_p), ("gb", ctypes.c_void_p),
                 ("N", ctypes.c_int), ("K", ctypes.c_int)]
@@ -296,7 +299,14 @@ def linear_dw_grouped(problems):
         if rows != Mrows or x.numel() != rows * K or not (dy.is_contiguous() and x.is_contiguous()):
             raise ValueError("linear_dw_grouped: all problems need contiguous dy [M,N], x [M,K] with the same M")
         arr[i] = _DwProblem(ptr(dy), ptr(x), ptr(gw), ptr(gb), N, K)
-    check(_lib.load().mgx_linear_dw_grouped(ctypes.cast(arr, ctypes.c_void_p), len(problems), Mrows, stream_ptr()),
+    lib = _lib.load()
+    parr = ctypes.cast(arr, ctypes.c_void_p)
+    need = lib.mgx_linear_dw_grouped_workspace(parr, len(problems), Mrows)
+    dev = problems[0][0].device
+    ws = _DW_WS.get(dev)          # per-device scratch (fp32 partial tiles of the M-splits), reused on the compute stream
+    if need and (ws is None or ws.numel() < need):
+        ws = _DW_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+    check(lib.mgx_linear_dw_grouped(parr, len(problems), Mrows, ptr(ws) if need else None, need, stream_ptr()),
           "mgx_linear_dw_grouped")
 
 

@@ -97,7 +97,7 @@ def test_header_is_plain_c_and_library_links_from_c(tmp_path):
         '#include "mgx.h"\n#include <stdio.h>\n'
         'int main(void) {\n'
         '    mgx_dw_problem p = {0};\n'
-        '    int rc = mgx_linear_dw_grouped(&p, 1, 128, NULL);\n'
+        '    int rc = mgx_linear_dw_grouped(&p, 1, 128, NULL, 0, NULL);\n'
         '    printf("%d %d %s\\n", mgx_abi_version(), rc, mgx_last_error());\n'
         '    return 0;\n}\n')
     exe = str(tmp_path / "abi")

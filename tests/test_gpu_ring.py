@@ -77,3 +77,37 @@ def test_ring_matches_tiled_kernels_bitwise(tmp_path):
             ref = ref + new[k + "_add"]
         err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-6)
         assert err < 2e-2, f"{k}: relative error {err:.3e} vs fp32 reference"
+
+
+def test_dw_ring_against_fp64_reference():
+    """weight / bias gradients of a block's four projections through the ring TN kernel + fix-up pass (whole 256 x 256
+    tilings, M >= 4096) against an fp64 product of the same bf16 operands; gradients ACCUMULATE into their slots."""
+    import torch
+    from musicgeneration_amd import ops, _lib
+    import ctypes
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(11)
+    M = 4096 + 32 * 5          # not a multiple of the split size: ragged last split
+    shapes = [(768, 256, True), (256, 256, False), (512, 256, True), (256, 512, False)]
+    probs, refs = [], []
+    for (N, K, has_b) in shapes:
+        dy = (torch.randn(M, N, generator=g) * 0.5).to(dev).bfloat16()
+        x = (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16()
+        gw = torch.randn(N, K, generator=g).to(dev)
+        gb = torch.randn(N, generator=g).to(dev) if has_b else None
+        refs.append((gw.double() + dy.double().t() @ x.double(), (gb.double() + dy.double().sum(0)) if has_b else None))
+        probs.append((dy, x, gw, gb))
+    lib = _lib.load()
+    arr = (ops._DwProblem * len(probs))()
+    for i, (dy, x, gw, gb) in enumerate(probs):
+        arr[i] = ops._DwProblem(ops.ptr(dy), ops.ptr(x), ops.ptr(gw), ops.ptr(gb), gw.shape[0], gw.shape[1])
+    need = lib.mgx_linear_dw_grouped_workspace(ctypes.cast(arr, ctypes.c_void_p), len(probs), M)
+    assert need > 0, "this group must take the ring kernel (whole 256x256 tiles, M % 32 == 0)"
+    ops.linear_dw_grouped(probs)
+    torch.cuda.synchronize()
+    for (dy, x, gw, gb), (rw, rb) in zip(probs, refs):
+        err = (gw.double() - rw).abs().max().item() / rw.abs().max().item()
+        assert err < 1e-5, f"gW {tuple(gw.shape)}: relative error {err:.2e}"
+        if gb is not None:
+            errb = (gb.double() - rb).abs().max().item() / rb.abs().max().item()
+            assert errb < 1e-5, f"gb {tuple(gb.shape)}: relative error {errb:.2e}"
