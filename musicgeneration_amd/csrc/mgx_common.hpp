@@ -70,10 +70,22 @@ MGX_DEV void drop_mult8(const DropCfg& c, uint32_t g, float* mult) {
     }
 }
 
+// Sum over the 64 lanes, returned in every lane.  DPP adds inside each row of 16 lanes (quad swaps, half-row and row
+// mirrors: 4 VALU of ~8 cycles each), then the four row sums through v_readlane: a __shfl_xor butterfly is six dependent
+// ds_bpermute round trips through the LDS pipe (~100+ cycles each), which was most of a LayerNorm-backward row.
+template <int CTRL> MGX_DEV float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 MGX_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                 // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);                // row_half_mirror
+    v += dpp_mov<0x140>(v);                // row_mirror: every lane of a row holds the row's sum
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 MGX_DEV float wave_max(float v) {
 #pragma unroll

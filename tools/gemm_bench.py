@@ -28,4 +28,12 @@ for name, N, K in shapes:
     mult = 6 if name != "vocab" else 1
     tot["fwd"] += t1 * mult; tot["dx"] += t2 * mult; tot["dw"] += t3 * mult
     print(f"{name:8s} N={N:5d} K={K:4d}  fwd {t1*1e3:6.1f} us {fl/t1/1e9:6.0f} TF/s | dx {t2*1e3:6.1f} us {fl/t2/1e9:6.0f} | dw {t3*1e3:6.1f} us {fl/t3/1e9:6.0f} | lib fwd {t4*1e3:6.1f} dx {t5*1e3:6.1f} dw {t6*1e3:6.1f} | floor hbm {byt/8e12*1e6:5.1f} mfma {fl/2.5e15*1e6:5.1f} us")
+# the four weight gradients of one encoder block in one launch (what the training step runs)
+probs = []
+for name, N, K in shapes[:4]:
+    probs.append((torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev), torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev),
+                  torch.zeros(N, K, device=dev), torch.zeros(N, device=dev) if name in ("qkv", "ffn_pre") else None))
+tg = timed(lambda: ops.linear_dw_grouped(probs))
+flg = sum(2.0 * M * N * K for _, N, K in shapes[:4])
+print(f"grouped dW of a block: {tg*1e3:6.1f} us {flg/tg/1e9:6.0f} TF/s  (x6 per step = {tg*6:.3f} ms)")
 print("per-step totals (ms):", {k: round(v, 3) for k, v in tot.items()})
