@@ -1,6 +1,8 @@
 """The 256 x 256 ring GEMM (linear.hip: linear_ring_kernel) against the 128 x 128 kernels it replaces for the big projections:
 same inputs through both paths in two child processes (the path is chosen once per process, MGX_GEMM_RING), outputs
-compared BIT FOR BIT (both accumulate the reduction in the same order), and against an fp32 torch reference."""
+compared BIT FOR BIT (both accumulate the reduction in the same order), and against an fp32 torch reference.
+The shapes with 300 and 512 tiles give some of the 256 persistent workgroups two tiles: the ring then runs across a
+tile boundary, with the epilogue's stores and the next tile's bias DMA in the in-order queue."""
 import os
 import subprocess
 import sys
@@ -24,7 +26,8 @@ g = torch.Generator(device="cpu").manual_seed(7)
 def rnd(*s): return (torch.randn(*s, generator=g) * 0.5).to(dev).bfloat16()
 # forward: (M, N, K, bias, act)
 for i, (M, N, K, use_b, act) in enumerate([(512, 256, 128, True, 0), (768, 512, 256, True, 1), (1024, 256, 512, False, 0),
-                                           (2048, 1536, 512, True, 0), (256, 256, 192, True, 0)]):
+                                           (2048, 1536, 512, True, 0), (256, 256, 192, True, 0),
+                                           (76800, 256, 128, True, 1), (131072, 256, 256, True, 0)]):
     A, W = rnd(M, K), rnd(N, K)
     b = (torch.randn(N, generator=g)).to(dev) if use_b else None
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
@@ -35,7 +38,8 @@ for i, (M, N, K, use_b, act) in enumerate([(512, 256, 128, True, 0), (768, 512, 
     out[f"fwd{i}_ref"] = ref.cpu().numpy()
 # dX: (M, N(reduction), K(out), relu mask, addend)
 for i, (M, N, K, use_y, use_add) in enumerate([(512, 128, 256, False, False), (768, 256, 512, True, False),
-                                               (1024, 1536, 512, False, True), (512, 512, 256, True, True)]):
+                                               (1024, 1536, 512, False, True), (512, 512, 256, True, True),
+                                               (76800, 128, 256, True, True)]):
     dY, W = rnd(M, N), rnd(N, K)
     y = rnd(M, K) if use_y else None
     add = rnd(M, K) if use_add else None
