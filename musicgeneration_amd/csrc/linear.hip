@@ -1380,12 +1380,12 @@ static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRin
         g.first_tile[i + 1] = g.first_tile[i] + (q.N / 256) * (q.K / 256);
     }
     const int tiles = g.first_tile[count];
-    int cus = 256;
-    {
+    static int cus = 0;                                    // queried once (the call is not cheap)
+    if (!cus) {
         hipDeviceProp_t prop;
         int dev = 0;
         hipGetDevice(&dev);
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     if (tiles > cus) return false;
     const int total = M / 32;
