@@ -900,8 +900,12 @@ __global__ __launch_bounds__(512, 1) void linear_dw_ring_kernel(const DwRing g, 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int unit = blockIdx.x;
-    const int t = unit / g.splits, sp = unit % g.splits;
+    // unit order: one XCD runs a contiguous range of (split, tile) pairs, split-major -- the tiles of one M-split read the
+    // same rows of dY / X (tiles of one row / column of a weight share an operand tile), so they meet in that XCD's L2
+    const int tiles_all = g.first_tile[g.n];
+    const int u = xcd_remap(blockIdx.x, gridDim.x);
+    const int sp = u / tiles_all, t = u - sp * tiles_all;
+    const int unit = t * g.splits + sp;                      // position of the partial tile in the workspace
     int p = 0;
     while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
     const int N = g.N[p], K = g.K[p];
