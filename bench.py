@@ -180,6 +180,18 @@ def decode_bench(args):
     dt = time.perf_counter() - t0
     steps = Ld - 1
     assert out.shape == (Bd, Ld) and int(out.max()) < V
+    # prompt handling: a prior of half the window, prefilled in one pass of the full-sequence kernels vs teacher-forced
+    # step by step (the first decode step after the prompt is included in both)
+    Pp = min(Ld // 2, 2048)
+    prompt = torch.randint(0, V - 1, (Bd, Pp), device="cuda")
+    pre = {}
+    for mode in ("batched", "token"):
+        mt.generate_cached(prompt[:, :65], 1, top_p=0.9, seed=1, prefill=mode)      # warm-up of that path
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        mt.generate_cached(prompt, 1, top_p=0.9, seed=0, prefill=mode)
+        torch.cuda.synchronize()
+        pre[mode] = time.perf_counter() - tp
     kv_bytes = nl * 2 * Bd * d * 2 * (steps * (steps + 1) / 2)          # K and V rows read over the whole run
     w_bytes = steps * 2 * sum(p.numel() for p in mt.parameters())       # bf16 weights once per step
     last_step_bytes = nl * 2 * Bd * d * 2 * Ld + 2 * sum(p.numel() for p in mt.parameters())
@@ -189,7 +201,9 @@ def decode_bench(args):
             "algorithmic_bytes_per_step_mean": (kv_bytes + w_bytes) / steps,
             "algorithmic_bytes_last_step": last_step_bytes,
             "achieved_gbs": (kv_bytes + w_bytes) / dt / 1e9, "peak_gbs": PEAK_HBM_GBS,
-            "frac": (kv_bytes + w_bytes) / dt / 1e9 / PEAK_HBM_GBS, "bound": "hbm"}
+            "frac": (kv_bytes + w_bytes) / dt / 1e9 / PEAK_HBM_GBS, "bound": "hbm",
+            "prefill": {"prompt_tokens": Pp, "batch": Bd, "batched_ms": 1e3 * pre["batched"], "token_by_token_ms": 1e3 * pre["token"],
+                        "batched_prompt_tokens_per_s": Bd * Pp / pre["batched"]}}
 
 
 def pmc_traffic(kernel, B, L, d):

@@ -199,13 +199,18 @@ class MusicTransformer(torch.nn.Module):
     @torch.no_grad()
     def generate_cached(self, prior: torch.Tensor, length: int, temperature: float = 1.0, top_k: int = 0,
                         top_p: float = 1.0, seed: int = 0, use_graph: bool = True, return_probs: bool = False,
-                        grammar=None):
+                        grammar=None, prefill: str = "auto", return_cache: bool = False):
         """Sample ``length`` events after ``prior`` [B,P] with per-layer K/V caches and absolute positions
         0..P+length-1 (requires P+length <= max_seq; no sliding window).  Every step runs
         embed -> N x (QKV GEMM, cached relative attention, fc, LN, FFN, LN) -> vocabulary GEMM -> fused
         sampler; the position lives on the device, so after a warm-up step the whole step is captured in
         one graph and replayed per token.  Returns int32 [B, P+length] (and, if ``return_probs``, the
-        f32 [B, P+length, V] next-token distributions, position p = distribution after token p)."""
+        f32 [B, P+length, V] next-token distributions, position p = distribution after token p).
+        ``prefill``: "batched" runs the first P-1 prior tokens through the full-sequence (training) kernels in ONE pass and
+        copies every layer's K/V rows into the caches -- a 500-event prompt costs one forward instead of 499 decode steps;
+        "token" teacher-forces the prior step by step; "auto" = batched for priors of more than 32 tokens (not with
+        ``return_probs``, which wants the distribution after every prior token).  ``return_cache`` adds the per-layer
+        (K, V) caches to the result (parity tests)."""
         st = self.store()
         st.sync_shadow()
         was_training = self.training
@@ -280,8 +285,36 @@ class MusicTransformer(torch.nn.Module):
             ops.sample_topk_topp(logits, V, pos, tok, out_tokens if sample_into_out else None, probs_step, temperature,
                                  top_k, top_p, seed, advance=True, allow_table=allow)
 
-        # prefill: the prior is teacher-forced token by token (it also warms every kernel up before capture)
-        for p in range(P):
+        if prefill not in ("auto", "token", "batched"):
+            raise ValueError("prefill must be 'auto', 'token' or 'batched'")
+        if prefill == "batched" and return_probs:
+            raise ValueError("return_probs needs prefill='token' (it reports the distribution after every prior token)")
+        first = 0
+        if prefill == "batched" or (prefill == "auto" and not return_probs and P > 32):
+            # batched prefill: positions 0..P-2 through the full-sequence kernels (causal, so the zero-padded tail up to a
+            # multiple of 32 cannot reach them); token P-1 then takes the ordinary decode step below
+            n = P - 1
+            if n > 0:
+                Lp = (n + 31) // 32 * 32
+                seq = torch.zeros(B, Lp, dtype=torch.int32, device=dev)
+                seq[:, :n] = prior_i[:, :n]
+                hh = ops.embed_pe_fwd(seq, Pm["Decoder.embedding.weight"].data, pe)
+                for i, ly in enumerate(layers):
+                    qkv_p = ops.linear_fwd(hh, ly["wqkv"], ly["bqkv"], 0)
+                    kc[i][:, :n] = qkv_p[:, :n, d:2 * d]
+                    vc[i][:, :n] = qkv_p[:, :n, 2 * d:]
+                    if i + 1 == nl:
+                        break                             # the last layer's output rows are not needed: token P-1 follows
+                    att, _ = ops.rel_attn_fwd(qkv_p, ly["E"], None)
+                    a_p = ops.linear_fwd(att, ly["wfc"], ly["bfc"], 0)
+                    o1_p = ops.add_ln_fwd(a_p, hh, ly["g1"], ly["b1"], 1e-6)[0]
+                    f_p = ops.linear_fwd(ops.linear_fwd(o1_p, ly["w1"], ly["bb1"], 1), ly["w2"], ly["bb2"], 0)
+                    hh = ops.add_ln_fwd(f_p, o1_p, ly["g2"], ly["b2"], 1e-6)[0]
+                pos.fill_(n)
+                tok.copy_(prior_i[:, n])
+                first = n
+        # the (rest of the) prior is teacher-forced token by token (it also warms every kernel up before capture)
+        for p in range(first, P):
             step(sample_into_out=(p == P - 1) and length > 0)
             if return_probs:
                 probs_all[:, p] = probs_step
@@ -309,7 +342,10 @@ class MusicTransformer(torch.nn.Module):
                     if return_probs:
                         probs_all[:, P + p] = probs_step
         self.train(was_training)
-        return (out_tokens, probs_all) if return_probs else out_tokens
+        res = (out_tokens, probs_all) if return_probs else out_tokens
+        if return_cache:
+            return (res, kc, vc)
+        return res
 
     def test(self):
         self.eval()

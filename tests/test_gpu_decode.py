@@ -351,3 +351,29 @@ def test_gru_train_packed_lengths_matches_torch_packed_gru():
         assert cos > 0.99, f"{name}: cos {cos}"
     with pytest.raises(ValueError):
         net.Train(init.cuda(), torch.from_numpy(X.astype(np.int64)).t().cuda(), lengths)     # time-major + lengths: refused
+
+
+@pytest.mark.parametrize("P", [33, 80, 96])
+def test_batched_prefill_fills_the_same_caches_as_token_by_token(P):
+    """A prompt goes through the full-sequence kernels in one pass (prefill='batched'): every layer's K/V cache rows and
+    the first sampled distribution must agree with teacher-forcing the prompt one decode step at a time."""
+    mt, _ = _model(L=128)
+    V, B = 337, 2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, V - 1, (B, P), generator=g).cuda()
+    (ta, pa), ka, va = mt.generate_cached(x, 1, top_k=1, return_probs=True, prefill="token", return_cache=True)
+    tb, kb, vb = mt.generate_cached(x, 1, top_k=1, prefill="batched", return_cache=True)
+    torch.cuda.synchronize()
+    for i in range(len(ka)):
+        for a, b, nm in ((ka[i], kb[i], "K"), (va[i], vb[i], "V")):
+            a, b = a[:, :P].float(), b[:, :P].float()
+            rel = (a - b).abs().max().item() / a.abs().max().item()
+            assert rel < 2e-2, f"layer {i} {nm} cache: relative difference {rel:.3e}"
+    # the token sampled after the prompt: greedy, so equal unless the top two probabilities are within kernel noise
+    p_last = pa[:, P - 1]
+    top2 = p_last.topk(2, -1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2e-2
+    assert (ta[:, P][clear] == tb[:, P][clear]).all()
+    assert (ta[:, :P] == tb[:, :P]).all()
+    with pytest.raises(ValueError):
+        mt.generate_cached(x, 1, return_probs=True, prefill="batched")
