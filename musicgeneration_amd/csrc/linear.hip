@@ -12,6 +12,10 @@
 //                                        atomics (128-byte row segments) straight into the flat grad
 //                                        buffer -- gradient accumulation across micro-batches for free.
 //   bias     gb += column sums of dY, folded into the dW kernel (its first k-tile column stages those rows anyway).
+//
+// Two families: the 128 x 128 kernels described above (any shape), and the 256 x 256 "ring" kernels further down
+// (linear_ring_kernel, linear_dw_ring_kernel: LDS-DMA staging, 4-stage ring, persistent workgroups) that the host
+// entry points pick for the big projections of an encoder block; both produce bit-identical forward / dX results.
 #include <stdlib.h>
 #include <type_traits>
 #include "rel_attn_common.hpp"
