@@ -56,13 +56,14 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
     const int ks = lane >> 3, dg = lane & 7;
     const int t = pos_dev[0];                                   // current position; keys 0..t
     const uint16_t* qrow = qkv_new + (size_t)b * 3 * d + hd * 64;
-    uint16_t* kc = kcache + (size_t)b * Lmax * d + hd * 64;
-    uint16_t* vc = vcache + (size_t)b * Lmax * d + hd * 64;
+    // caches are head-major [B, h, Lmax, 64]: a workgroup streams one contiguous run of 128-byte rows
+    uint16_t* kc = kcache + ((size_t)b * heads + hd) * Lmax * 64;
+    uint16_t* vc = vcache + ((size_t)b * heads + hd) * Lmax * 64;
     // append this step's key/value for the following steps (split 0 of each head owns the head's 64 columns); in THIS
     // step row t is read from qkv_new, so no workgroup depends on another one's store
     if (sp == 0) {
-        if (tid < 8) *(u32x4*)(kc + (size_t)t * d + tid * 8) = *(const u32x4*)(qrow + d + tid * 8);
-        else if (tid < 16) *(u32x4*)(vc + (size_t)t * d + (tid - 8) * 8) = *(const u32x4*)(qrow + 2 * d + (tid - 8) * 8);
+        if (tid < 8) *(u32x4*)(kc + (size_t)t * 64 + tid * 8) = *(const u32x4*)(qrow + d + tid * 8);
+        else if (tid < 16) *(u32x4*)(vc + (size_t)t * 64 + (tid - 8) * 8) = *(const u32x4*)(qrow + 2 * d + (tid - 8) * 8);
     }
     float q[8];
     unpack8(*(const u32x4*)(qrow + dg * 8), q);
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
         const int j = j0 + ks;
         const bool valid = j < hi;
         const int jc = valid ? j : hi - 1;
-        const uint16_t* kp = (jc == t) ? qrow + d : kc + (size_t)jc * d;
-        const uint16_t* vp = (jc == t) ? qrow + 2 * d : vc + (size_t)jc * d;
+        const uint16_t* kp = (jc == t) ? qrow + d : kc + (size_t)jc * 64;
+        const uint16_t* vp = (jc == t) ? qrow + 2 * d : vc + (size_t)jc * 64;
         float kf[8], ef[8], vf[8];
         unpack8(*(const u32x4*)(kp + dg * 8), kf);
         unpack8(*(const u32x4*)(Eb + (size_t)jc * 64 + dg * 8), ef);

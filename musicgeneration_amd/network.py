@@ -222,8 +222,9 @@ class MusicTransformer(torch.nn.Module):
         dev = st.param.device
         d, V, Vp, nl = self.embedding_dim, self.vocab_size, self.vocab_padded, self.num_layer
         bf = torch.bfloat16
-        kc = [torch.zeros(B, total, d, dtype=bf, device=dev) for _ in range(nl)]
-        vc = [torch.zeros(B, total, d, dtype=bf, device=dev) for _ in range(nl)]
+        # caches are head-major [B, h, total, 64]: the decode kernel's workgroup (b, h) streams one contiguous run
+        kc = [torch.zeros(B, d // 64, total, 64, dtype=bf, device=dev) for _ in range(nl)]
+        vc = [torch.zeros(B, d // 64, total, 64, dtype=bf, device=dev) for _ in range(nl)]
         pos = torch.zeros(1, dtype=torch.int32, device=dev)
         tok = prior[:, 0].to(torch.int32).contiguous().to(dev)
         prior_i = prior.to(torch.int32).to(dev)
@@ -301,8 +302,8 @@ class MusicTransformer(torch.nn.Module):
                 hh = ops.embed_pe_fwd(seq, Pm["Decoder.embedding.weight"].data, pe)
                 for i, ly in enumerate(layers):
                     qkv_p = ops.linear_fwd(hh, ly["wqkv"], ly["bqkv"], 0)
-                    kc[i][:, :n] = qkv_p[:, :n, d:2 * d]
-                    vc[i][:, :n] = qkv_p[:, :n, 2 * d:]
+                    kc[i][:, :, :n] = qkv_p[:, :n, d:2 * d].view(B, n, d // 64, 64).permute(0, 2, 1, 3)
+                    vc[i][:, :, :n] = qkv_p[:, :n, 2 * d:].view(B, n, d // 64, 64).permute(0, 2, 1, 3)
                     if i + 1 == nl:
                         break                             # the last layer's output rows are not needed: token P-1 follows
                     att, _ = ops.rel_attn_fwd(qkv_p, ly["E"], None)

@@ -327,8 +327,12 @@ def rel_attn_decode_workspace(B, Lmax, d, device):
 
 
 def rel_attn_decode(qkv_new, kcache, vcache, E, pos_dev, ctx, workspace=None):
+    """kcache / vcache bf16 [B, h, Lmax, 64] (head-major: workgroup (b, h) streams one contiguous run of rows)"""
     _need_cuda(qkv_new, kcache, vcache, E, pos_dev, ctx, workspace)
-    B, Lmax, d = kcache.shape
+    B, heads, Lmax, dh = kcache.shape
+    if dh != 64 or vcache.shape != kcache.shape:
+        raise ValueError("rel_attn_decode: caches must be bf16 [B, h, Lmax, 64]")
+    d = heads * 64
     check(_lib.load().mgx_rel_attn_decode(ptr(qkv_new), ptr(kcache), ptr(vcache), ptr(E), ptr(pos_dev), ptr(ctx), ptr(workspace),
                                           0 if workspace is None else workspace.numel(), B, Lmax, d, E.shape[0], stream_ptr()),
           "mgx_rel_attn_decode")

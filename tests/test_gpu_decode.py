@@ -366,7 +366,7 @@ def test_batched_prefill_fills_the_same_caches_as_token_by_token(P):
     torch.cuda.synchronize()
     for i in range(len(ka)):
         for a, b, nm in ((ka[i], kb[i], "K"), (va[i], vb[i], "V")):
-            a, b = a[:, :P].float(), b[:, :P].float()
+            a, b = a[:, :, :P].float(), b[:, :, :P].float()          # caches are [B, h, total, 64]
             rel = (a - b).abs().max().item() / a.abs().max().item()
             assert rel < 2e-2, f"layer {i} {nm} cache: relative difference {rel:.3e}"
     # the token sampled after the prompt: greedy, so equal unless the top two probabilities are within kernel noise
