@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace */
-#define MGX_ABI_VERSION 10
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64] */
+#define MGX_ABI_VERSION 11
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -181,7 +181,8 @@ int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void
 int mgx_decode_embed(const int32_t* tok, const float* table, const float* pe, const int32_t* pos_dev,
                      uint16_t* out, int B, int d, int V, void* stream);
 /* qkv_new bf16 [B,3d] (projection of the token at position t): k_t, v_t are appended to
- * kcache/vcache bf16 [B,Lmax,d] at row t, then ctx bf16 [B,d] = softmax_j((q.k_j + q.E[M-1-(t-j)])/8) v_j
+ * kcache/vcache bf16 [B,h,Lmax,64] (head-major: the workgroup of (b,h) streams one contiguous run of 128-byte rows)
+ * at row t, then ctx bf16 [B,d] = softmax_j((q.k_j + q.E[M-1-(t-j)])/8) v_j
  * over j = 0..t.  t < Lmax <= M.                                                                      */
 /* Long caches are split over several workgroups per (b,h) whose partial results a second kernel merges: workspace =
  * caller scratch >= mgx_rel_attn_decode_workspace(B, Lmax, d) bytes (0 for short caches: NULL is accepted then).      */
