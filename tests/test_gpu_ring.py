@@ -83,7 +83,12 @@ def test_ring_matches_tiled_kernels_bitwise(tmp_path):
         assert err < 2e-2, f"{k}: relative error {err:.3e} vs fp32 reference"
 
 
-def test_dw_ring_against_fp64_reference():
+@pytest.mark.parametrize("M,shapes", [
+    (4096 + 32 * 5, [(768, 256, True), (256, 256, False), (512, 256, True), (256, 512, False)]),   # 12 steps per unit, ragged last split
+    (4096, [(256, 256, True)]),                          # one tile, 128 splits of ONE 32-row step (the short-stream paths)
+    (12288, [(256, 256, False), (256, 256, True)]),      # 2-3 steps per unit
+])
+def test_dw_ring_against_fp64_reference(M, shapes):
     """weight / bias gradients of a block's four projections through the ring TN kernel + fix-up pass (whole 256 x 256
     tilings, M >= 4096) against an fp64 product of the same bf16 operands; gradients ACCUMULATE into their slots."""
     import torch
@@ -91,8 +96,6 @@ def test_dw_ring_against_fp64_reference():
     import ctypes
     dev = "cuda:0"
     g = torch.Generator(device="cpu").manual_seed(11)
-    M = 4096 + 32 * 5          # not a multiple of the split size: ragged last split
-    shapes = [(768, 256, True), (256, 256, False), (512, 256, True), (256, 512, False)]
     probs, refs = [], []
     for (N, K, has_b) in shapes:
         dy = (torch.randn(M, N, generator=g) * 0.5).to(dev).bfloat16()
