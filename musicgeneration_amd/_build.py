@@ -1,9 +1,15 @@
 """Build libmgx.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
 
 Cross-compiles without a GPU.  The .so stays inside the package directory so that it travels
-with the source tree (it is git-ignored, not gpurun-ignored)."""
+with the source tree (it is git-ignored, not gpurun-ignored).
+
+`python -m musicgeneration_amd._build [--force]` builds the product library.
+`python -m musicgeneration_amd._build --variant NAME -DMACRO[=v] ...` builds `libmgx_NAME.so` beside it with extra
+macros: the timing-only "peel" / in-kernel "stamp" builds the profile notes quote are made this way, from the
+tracked sources, and loaded with `MGX_LIB_PATH=musicgeneration_amd/libmgx_NAME.so` (tools/variants.sh)."""
 from __future__ import annotations
 
+import fcntl
 import os
 import shutil
 import subprocess
@@ -13,7 +19,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgx.so")
-SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_bwd.hip", "linear.hip", "decode.hip", "gru_train.hip"]
+SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_fwd2.hip", "rel_attn_bwd.hip", "linear.hip", "decode.hip",
+           "gru_train.hip"]
+# per-file flags.  The 64-rows-per-wave attention kernels run one wave per SIMD with the whole 512-entry register file:
+# MFMA results that VALU code reads (scores) must stay in arch VGPRs (with more than 256 registers available hipcc otherwise
+# gives every MFMA an AGPR destination and copies each result out), and the SLP vectoriser must not pair the two blocks'
+# row sums into v_pk_add_f32 (slower than two v_add_f32 beside MFMAs).
+EXTRA_FLAGS = {"rel_attn_fwd2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -31,49 +43,71 @@ def have_hipcc() -> bool:
         return False
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "mgx.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every source in csrc/ for gfx950 and link libmgx.so.  Returns the library path."""
-    if not force and not _stale():
-        return LIB
+def _compile_and_link(lib: str, objdir: str, defines, verbose: bool) -> None:
     hipcc = _hipcc()
-    objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-              "-I" + CSRC, "-Wno-unused-value", "-Wno-unused-result"]
-    objs = []
-    procs = []
+              "-I" + CSRC, "-Wno-unused-value", "-Wno-unused-result"] + list(defines)
+    objs, procs = [], []
+    pid = os.getpid()
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = common + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+        # pid-unique object names: two processes that get past the lock in turn never share a half-written object
+        obj = os.path.join(objdir, f"{os.path.splitext(src)[0]}.{pid}.o")
+        cmd = common + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
-    for src, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
-            print(out)
-    tmp = LIB + ".tmp"
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n" + r.stdout)
-    os.replace(tmp, LIB)
-    return LIB
+    try:
+        for src, p in procs:
+            out, _ = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+            if verbose and out.strip():
+                print(out)
+        tmp = f"{lib}.{pid}.tmp"
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout)
+        os.replace(tmp, lib)                             # atomic: a concurrent CDLL sees the old or the new file, never a part
+    finally:
+        for o in objs:
+            if os.path.exists(o):
+                os.remove(o)
+
+
+def build(force: bool = False, verbose: bool = False, variant: str | None = None, defines=()) -> str:
+    """Compile every source in csrc/ for gfx950 and link libmgx.so (or libmgx_<variant>.so with extra -D macros).
+    Returns the library path.  Safe to call from several processes at once (torchrun ranks, bench.py's self-launch):
+    the stale check and the build run under an exclusive file lock, and a rank that waited finds the library fresh."""
+    lib = LIB if not variant else os.path.join(PKG, f"libmgx_{variant}.so")
+    if not force and not variant and not _stale(lib):
+        return lib
+    objdir = os.path.join(PKG, "build", variant or "product")
+    os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    with open(os.path.join(PKG, "build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if force or variant or _stale(lib):          # re-check: another process may have built it while we waited
+                _compile_and_link(lib, objdir, defines, verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    argv = sys.argv[1:]
+    var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
+    print(build(force="--force" in argv, verbose="-v" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")]))

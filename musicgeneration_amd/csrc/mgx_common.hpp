@@ -93,6 +93,17 @@ MGX_DEV float wave_max(float v) {
     return v;
 }
 
+// host: environment switch `name` is set and starts with '0' (A/B toggles; read on every call, so a test can flip it)
+#include <stdlib.h>
+static inline bool env_is_zero(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] == '0';
+}
+static inline bool env_is_one(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] == '1';
+}
+
 // ---- host-side error plumbing -----------------------------------------------------------------
 void mgx_set_error(const char* fmt, ...);
 #define MGX_REQUIRE(cond, code, ...)            \

@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=8); ap.add_argument("--L", type=int, default=2048)
 ap.add_argument("--d", type=int, default=512); ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--parts", type=int, default=63, help="bit0 fwd, bit1 delta, bit2 dq, bit3 dkv, bit4 de (streamed), bit5 de (recompute)")
+ap.add_argument("--rounds", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(7)
@@ -27,7 +28,18 @@ def timed(fn, units, name):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     print(f"{name:8s} {ms:8.3f} ms   executed {units*unit/ms/1e9:8.1f} TF/s ({units} units)")
-if a.parts & 1: timed(lambda: ops.rel_attn_fwd(qkv, E, None), 3, "fwd")
+def with_env(k, v, fn):
+    def g():
+        old = os.environ.get(k); os.environ[k] = v
+        try: fn()
+        finally:
+            if old is None: os.environ.pop(k, None)
+            else: os.environ[k] = old
+    return g
+if a.parts & 1:
+    for _ in range(a.rounds):          # interleaved rounds in one process (A/B)
+        timed(lambda: ops.rel_attn_fwd(qkv, E, None), 3, "fwd")
+        timed(with_env("MGX_ATTN_FWD64", "0", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd32")
 if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, ws), 0, "delta")
 if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2, dqkv, ws), 5, "dq")
 if a.parts & 8: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
