@@ -103,6 +103,10 @@ static inline bool env_is_one(const char* name) {
     const char* v = getenv(name);
     return v && v[0] == '1';
 }
+static inline int env_digit(const char* name, int dflt) {      // first character as a digit, `dflt` when unset / not a digit
+    const char* v = getenv(name);
+    return (v && v[0] >= '0' && v[0] <= '9') ? v[0] - '0' : dflt;
+}
 
 // ---- host-side error plumbing -----------------------------------------------------------------
 void mgx_set_error(const char* fmt, ...);

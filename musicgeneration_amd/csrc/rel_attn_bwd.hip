@@ -76,14 +76,6 @@ MGX_DEV bf16x8 frag_Tn(const char* tile, int lane, int ks, int ct) {
     return out;
 }
 
-MGX_DEV u32x4 scale8(const u32x4& raw, float sc) {
-    float f[8];
-    unpack8(raw, f);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] *= sc;
-    return pack8(f);
-}
-
 // ================================================================================================
 // K1: dQ.  Same sweep as the forward (query-block owner, key tiles 0..diagonal).
 //   orientation: keys on registers, queries on lanes (S^T, P^T, dP^T, dS^T), dqs^T[c][a] accumulators.
@@ -101,23 +93,6 @@ constexpr int OFF_PAD = OFF_DBAND + WAVES * 32 * DB_STRIDE; // key-padding words
 constexpr int OFF_FLAG = OFF_PAD + 1024;                   // "this batch row has padded keys" flag
 constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 70,672 B -> 2 workgroups per CU
 }  // namespace k1
-
-// transposed fragment read from an image-R tile (2-way bank conflict, saves a second LDS image):
-// X[kappa(j)][32*ct + (lane&31)], kappa(j) = 16*s + 8*(j>>2) + 4*hh + (j&3)
-MGX_DEV bf16x8 frag_T_onR(const char* tile, int lane, int s, int ct) {
-    const int i = lane & 15, g = lane >> 4, hh = lane >> 5;
-    const int rq = i >> 2;
-    const int chunk = 4 * ct + 2 * (g & 1) + ((i & 3) >> 1);
-    const int byte_in = 8 * (i & 1);
-    bf16x8 out;
-#pragma unroll
-    for (int jq = 0; jq < 2; ++jq) {
-        const int row = 16 * s + 8 * jq + 4 * hh + rq;
-        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + imgR_off(row, chunk) + byte_in));
-        out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
-    }
-    return out;
-}
 
 template <bool EXPORT_DS, bool OWN_DELTA>
 __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
@@ -1048,7 +1023,11 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
     const dim3 gq(bg * heads, ((L + 127) / 128) * (B / bg));
     const bool export_ds = (parts & 8) || !(parts & 16);
-    if (parts & 2) {
+    // L % 256 == 0 (cfg2, cfg4): the software-pipelined dQ kernel with 64 query rows per wave (rel_attn_bwd2.hip), in the
+    // configuration the training step uses (dS export + own delta); MGX_ATTN_DQ64=0 keeps the 32-row kernel (A/B, cross-check)
+    if ((parts & 2) && L % 256 == 0 && export_ds && dq_makes_delta && !env_is_zero("MGX_ATTN_DQ64")) {
+        if (int rc = dq64_launch(qkv, EfA, EfT, padbits, dctx, lse, delta, dqkv, dsrel, ctx, B, L, d, stream)) return rc;
+    } else if (parts & 2) {
 #define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, \
                                                    padbits, dctx, lse, delta, dqkv, dsrel, ctx, L, d, bg)
         if (export_ds) { if (dq_makes_delta) MGX_DQ_LAUNCH(true, true); else MGX_DQ_LAUNCH(true, false); }

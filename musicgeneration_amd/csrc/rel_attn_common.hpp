@@ -65,6 +65,31 @@ MGX_DEV bf16x8 frag_T(const char* tile, int lane, int s, int ct) {
     return out;
 }
 
+// transposed fragment read from an image-R tile (2-way bank conflict, saves a second LDS image):
+// X[kappa(j)][32*ct + (lane&31)], kappa(j) = 16*s + 8*(j>>2) + 4*hh + (j&3)
+MGX_DEV bf16x8 frag_T_onR(const char* tile, int lane, int s, int ct) {
+    const int i = lane & 15, g = lane >> 4, hh = lane >> 5;
+    const int rq = i >> 2;
+    const int chunk = 4 * ct + 2 * (g & 1) + ((i & 3) >> 1);
+    const int byte_in = 8 * (i & 1);
+    bf16x8 out;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int row = 16 * s + 8 * jq + 4 * hh + rq;
+        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + imgR_off(row, chunk) + byte_in));
+        out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
+    }
+    return out;
+}
+
+MGX_DEV u32x4 scale8(const u32x4& raw, float sc) {
+    float f[8];
+    unpack8(raw, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] *= sc;
+    return pack8(f);
+}
+
 // accumulator registers 8s..8s+7 -> bf16x8 operand fragment for k-step s (k order kappa, see frag_T)
 MGX_DEV bf16x8 acc_to_frag(const f32x16& c, int s) {
     u32x4 w;
@@ -192,5 +217,10 @@ static inline void launch_er_frag(const uint16_t* Er, u32x4* EfA, u32x4* EfT, in
 
 int fwd64_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, uint16_t* ctx, float* lse, int B, int L, int d,
                  void* stream);   // rel_attn_fwd2.hip
+int fwdpp_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, uint16_t* ctx, float* lse, int B, int L, int d,
+                 void* stream);   // rel_attn_fwd3.hip
+int dq64_launch(const uint16_t* qkv, const void* EfA, const void* EfT, const uint32_t* padbits, const uint16_t* dctx,
+                const float* lse, float* delta, uint16_t* dqkv, uint16_t* dsrel, const uint16_t* ctx, int B, int L, int d,
+                void* stream);    // rel_attn_bwd2.hip
 
 }  // namespace relattn

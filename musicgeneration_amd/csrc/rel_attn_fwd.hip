@@ -347,11 +347,13 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
     if (int rc = fwd_common_checks("mgx_rel_attn_fwd", workspace, ws_bytes, B, L, d, M)) return rc;
     set_fwd_attrs();
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
-    // MGX_ATTN_FWD64=1 and L % 256 == 0: the software-pipelined kernel with 64 query rows per wave (rel_attn_fwd2.hip).
-    // Opt-in: one wave per SIMD issues at most one instruction per ~4 cycles, and the forward needs ~10 non-MFMA
-    // instructions per MFMA (exp / row sums / packing / band stores), so at cfg2 it runs 0.34 ms against 0.29 ms here.
-    if (L % 256 == 0 && env_is_one("MGX_ATTN_FWD64"))
-        return fwd64_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
+    // L % 256 == 0: MGX_ATTN_FWD64 = 2 the ping-pong kernel (rel_attn_fwd3.hip), 1 the 64-rows-per-wave kernel
+    // (rel_attn_fwd2.hip), 0 this file's 32-row kernel
+    if (L % 256 == 0) {
+        const int mode = env_digit("MGX_ATTN_FWD64", 0);
+        if (mode == 2) return fwdpp_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
+        if (mode == 1) return fwd64_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
+    }
     const int bg = batch_group(B, L, d);
     dim3 grid(bg * (d / 64), ((L + 127) / 128) * (B / bg));
     hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,

@@ -21,13 +21,6 @@ dqkv = torch.empty_like(qkv); ws = torch.empty(ops._lib.load().mgx_rel_attn_bwd_
 ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, ws)
 torch.cuda.synchronize()
 unit = a.B * a.L * a.L * a.d
-def timed(fn, units, name):
-    fn(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / a.reps
-    print(f"{name:8s} {ms:8.3f} ms   executed {units*unit/ms/1e9:8.1f} TF/s ({units} units)")
 def with_env(k, v, fn):
     def g():
         old = os.environ.get(k); os.environ[k] = v
@@ -36,13 +29,27 @@ def with_env(k, v, fn):
             if old is None: os.environ.pop(k, None)
             else: os.environ[k] = old
     return g
+def timed(fn, units, name):
+    fn(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
+    print(f"{name:8s} {ms:8.3f} ms   executed {units*unit/ms/1e9:8.1f} TF/s ({units} units)")
 if a.parts & 1:
     for _ in range(a.rounds):          # interleaved rounds in one process (A/B)
-        timed(lambda: ops.rel_attn_fwd(qkv, E, None), 3, "fwd")
         timed(with_env("MGX_ATTN_FWD64", "0", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd32")
+        timed(with_env("MGX_ATTN_FWD64", "1", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd64")
+        timed(with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwdpp")
 if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, ws), 0, "delta")
-if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2, dqkv, ws), 5, "dq")
-if a.parts & 8: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
+if a.parts & 4:
+    for _ in range(a.rounds):
+        # parts 1|2 = what the training step launches: E fragment pre-pass (5 us) + the dQ kernel that makes its own delta
+        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 3, dqkv, ws), 5, "dq")
+        timed(with_env("MGX_ATTN_DQ64", "0", lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 3, dqkv, ws)), 5, "dq32")
+if a.parts & 8:
+    for _ in range(a.rounds):
+        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
+        timed(with_env("MGX_ATTN_DKV64", "0", lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws)), 6, "dkv32")
 if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de")
 if a.parts & 32: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 16, dqkv, ws), 6, "de_rec")
-if a.parts & 4: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2 | 16, dqkv, ws), 5, "dq_noexp")
