@@ -124,22 +124,29 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
 
     const int srow = tid >> 3, sch = tid & 7;
     const int st_offR = imgR_off(srow, sch);
-    const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;
-    const uint16_t* vg = kg + d;
-    const size_t tile_stride = (size_t)32 * ld;
+    // Every global address of the sweep is (wave-uniform base in SGPRs) + (32-bit per-lane offset) + immediate, so a load
+    // costs no vector address arithmetic (a 64-bit per-lane pointer bumped per step cost 2-3 VALU + SALU per load).
+    const char* kv_base = (const char*)(qkv_b + d + hd * 64);                 // K columns of this head; V is d elements further
+    const uint32_t kv_voff = (uint32_t)((srow * ld + sch * 8) * 2);            // bytes
+    const uint32_t tile_bytes = (uint32_t)(32 * ld * 2);                       // one 32-row step of qkv
+    auto k_tile = [&](int t) { return *(const u32x4*)(kv_base + (size_t)t * tile_bytes + kv_voff); };
+    auto v_tile = [&](int t) { return *(const u32x4*)(kv_base + (size_t)t * tile_bytes + (size_t)d * 2 + kv_voff); };
     // fragment-ordered copies of Er (er_frag_kernel, rel_attn_common.hpp): 1 KB contiguous per wave load.  Every load
     // of the sweep is unconditional with a clamped index (a load inside a branch makes the compiler drain the whole
     // VMEM queue where the branch rejoins); data of clamped tiles / chunks is never used.
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     // Er row fragment ks of chunk q (row t = lane&31 of the chunk, i.e. delta = 32q + t)
-    auto e_frag = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, EfA[(size_t)(max(q, 0) * 4 + ks) * 64 + lane]); };
+    auto e_frag = [&](int q, int ks) {
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)EfA + (size_t)max(q, 0) * 4096 + ks * 1024 + lane16));
+    };
     // ErT fragment: row c = 32*ct + (lane&31), k = t = 16*ks + 8*hh + j of chunk q
     auto et_frag = [&](int q, int ks, int ct) {
-        return __builtin_bit_cast(bf16x8, EfT[(size_t)((max(q, 0) * 2 + ks) * 2 + ct) * 64 + lane]);
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)EfT + (size_t)max(q, 0) * 4096 + (2 * ks + ct) * 1024 + lane16));
     };
 
     {   // prologue staging
-        *(u32x4*)(smem + OFF_KR + st_offR) = *(const u32x4*)kg;
-        *(u32x4*)(smem + OFF_VR + st_offR) = *(const u32x4*)vg;
+        *(u32x4*)(smem + OFF_KR + st_offR) = k_tile(0);
+        *(u32x4*)(smem + OFF_VR + st_offR) = v_tile(0);
         // zero the dS band (its never-written half must read as 0 on the first step)
         for (int o = tid * 16; o < WAVES * 32 * DB_STRIDE; o += 256 * 16) *(u32x4*)(smem + OFF_DBAND + o) = u32x4{0, 0, 0, 0};
     }
@@ -209,13 +216,17 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     for (int r = 0; r < 16; ++r)
         wcl[r] = lds_addr_of(smem) + band_base + hh * BAND_REGION + (((crow(r, hh) - a) & 63) << 2);
     const int rbase = band_base + band_rowoff(a) + 16 * hh;
-    auto band_put = [&](const f32x16& v, int q) {        // chunk q of Q.Er^T -> band
-        const uint32_t tog = (q & 1) << 7;
+    // PHYSICAL chunk parity = (chunk - q0) & 1: each wave has its own bands, so the assignment is free, and with it the
+    // chunk stored in step s has parity (s + 1) & 1 and the tile read in step s parity s & 1 for EVERY wave -- compile-time
+    // constants in the two-step main loop (with the chunk's own parity every band store paid a v_bitop3 and every dS store
+    // a v_cndmask to select the address at run time).
+    auto band_put = [&](const f32x16& v, int par) {      // a chunk of Q.Er^T -> band
+        const uint32_t tog = (uint32_t)par << 7;
 #pragma unroll
         for (int r = 0; r < 16; ++r) lds_store_f32((wcl[r] ^ tog) + r * BAND_STRIDE, v[r]);
     };
-    auto band_get = [&](int dq) {                        // Srel^T of the tile with D/32 = dq
-        const char* rb = smem + rbase + ((dq & 1) << 7);
+    auto band_get = [&](int par) {                       // Srel^T of a tile
+        const char* rb = smem + rbase + (par << 7);
         f32x16 c;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         f32x16 qe = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
-        band_put(qe, q0);
+        band_put(qe, 0);                                 // chunk q0: physical parity 0
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(q0 - 1, ks);    // new chunk of step 0
     }
@@ -245,16 +256,17 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     // (half the memory of a full [I][q] grid; the consumer treats q > I as zeros).  Inside a tile the 16-byte unit of
     // (row a, columns 16ks+8hh..+7) sits at ks*512 + a*16 + hh*8 elements -- each wave store instruction writes 1 KB
     // contiguously.
-    uint16_t* dsp = nullptr;
+    char* ds_base = nullptr;                             // wave-uniform: tile (b,h, I = q0, chunk 0)
+    const uint32_t ds_voff = (uint32_t)(a * 16 + hh * 8) * 2u;
     if (EXPORT_DS) {
         const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
-        dsp = dsrel + (((size_t)b * heads + hd) * ntri + (size_t)q0 * (q0 + 1) / 2) * 1024 + a * 16 + hh * 8;
+        ds_base = (char*)(dsrel + (((size_t)b * heads + hd) * ntri + (size_t)q0 * (q0 + 1) / 2) * 1024);
     }
     const int am = a - 4 * hh;                           // key crow(r,hh) is in the future of query a  <=>  crow(r,0) > am
 
     // ---- one tile, from S^T (band term already in c) to the exported dS chunk ---------------------------------------
     // MASKED: apply the diagonal / key-padding masks (general body only)
-    auto tile_tail = [&](f32x16& c, int dq, int cur, uint32_t pw, auto masked_tag, const bf16x8 (&et)[4]) {
+    auto tile_tail = [&](f32x16& c, int dq, int p, int cur, uint32_t pw, auto masked_tag, const bf16x8 (&et)[4]) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const char* kt = smem + OFF_KR + cur * TILE_BYTES;
 #pragma unroll
@@ -282,46 +294,50 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = c[r] * (dp[r] - dlt);
         // dqs^T += K^T dS^T
+        bf16x8 df[2];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            const bf16x8 df = acc_to_frag(c, ss);
-            dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df, dq0);
-            dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df, dq1);
+            df[ss] = acc_to_frag(c, ss);
+            dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df[ss], dq0);
+            dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df[ss], dq1);
         }
-        // un-skew dS into the (query, delta) band, then the completed chunk dq feeds dq_rel
-        if (dq & 1) {
+        // un-skew dS into the (query, delta) band -- the bf16 pairs packed for the product above are stored as their low
+        // and high halves (ds_write_b16 / ds_write_b16_d16_hi: no second conversion) --, then the completed chunk feeds dq_rel
 #pragma unroll
-            for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa1[r]) = f32_to_bf16(c[r]);
-        } else {
+        for (int ss = 0; ss < 2; ++ss) {
+            const u32x4 wv = __builtin_bit_cast(u32x4, df[ss]);               // word j: keys 8ss+2j (low), 8ss+2j+1 (high)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) *(uint16_t*)(dband + dwa0[r]) = f32_to_bf16(c[r]);
+            for (int j = 0; j < 4; ++j) {
+                const int r0 = 8 * ss + 2 * j;
+                *(uint16_t*)(dband + (p ? dwa1[r0] : dwa0[r0])) = (uint16_t)wv[j];
+                *(uint16_t*)(dband + (p ? dwa1[r0 + 1] : dwa0[r0 + 1])) = (uint16_t)(wv[j] >> 16);
+            }
         }
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2);
+            const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + (p * 32 + 16 * ks + 8 * hh) * 2);
             dq0 = mfma(et[2 * ks], gq, dq0);
             dq1 = mfma(et[2 * ks + 1], gq, dq1);
         }
     };
-    auto export_chunk = [&](int dq) {
+    auto export_chunk = [&](int dq, int p) {
         // completed chunk dq of dS[i][delta] -> workspace.  Last in the step: VMEM operations retire in order, so
         // the wait for the NEXT step's K/V tiles then only covers stores that have had a whole step to drain.
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            __builtin_nontemporal_store(*(const u32x4*)(dband + a * DB_STRIDE + ((dq & 1) * 32 + 16 * ks + 8 * hh) * 2),
-                                        (u32x4*)(dsp + (size_t)dq * 1024 + 512 * ks));   // streamed: keep K/V/E in L2
+            __builtin_nontemporal_store(*(const u32x4*)(dband + a * DB_STRIDE + (p * 32 + 16 * ks + 8 * hh) * 2),
+                                        (u32x4*)(ds_base + (size_t)dq * 2048 + 1024 * ks + ds_voff));   // streamed: keep K/V/E in L2
     };
 
-    // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: ONE branch-free body -------------
+    // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: branch-free, two steps per trip so that the
+    //      LDS buffers and the band parities of a step are compile-time constants (nmain = Q0 is a multiple of 4) -------------
     const int nmain = anypad ? 0 : Q0;                    // Q0 <= ntw - 1: a next tile always exists inside this loop
-    size_t koff = (ntw > 1) ? tile_stride : 0;            // element offset of the tile to prefetch
-    int s = 0;
-    for (; s < nmain; ++s) {
-        const int cur = s & 1;
-        const u32x4 kreg = *(const u32x4*)(kg + koff);
-        const u32x4 vreg = *(const u32x4*)(vg + koff);
-        koff += (s + 2 < ntw) ? tile_stride : 0;
+    auto main_step = [&](int s, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;     // = s & 1: LDS buffer of tile s, physical parity of chunk dq
+        const int tn = min(s + 1, ntw - 1);
+        const u32x4 kreg = k_tile(tn);
+        const u32x4 vreg = v_tile(tn);
         const int dq = q0 - s;                            // >= 1
         // fragments of ErT for chunk dq (used at the end of this step)
         bf16x8 et[4];
@@ -330,26 +346,31 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         f32x16 c = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c = mfma(qf[ks], e[ks], c);
-        band_put(c, dq - 1);
+        band_put(c, PAR ^ 1);                             // chunk dq-1
         wave_lds_fence();
-        c = band_get(dq);
+        c = band_get(PAR);
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(dq - 2, ks);      // Er chunk of the next step
         __builtin_amdgcn_sched_barrier(0x78F);             // VMEM may not sink below: the fragments are needed at the top of the next step
-        tile_tail(c, dq, cur, 0u, std::false_type{}, et);
-        *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
-        *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
-        if (EXPORT_DS) export_chunk(dq);
+        tile_tail(c, dq, PAR, PAR, 0u, std::false_type{}, et);
+        *(u32x4*)(smem + OFF_KR + (PAR ^ 1) * TILE_BYTES + st_offR) = kreg;
+        *(u32x4*)(smem + OFF_VR + (PAR ^ 1) * TILE_BYTES + st_offR) = vreg;
+        if (EXPORT_DS) export_chunk(dq, PAR);
         __syncthreads();
+    };
+    int s = 0;
+    for (; s < nmain; s += 2) {
+        main_step(s, std::integral_constant<int, 0>{});
+        main_step(s + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- general body: the diagonal 128 x 128 block (a wave is full / on its diagonal / done), padded keys ------------
     for (; s < ntw; ++s) {
         const int cur = s & 1;
-        const u32x4 kreg = *(const u32x4*)(kg + koff);
-        const u32x4 vreg = *(const u32x4*)(vg + koff);
-        koff += (s + 2 < ntw) ? tile_stride : 0;
+        const int tn = min(s + 1, ntw - 1);
+        const u32x4 kreg = k_tile(tn);
+        const u32x4 vreg = v_tile(tn);
         const int dq = q0 - s;
         if (dq >= 0) {
             const uint32_t pw = padword(s);
@@ -360,20 +381,20 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
                 f32x16 qe = zero16();
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
-                band_put(qe, dq - 1);
+                band_put(qe, cur ^ 1);
             }
             wave_lds_fence();
-            f32x16 c = band_get(dq);
+            f32x16 c = band_get(cur);
             wave_lds_fence();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(dq - 2, ks);
-            tile_tail(c, dq, cur, pw, std::true_type{}, et);
+            tile_tail(c, dq, cur, cur, pw, std::true_type{}, et);
         }
         if (s + 1 < ntw) {
             *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
             *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
         }
-        if (EXPORT_DS && dq >= 0) export_chunk(dq);
+        if (EXPORT_DS && dq >= 0) export_chunk(dq, cur);
         __syncthreads();
     }
     if (wave_on) store_rows_lds(dqkv + ((size_t)b * L + i0) * ld + hd * 64, ld, dq0, dq1, lane, 0.125f, smem + band_base);
@@ -1023,9 +1044,10 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
     const dim3 gq(bg * heads, ((L + 127) / 128) * (B / bg));
     const bool export_ds = (parts & 8) || !(parts & 16);
-    // L % 256 == 0 (cfg2, cfg4): the software-pipelined dQ kernel with 64 query rows per wave (rel_attn_bwd2.hip), in the
-    // configuration the training step uses (dS export + own delta); MGX_ATTN_DQ64=0 keeps the 32-row kernel (A/B, cross-check)
-    if ((parts & 2) && L % 256 == 0 && export_ds && dq_makes_delta && !env_is_zero("MGX_ATTN_DQ64")) {
+    // MGX_ATTN_DQ64=1 and L % 256 == 0: the software-pipelined dQ kernel with 64 query rows per wave (rel_attn_bwd2.hip), in
+    // the configuration the training step uses (dS export + own delta).  Opt-in: 0.72 ms against 0.60 ms for the kernel below
+    // at cfg2 (profiles/README.md, round 3).
+    if ((parts & 2) && L % 256 == 0 && export_ds && dq_makes_delta && env_is_one("MGX_ATTN_DQ64")) {
         if (int rc = dq64_launch(qkv, EfA, EfT, padbits, dctx, lse, delta, dqkv, dsrel, ctx, B, L, d, stream)) return rc;
     } else if (parts & 2) {
 #define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, \

@@ -28,17 +28,21 @@ using namespace relattn;
 
 namespace f3 {
 constexpr int WAVES = 8;
-constexpr int NBUF = 4;
+constexpr int NBUF = 8;
 constexpr int OFF_K = 0;                                        // 4 x 4 KiB   image R
 constexpr int OFF_V = OFF_K + NBUF * TILE_BYTES;                // 4 x 4 KiB   image T
 constexpr int OFF_BAND = OFF_V + NBUF * TILE_BYTES;             // 8 x (32 rows x 272 B) fp32 rotated bands
 constexpr int OFF_PAD = OFF_BAND + WAVES * BAND_BYTES;          // key-padding words of this batch row (first 256)
 constexpr int OFF_FLAG = OFF_PAD + 1024;
-constexpr int LDS_BYTES = OFF_FLAG + 16;                        // 103,440 B -> 1 workgroup (8 waves) per CU
+constexpr int LDS_BYTES = OFF_FLAG + 16;                        // 136,208 B -> 1 workgroup (8 waves) per CU
 constexpr float M_INIT = -1.0e37f;
 constexpr float L_SAFE = 1.0e24f;
 }  // namespace f3
 
+// RIGID: two barriers per step (every M segment faces a V segment of the SIMD partner and nothing else).
+// !RIGID: ONE barrier per step -- waves 0-3 pass it after their V segment, waves 4-7 between their M and V segments, so the
+//         partners still run the two segments in opposite order but flow freely inside a barrier interval.
+template <bool RIGID>
 __global__ __launch_bounds__(512, 2) void rel_attn_fwd_pp_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ Ef, const uint32_t* __restrict__ padbits,
     uint16_t* __restrict__ ctx, float* __restrict__ lse_out, int L, int d, int bgroup) {
@@ -68,9 +72,10 @@ __global__ __launch_bounds__(512, 2) void rel_attn_fwd_pp_kernel(
     const size_t tile_stride = (size_t)32 * ld;
     auto ef = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, Ef[(size_t)(max(q, 0) * 4 + ks) * 64 + lane]); };
 
-    // ---- prologue: tiles 0 and 1 into the ring, key-padding words -----------------------------------------------------------
+    // ---- prologue: tiles 0, 1, 2 into the ring, key-padding words --------------------------------------------------------
     *(u32x4*)(smem + st_off) = *(const u32x4*)sg;
     *(u32x4*)(smem + st_off + TILE_BYTES) = *(const u32x4*)(sg + tile_stride);
+    *(u32x4*)(smem + st_off + 2 * TILE_BYTES) = *(const u32x4*)(sg + 2 * tile_stride);          // ntile >= 8
     int anypad = 0;
     if (padbits) {
         if (tid == 0) *(volatile uint32_t*)(smem + OFF_FLAG) = 0u;
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(512, 2) void rel_attn_fwd_pp_kernel(
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, scale8(*(const u32x4*)(qp + ks * 16), 0.125f));
     }
-    // staging registers: tile 2 now, tile t+3 during step t.  Loads are clamped to the last tile (never used beyond it).
-    u32x4 sreg = *(const u32x4*)(sg + (size_t)min(2, ntile - 1) * tile_stride);
+    // staging registers: tile 3 now, tile t+4 during step t.  Loads are clamped to the last tile (never used beyond it).
+    u32x4 sreg = *(const u32x4*)(sg + (size_t)3 * tile_stride);
     __syncthreads();
 
     // band addressing (rel_attn_common.hpp).  PHYSICAL chunk parity = (chunk - q0) & 1 (each wave has its own band, so the
@@ -193,11 +198,12 @@ __global__ __launch_bounds__(512, 2) void rel_attn_fwd_pp_kernel(
                 o1 = mfma(vfr[ss][1], pf[ss], o1);
             }
         }
-        __syncthreads();
+        if (RIGID || late) __syncthreads();
         // ---- V segment ----
-        // ring: tile s+2 -> buffer (s+2) & 3 (written now, first read one barrier later); registers <- tile s+3
-        *(u32x4*)(smem + st_off + ((s + 2) & 3) * TILE_BYTES) = sreg;
-        sreg = *(const u32x4*)(sg + (size_t)min(s + 3, ntile - 1) * tile_stride);
+        // ring: tile s+3 -> buffer (s+3) & 7 (complete two barriers before its first read in V segment s+2, whichever group
+        // wrote which half; it replaces tile s-5); registers <- tile s+4
+        *(u32x4*)(smem + st_off + ((s + 3) & 7) * TILE_BYTES) = sreg;
+        sreg = *(const u32x4*)(sg + (size_t)min(s + 4, ntile - 1) * tile_stride);
         if (s <= last) {
             const int dq = q0 - s;                        // >= -1
             if (dq <= 0 || anypad) {
@@ -231,22 +237,22 @@ __global__ __launch_bounds__(512, 2) void rel_attn_fwd_pp_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) e[PAR][ks] = ef(q0 - s - 4, ks);      // multiplied in M segment s+2
             cS = band_get(PAR ^ 1);                       // Srel^T of tile s+1
-            const char* kt = smem + OFF_K + ((s + 1) & 3) * TILE_BYTES;
-            const char* vt = smem + OFF_V + (s & 3) * TILE_BYTES;
+            const char* kt = smem + OFF_K + ((s + 1) & 7) * TILE_BYTES;
+            const char* vt = smem + OFF_V + (s & 7) * TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[ks] = frag_R(kt, a, hh, ks);
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) { vfr[ss][0] = frag_T(vt, lane, ss, 0); vfr[ss][1] = frag_T(vt, lane, ss, 1); }
         }
-        __syncthreads();
+        if (RIGID || !late) __syncthreads();
     };
 
-    if (late) __syncthreads();                            // half a step behind: this group's M segments face the other's V segments
+    if (RIGID && late) __syncthreads();                   // half a step behind: this group's M segments face the other's V segments
     for (int s = 0; s < nstep; s += 2) {                  // nstep = Q0 + 9 is odd: the second call of the last trip is s = nstep
         step(s, std::integral_constant<int, 0>{});
         if (s + 1 < nstep) step(s + 1, std::integral_constant<int, 1>{});
     }
-    if (!late) __syncthreads();                           // same number of barriers for both groups
+    if (RIGID && !late) __syncthreads();                  // same number of barriers for both groups
 
     // ---- epilogue: ctx[b, i0+a, hd*64 + c] = O^T[c][a] / l ; lse = m + ln l ---------------------
     const int i0 = q0 * 32;
@@ -266,14 +272,20 @@ static int fwdpp_batch_group(int B, int L, int d) {
 // launched by mgx_rel_attn_fwd (rel_attn_fwd.hip) when L % 256 == 0; the workspace already holds the fragment-ordered Er
 int relattn::fwdpp_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, uint16_t* ctx, float* lse, int B,
                           int L, int d, void* stream) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)rel_attn_fwd_pp_kernel,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, f3::LDS_BYTES);
-    (void)attr;
+    static const hipError_t attr0 = hipFuncSetAttribute((const void*)rel_attn_fwd_pp_kernel<true>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, f3::LDS_BYTES);
+    static const hipError_t attr1 = hipFuncSetAttribute((const void*)rel_attn_fwd_pp_kernel<false>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, f3::LDS_BYTES);
+    (void)attr0; (void)attr1;
     const int bg = fwdpp_batch_group(B, L, d);
     MGX_REQUIRE((long)(L / 256) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_fwd: L/256 * batch groups too large");
     dim3 grid(bg * (d / 64), (L / 256) * (B / bg));
-    hipLaunchKernelGGL(rel_attn_fwd_pp_kernel, grid, dim3(512), f3::LDS_BYTES, (hipStream_t)stream, qkv, (const u32x4*)EfA,
-                       padbits, ctx, lse, L, d, bg);
+    if (env_is_one("MGX_ATTN_PP_RIGID"))
+        hipLaunchKernelGGL(rel_attn_fwd_pp_kernel<true>, grid, dim3(512), f3::LDS_BYTES, (hipStream_t)stream, qkv,
+                           (const u32x4*)EfA, padbits, ctx, lse, L, d, bg);
+    else
+        hipLaunchKernelGGL(rel_attn_fwd_pp_kernel<false>, grid, dim3(512), f3::LDS_BYTES, (hipStream_t)stream, qkv,
+                           (const u32x4*)EfA, padbits, ctx, lse, L, d, bg);
     MGX_CHECK_LAUNCH("mgx_rel_attn_fwd(ping-pong)");
     return MGX_OK;
 }

@@ -41,15 +41,15 @@ if a.parts & 1:
         timed(with_env("MGX_ATTN_FWD64", "0", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd32")
         timed(with_env("MGX_ATTN_FWD64", "1", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd64")
         timed(with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwdpp")
+        timed(with_env("MGX_ATTN_PP_RIGID", "1", with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None))), 3, "fwdpp_r")
 if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, ws), 0, "delta")
 if a.parts & 4:
     for _ in range(a.rounds):
         # parts 1|2 = what the training step launches: E fragment pre-pass (5 us) + the dQ kernel that makes its own delta
-        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 3, dqkv, ws), 5, "dq")
         timed(with_env("MGX_ATTN_DQ64", "0", lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 3, dqkv, ws)), 5, "dq32")
+        timed(with_env("MGX_ATTN_DQ64", "1", lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 3, dqkv, ws)), 5, "dq64")
 if a.parts & 8:
     for _ in range(a.rounds):
         timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
-        timed(with_env("MGX_ATTN_DKV64", "0", lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws)), 6, "dkv32")
 if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de")
 if a.parts & 32: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 16, dqkv, ws), 6, "de_rec")
