@@ -240,16 +240,37 @@ def _free_port():
     return port
 
 
+def _kfd_gpu_count():
+    """GPU agents of this node as the kernel driver lists them (CPU agents have simd_count 0); None if unreadable."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a torchrun environment: start N fresh ranks as CHILD processes
     (torch.distributed.run, one per GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line.  The parent
     never touches the GPU (no HIP call before or after the spawn) and never exec()s."""
     import subprocess
     if not args.one_device:
-        n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
-        if n_dev < args.gpus:
-            print(f"bench.py: --gpus {args.gpus} but only {n_dev} HIP device(s) visible", file=sys.stderr)
+        # count GPU agents from the KFD topology in sysfs: no HIP call in this process (torch.cuda.device_count() opens
+        # the HIP runtime); when sysfs says nothing, let the child ranks fail on their own set_device
+        n_dev = _kfd_gpu_count()
+        if n_dev is not None and n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) in /sys/class/kfd/kfd/topology", file=sys.stderr)
             return 2
+    # build libmgx.so ONCE here (hipcc only, no GPU call): N ranks importing a stale tree would otherwise all compile it
+    from musicgeneration_amd import _build
+    if _build.have_hipcc():
+        _build.build()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)

@@ -1012,8 +1012,7 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     MGX_REQUIRE(ws_bytes >= mgx_rel_attn_bwd_workspace(B, L, d) && ((uintptr_t)workspace & 255) == 0, MGX_ERR_SHAPE,
                 "mgx_rel_attn_bwd: workspace must be 256-byte aligned and >= mgx_rel_attn_bwd_workspace() = %zu bytes (got %zu)",
                 mgx_rel_attn_bwd_workspace(B, L, d), ws_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_once = [] {                  // thread-safe one-time init (C++11 function-local static)
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
@@ -1021,8 +1020,9 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
         hipFuncSetAttribute((const void*)rel_attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3s::LDS_BYTES);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_once;
     hipStream_t s = (hipStream_t)stream;
     const int heads = d / 64;
     const uint16_t* Er = E + (size_t)(M - L) * 64;

@@ -314,11 +314,13 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
 }
 
 static void set_fwd_attrs() {
-    static bool attr_set = false;
-    if (attr_set) return;
-    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
+    // function-local static: initialised exactly once, thread-safe (C++11), as mgx.h promises for the whole library
+    static const bool once = [] {
+        hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        return true;
+    }();
+    (void)once;
 }
 
 extern "C" size_t mgx_rel_attn_fwd_workspace(int L) { return L > 0 ? er_frag_bytes(L) : 0; }

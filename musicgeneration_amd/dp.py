@@ -20,17 +20,22 @@ import torch.distributed as dist
 class DataParallel:
     """Wraps a MusicTransformer: hooks its bucket-ready callbacks, broadcasts rank 0's weights."""
 
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, force_collectives: bool = False):
+        """``force_collectives``: issue every collective even in a world of one rank (broadcast, per-bucket all-reduce,
+        loss-weight all-reduce).  A sum over one rank is the identity, so results must be bit-identical to a run without
+        data parallelism -- which lets a single-GPU box prove RCCL communicator setup, stream ordering against the backward
+        kernels and the flat-buffer views before the first multi-GPU run (tests/test_gpu_dp.py)."""
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.force = bool(force_collectives) and dist.is_initialized()
         self._works: List = []
         self._sync = True
         self._exposed: List = []          # (event before wait, event after wait) pairs of the compute stream
         self.measure_overlap = False
         model._dp = self
-        if self.world > 1:
+        if self.world > 1 or self.force:
             st = model.store()
             dist.broadcast(st.param, src=0, group=self.pg)      # one broadcast of the flat buffer
             st.sync_shadow(force=True)
@@ -52,7 +57,7 @@ class DataParallel:
 
     def bucket_ready(self, name: str):
         """called from inside backward when every gradient of bucket ``name`` has been accumulated"""
-        if self.world == 1 or not self._sync:
+        if (self.world == 1 and not self.force) or not self._sync:
             return
         st = self.model.store()
         for bname, lo, hi in st.buckets:
@@ -95,7 +100,7 @@ class DataParallel:
         scaled by 1/world in the optimiser; multiplying rank r's loss by  n_r * world / sum_r n_r  makes the
         result the global-batch mean exactly (one 4-byte all-reduce; == 1 on pad-free data).  Device-side, no
         host sync."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return torch.ones((), dtype=torch.float32, device=n_local.device)
         tot = n_local.detach().to(torch.float32).clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.pg)
@@ -111,7 +116,7 @@ class DataParallel:
         return out
 
     def all_reduce_scalar_mean(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return t
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)

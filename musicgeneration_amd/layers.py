@@ -297,7 +297,6 @@ class Encoder(torch.nn.Module):
         p = self.rate if self.training else 0.0
         self._seed_ctr += 1
         seed = (torch.initial_seed() * 1000003 + self._seed_ctr * 64) & 0x7FFFFFFFFFFFFFFF
-        gtable = torch.zeros_like(self.embedding.weight, dtype=torch.float32)
         h = _EmbedStd.apply(tok, self.embedding.weight, self.pos_encoding.table()[: tok.shape[1]].contiguous(), p, seed)
         for layer in self.enc_layers:
             h, w = layer(h, mask)

@@ -97,7 +97,7 @@ class MusicTransformer(torch.nn.Module):
         p = self.dropout_rate if self.training else 0.0
         seed = self._next_seed()
         dp = self._dp
-        done = ((lambda name: (lambda: dp.bucket_ready(name))) if (dp is not None and dp.world > 1 and training)
+        done = ((lambda name: (lambda: dp.bucket_ready(name))) if (dp is not None and (dp.world > 1 or dp.force) and training)
                 else (lambda name: None))
 
         padbits = ops.pad_bitmap(tok, self.pad_token)
@@ -209,8 +209,11 @@ class MusicTransformer(torch.nn.Module):
         ``prefill``: "batched" runs the first P-1 prior tokens through the full-sequence (training) kernels in ONE pass and
         copies every layer's K/V rows into the caches -- a 500-event prompt costs one forward instead of 499 decode steps;
         "token" teacher-forces the prior step by step; "auto" = batched for priors of more than 32 tokens (not with
-        ``return_probs``, which wants the distribution after every prior token).  ``return_cache`` adds the per-layer
-        (K, V) caches to the result (parity tests)."""
+        ``return_probs``, which wants the distribution after every prior token; falls back to "token" when the prompt padded
+        to a multiple of 32 rows would exceed max_seq).  The two prefill paths fill the caches through different GEMM kernels
+        (same values to bf16 rounding, not bitwise), so with a fixed seed the SAMPLED continuation may differ between a
+        33-token and a 32-token prompt's path: pass ``prefill`` explicitly where run-to-run identical samples matter.
+        ``return_cache`` adds the per-layer (K, V) caches to the result (parity tests)."""
         st = self.store()
         st.sync_shadow()
         was_training = self.training
@@ -291,7 +294,12 @@ class MusicTransformer(torch.nn.Module):
         if prefill == "batched" and return_probs:
             raise ValueError("return_probs needs prefill='token' (it reports the distribution after every prior token)")
         first = 0
-        if prefill == "batched" or (prefill == "auto" and not return_probs and P > 32):
+        # the batched pass pads the prompt to a multiple of 32 rows; when that exceeds max_seq (max_seq not a multiple of 32)
+        # the full-sequence kernels cannot take it: 'auto' falls back to token-by-token prefill, 'batched' says why
+        fits = (P - 1 + 31) // 32 * 32 <= self.max_seq
+        if prefill == "batched" and not fits:
+            raise ValueError(f"prefill='batched' pads the {P - 1}-token prompt to {(P - 1 + 31) // 32 * 32} rows > max_seq={self.max_seq}")
+        if prefill == "batched" or (prefill == "auto" and not return_probs and P > 32 and fits):
             # batched prefill: positions 0..P-2 through the full-sequence kernels (causal, so the zero-padded tail up to a
             # multiple of 32 cannot reach them); token P-1 then takes the ordinary decode step below
             n = P - 1

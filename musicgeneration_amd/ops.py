@@ -303,9 +303,15 @@ def linear_dw_grouped(problems):
     parr = ctypes.cast(arr, ctypes.c_void_p)
     need = lib.mgx_linear_dw_grouped_workspace(parr, len(problems), Mrows)
     dev = problems[0][0].device
-    ws = _DW_WS.get(dev)          # per-device scratch (fp32 partial tiles of the M-splits), reused on the compute stream
+    # scratch for the fp32 partial tiles of the M-splits, one per (device, stream): two calls on different streams must not
+    # share partial tiles, and a buffer is only ever replaced by a larger one for the stream that asked (the caching allocator
+    # keeps the old block alive until that stream's work on it is done; never while a graph is being captured)
+    key = (dev, stream_ptr())
+    ws = _DW_WS.get(key)
     if need and (ws is None or ws.numel() < need):
-        ws = _DW_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("linear_dw_grouped: the workspace must exist before graph capture (run one step eagerly first)")
+        ws = _DW_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
     check(lib.mgx_linear_dw_grouped(parr, len(problems), Mrows, ptr(ws) if need else None, need, stream_ptr()),
           "mgx_linear_dw_grouped")
 

@@ -167,6 +167,7 @@ def main(argv=None):
             for b in range(nb):
                 try:
                     batch_x, batch_y = dataset.slide_seq2seq_batch(options.batch_size, options.max_seq)
+                    utils.check_pads_trail(batch_x, pad)                   # host-side, before the H2D copy
                     batch_x, batch_y = to_dev(batch_x), to_dev(batch_y)
                 except (IndexError, ValueError):
                     # the reference swallows IndexError (train.py:261-262); a file of exactly max_seq+1 events raises

@@ -52,6 +52,20 @@ def get_masked_with_pad_tensor(size, src, trg, pad_token):
     return all_pad, all_pad, key_is_pad | future[None, None]
 
 
+def check_pads_trail(batch, pad_token) -> None:
+    """Host-side guard at the data boundary (numpy / CPU tensor [B, L], before the H2D copy): padding may only TRAIL a
+    sequence.  A row whose first tokens are padding has queries with every visible key masked; there the reference's
+    softmax is a rounding artefact of ``-1e9 + x`` in fp32 (layers.py:99-102) and the kernels return the uniform average
+    over j <= i instead -- outside the parity contract, so such input is refused rather than trained on."""
+    import numpy as np
+    a = batch.numpy() if isinstance(batch, torch.Tensor) else np.asarray(batch)
+    is_pad = (a == pad_token)
+    if is_pad.any() and bool((is_pad[:, :-1] & ~is_pad[:, 1:]).any()):
+        rows = np.nonzero((is_pad[:, :-1] & ~is_pad[:, 1:]).any(axis=1))[0][:4].tolist()
+        raise ValueError(f"padding token {pad_token} is followed by a real token in batch rows {rows}: pads must only trail "
+                         "(leading / interior padding is outside the parity contract with the reference)")
+
+
 def event_indeces_to_midi_file(event_indeces, midi_file_name, velocity_scale=0.8):
     """utils.py:25-31"""
     from .sequence import EventSeq

@@ -15,8 +15,12 @@ def main(out_path):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     torch.cuda.set_device(0)
+    rccl1 = os.environ.get("MGX_TEST_RCCL1") == "1"    # one rank, backend "nccl" (= RCCL), every collective forced
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif rccl1:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{os.environ['MGX_TEST_PORT']}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
     from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
     from musicgeneration_amd.dp import DataParallel
     from musicgeneration_amd.network import MusicTransformer
@@ -27,7 +31,7 @@ def main(out_path):
     if world == 1:
         torch.manual_seed(100)
         mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0).cuda().train()
-    dp = DataParallel(mt)
+    dp = DataParallel(mt, force_collectives=rccl1)
     opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale)
     sch = CustomSchedule(d, warmup_steps=20, optimizer=opt)
     lossf = SmoothCrossEntropyLoss(0.1, V, V - 1)
@@ -39,16 +43,18 @@ def main(out_path):
             xf = xf[rank * (B // world):(rank + 1) * (B // world)]
         x, y = xf[:, :-1].to(torch.int32).cuda(), xf[:, 1:].to(torch.int32).cuda()
         loss = lossf(mt(x), y)
+        if rccl1:                                                       # the loss-weight all-reduce too (== 1 here)
+            loss = loss * dp.loss_weight((y != V - 1).sum())
         loss.backward()
         sch.step()                                                      # waits for the bucket all-reduces, then Adam
         opt.zero_grad()
         losses.append(float(dp.all_reduce_scalar_mean(loss.detach())))
     st = mt.store()
     res = {"losses": losses, "param_sum": float(st.param.double().sum()), "param_abs": float(st.param.double().abs().sum()),
-           "buckets": len(st.buckets), "bytes_reduced": dp.bytes_reduced}
+           "buckets": len(st.buckets), "bytes_reduced": dp.bytes_reduced, "describe": dp.describe()}
     if rank == 0:
         json.dump(res, open(out_path, "w"))
-    if world > 1:
+    if world > 1 or rccl1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(world, out, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(world, out, port, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     worker = os.path.join(HERE, "_dp_gpu_worker.py")
     if world == 1:
         cmd = [sys.executable, worker, out]
@@ -41,3 +41,25 @@ def test_two_ranks_match_one_process(tmp_path):
         assert abs(a - b) <= 2e-3 * abs(a), (one["losses"], two["losses"])     # bf16 kernels, atomics order
     assert abs(one["param_sum"] - two["param_sum"]) <= 1e-3 * one["param_abs"]
     assert one["losses"][-1] < one["losses"][0]
+
+
+def test_rccl_world_of_one_matches_no_dp(tmp_path):
+    """RCCL itself on the one GPU this box has: `init_process_group("nccl", world_size=1)` and a DataParallel that is
+    forced through its whole collective path -- rank-0 broadcast of the flat parameter buffer, one asynchronous
+    all-reduce per bucket on views of the flat gradient buffer issued from inside backward, wait_all before the fused
+    Adam, the 4-byte loss-weight all-reduce.  A sum over one rank is the identity, so the run must follow the run
+    without data parallelism to the run-to-run noise of the kernels' fp32 atomics (measured here by running the
+    plain configuration twice); a mis-ordering between the RCCL stream and the backward kernels (an all-reduce reading a
+    bucket before its last gradient kernel finished, Adam running before the reduce) shows up orders of magnitude above it."""
+    one = _run(1, str(tmp_path / "one.json"), 0)
+    again = _run(1, str(tmp_path / "again.json"), 0)
+    rccl = _run(1, str(tmp_path / "rccl.json"), 0, MGX_TEST_RCCL1="1", MGX_TEST_PORT=str(_free_port()))
+    assert rccl["describe"]["backend"] == "nccl" and rccl["describe"]["rccl_version"], rccl["describe"]
+    print("RCCL version", rccl["describe"]["rccl_version"])
+    assert rccl["buckets"] >= 3 and rccl["bytes_reduced"] > 0 and one["bytes_reduced"] == 0
+    noise = max(abs(a - b) / abs(a) for a, b in zip(one["losses"], again["losses"]))
+    tol = max(10 * noise, 2e-6)
+    for a, b in zip(one["losses"], rccl["losses"]):
+        assert abs(a - b) <= tol * abs(a), (one["losses"], rccl["losses"], noise)
+    pnoise = abs(one["param_sum"] - again["param_sum"]) / one["param_abs"]
+    assert abs(one["param_sum"] - rccl["param_sum"]) <= max(10 * pnoise, 1e-7) * one["param_abs"]
