@@ -445,23 +445,34 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 
     const int srow = tid >> 3, sch = tid & 7;
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
-    const uint16_t* qg = qkv_b + (size_t)(J0 + srow) * ld + hd * 64 + sch * 8;                  // + t*32*ld
-    const uint16_t* og = dctx + ((size_t)b * L + J0 + srow) * d + hd * 64 + sch * 8;            // + t*32*d
+    // Every global address of the sweep is (wave-uniform base in SGPRs) + (32-bit per-lane offset) + immediate.
+    const char* q_base = (const char*)(qkv_b + (size_t)J0 * ld + hd * 64);                      // + t * 32 rows
+    const char* o_base = (const char*)(dctx + ((size_t)b * L + J0) * d + hd * 64);
+    const uint32_t q_voff = (uint32_t)((srow * ld + sch * 8) * 2), o_voff = (uint32_t)((srow * d + sch * 8) * 2);
+    const uint32_t q_step = (uint32_t)(32 * ld * 2), o_step = (uint32_t)(32 * d * 2);
+    auto q_tile = [&](int t) { return *(const u32x4*)(q_base + (size_t)t * q_step + q_voff); };
+    auto o_tile = [&](int t) { return *(const u32x4*)(o_base + (size_t)t * o_step + o_voff); };
     // fragment ks of Er chunk q for this lane (fragment-ordered copy: 1 KB contiguous per wave load).  Every load of the
     // sweep is unconditional with a clamped index; data of clamped tiles / chunks is never used.
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto e_frag = [&](int q, int ks) {
-        return __builtin_bit_cast(bf16x8, EfA[(size_t)(min(max(q, 0), nchunk - 1) * 4 + ks) * 64 + lane]);
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)EfA + (size_t)min(max(q, 0), nchunk - 1) * 4096 + ks * 1024 + lane16));
     };
-    // lse (threads with tid&32 == 0) / delta (tid&32 != 0) of row (tid&31) of query tile t.  EVERY thread loads (threads
-    // 0..63 publish): a load under `if (tid < 64)` is a branch around VMEM, and where it rejoins the compiler drains the
-    // whole VMEM queue -- i.e. waits for the tile prefetch issued two instructions earlier, on every step.
+    // lse * log2e (threads with tid&32 == 0) / MINUS delta (tid&32 != 0) of row (tid&31) of query tile t.  EVERY thread loads
+    // (threads 0..63 publish): a load under `if (tid < 64)` is a branch around VMEM, and where it rejoins the compiler drains
+    // the whole VMEM queue -- i.e. waits for the tile prefetch issued two instructions earlier, on every step.
+    // -delta is the INITIAL accumulator of dP = dO V^T (the rows of the accumulator are the query rows), so dS = P (dP - delta)
+    // costs one multiply per element and no subtraction.
     const float* stat_ptr = ((tid & 32) ? delta : lse) + stat_base + (tid & 31);
-    const float stat_mul = (tid & 32) ? 1.f : LOG2E;
+    const float stat_mul = (tid & 32) ? -1.f : LOG2E;
     auto stat_src = [&](int t) { return stat_ptr[J0 + 32 * min(t, nT - 1)]; };     // raw; scaled by stat_mul when published
 
     {
-        const u32x4 qq = scale8(*(const u32x4*)qg, 0.125f);
-        const u32x4 oo = *(const u32x4*)og;
+        // q is NOT pre-scaled here (the forward and dQ kernels hold q/8 in registers for the whole sweep; this kernel would
+        // rescale every staged tile): 1/8 is exact, so it moves into the exponent's multiplier (log2e/8) and into the final
+        // scale of dK -- bit-identical products, 20 fewer VALU per thread and step.
+        const u32x4 qq = q_tile(0);
+        const u32x4 oo = o_tile(0);
         *(u32x4*)(smem + OFF_QR + st_offR) = qq;
         *(u32x4*)(smem + OFF_QT + st_offT) = qq;
         *(u32x4*)(smem + OFF_OR + st_offR) = oo;
@@ -519,7 +530,11 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             f32x16 qe = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR][ks], qe);
-            const uint32_t wa = wr0 + ((dq & 1) << 7);
+            // PHYSICAL parity of chunk dq = (chunk + wk) & 1 = t & 1: constant per step.  The base stays a register of its own
+            // (opaque to the optimiser): folded into the immediates, 128 + 256 k is no multiple of 64 dwords and the sixteen
+            // stores no longer pair into eight ds_write2st64_b32
+            uint32_t wa = wr0 + (cur << 7);
+            asm volatile("" : "+v"(wa));
 #pragma unroll
             for (int r = 0; r < 16; ++r) lds_store_f32(wa + crow(r, 0) * 256, qe[r]);
         }
@@ -527,7 +542,8 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             f32x16 qe = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR ^ 1][ks], qe);
-            const uint32_t wa = wr0 + (((dq - 1) & 1) << 7);
+            uint32_t wa = wr0 + ((cur ^ 1) << 7);
+            asm volatile("" : "+v"(wa));
 #pragma unroll
             for (int r = 0; r < 16; ++r) lds_store_f32(wa + crow(r, 0) * 256, qe[r]);
         }
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         wave_lds_fence();
         f32x16 c;
         {
-            const uint32_t tog = (dq & 1) << 7;
+            const uint32_t tog = (uint32_t)cur << 7;
 #pragma unroll
             for (int r = 0; r < 16; ++r) c[r] = *(lds_f32_ptr)(uintptr_t)(rd[r] ^ tog);
         }
@@ -556,7 +572,12 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             }
         }
         const char* st = smem + OFF_ST + cur * ST_BYTES;
-        f32x16 dp = zero16();
+        f32x16 dp;                                        // initial accumulator: -delta of the accumulator's query rows
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
+            dp[4 * g4] = d4.x; dp[4 * g4 + 1] = d4.y; dp[4 * g4 + 2] = d4.z; dp[4 * g4 + 3] = d4.w;
+        }
         const char* orr = smem + OFF_OR + cur * TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(orr, bl, hh, ks), vf[ks], dp);
@@ -564,12 +585,11 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
-            const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], LOG2E, -l4[k]));
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], 0.125f * LOG2E, -l4[k]));    // c = 8 S
                 c[4 * g4 + k] = p;
-                ds[4 * g4 + k] = p * (dp[4 * g4 + k] - d4[k]);
+                ds[4 * g4 + k] = p * dp[4 * g4 + k];
             }
         }
         const char* ot = smem + OFF_OT + cur * TILE_BYTES;
@@ -589,14 +609,13 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     float streg = 0.f;
     auto prefetch = [&](int t) {      // tile t + 1, clamped
         const int tn = min(t + 1, nT - 1);
-        qreg = *(const u32x4*)(qg + (size_t)tn * 32 * ld);
-        oreg = *(const u32x4*)(og + (size_t)tn * 32 * d);
+        qreg = q_tile(tn);
+        oreg = o_tile(tn);
         streg = stat_src(tn);
     };
     auto publish = [&](int nxt) {
-        const u32x4 qq = scale8(qreg, 0.125f);
-        *(u32x4*)(smem + OFF_QR + nxt * TILE_BYTES + st_offR) = qq;
-        *(u32x4*)(smem + OFF_QT + nxt * TILE_BYTES + st_offT) = qq;
+        *(u32x4*)(smem + OFF_QR + nxt * TILE_BYTES + st_offR) = qreg;
+        *(u32x4*)(smem + OFF_QT + nxt * TILE_BYTES + st_offT) = qreg;
         *(u32x4*)(smem + OFF_OR + nxt * TILE_BYTES + st_offR) = oreg;
         *(u32x4*)(smem + OFF_OT + nxt * TILE_BYTES + st_offT) = oreg;
         // every thread stores (threads >= 64 write duplicates nobody reads): a store under `tid < 64` pulls the load above
@@ -636,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 
     if (wave_on) {
         uint16_t* row0 = dqkv + ((size_t)b * L + j0) * ld + hd * 64;
-        store_rows_lds(row0 + d, ld, dk0, dk1, lane, 1.f, band);
+        store_rows_lds(row0 + d, ld, dk0, dk1, lane, 0.125f, band);      // dk = dS^T (q/8)
         store_rows_lds(row0 + 2 * d, ld, dv0, dv1, lane, 1.f, band);
     }
 }
