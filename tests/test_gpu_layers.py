@@ -89,11 +89,28 @@ def test_encoder_and_layer_forward_match_oracle():
     wsum = torch.linspace(-1, 1, hid.numel()).reshape(hid.shape)
     (hid * wsum.cuda()).sum().backward()
     (ref * wsum).sum().backward()
-    for name in ("embedding.weight", "enc_layers.0.rga.E", "enc_layers.1.FFN_pre.weight", "enc_layers.0.layernorm1.weight",
-                 "enc_layers.1.rga.fc.bias"):
-        got = dict(enc.named_parameters())[name].grad
-        # stand-alone nodes round to bf16 between every op, and these gradients have crossed both layers' hand-offs
-        assert _cos(got, pr["Decoder." + name].grad) >= 0.98, name
+    # (a) EVERY parameter against the oracle with bf16 rounding emulated at the points where the kernels store bf16: this is
+    #     the bound that pins the kernels (measured >= 0.9999 on all of them; SURVEY 8c asks 0.999)
+    R.EMULATE_BF16 = True
+    try:
+        pe = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ref_e, _ = R.decoder_stack(pe, tok, R.look_ahead_mask(tok, pad))
+        (ref_e * wsum).sum().backward()
+    finally:
+        R.EMULATE_BF16 = False
+    for name, prm in enc.named_parameters():
+        if name.endswith("Wk.bias"):      # exactly-zero true gradient (softmax shift invariance): noise on both sides
+            continue
+        assert _cos(prm.grad, pe["Decoder." + name].grad) >= 0.999, name
+        # (b) against the fp32 oracle: what bf16 ACTIVATIONS cost on this synthetic objective (a linspace-weighted sum of the
+        #     hidden states).  The floor is set by the attention-score gradients: dS = P (dP - delta) is a difference of two
+        #     O(|dO||V|) terms rounded to bf16 before the dq / dk / dE products, so Wq / Wk / E sit at 0.980-0.987 here
+        #     (measured, tools/tol_probe.py) while every other parameter is >= 0.995; halving the logit scale moves them
+        #     to 0.982-0.99, i.e. it is rounding of the score gradient, not logit blow-up.
+        #     The embedding is the other loose one (0.988): a row is the sum over the one or two positions that hold the token
+        #     (B L = 128 positions, 89 tokens), so the rounding of dX there is not averaged out.
+        floor = 0.975 if any(t in name for t in ("rga.Wq", "rga.Wk", "rga.E")) else (0.98 if name == "embedding.weight" else 0.99)
+        assert _cos(prm.grad, pr["Decoder." + name].grad) >= floor, (name, _cos(prm.grad, pr["Decoder." + name].grad))
     # one layer on its own
     x = (torch.randn(B, L, d, generator=g) * 0.5)
     out, w = enc.enc_layers[0](x.cuda(), lam.cuda())

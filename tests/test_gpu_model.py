@@ -174,13 +174,51 @@ def test_g9b_three_optimizer_steps_vs_reference_run(golden_dir):
     for k in [n[len("delta."):] for n in g if n.startswith("delta.")]:
         delta = sd[k] - p0[k]
         ref = torch.from_numpy(g["delta." + k])
-        assert _cos(delta, ref) >= 0.9, (k, _cos(delta, ref))
+        # measured 0.972 (E), 0.992, 0.999, 1.000 (tools/tol_probe.py).  E is the loosest: Adam's first steps move every
+        # element by ~lr * sign(g), so an entry whose tiny gradient flips sign under bf16 noise contributes a full-size
+        # error, and E's rows at large distances (few (i,j) pairs at L=32) are such entries
+        assert _cos(delta, ref) >= (0.96 if k.endswith("rga.E") else 0.97), (k, _cos(delta, ref))
     names = [str(n) for n in g["delta_norm_names"]]
     for k, rn in zip(names, g["delta_norms"]):
         if k.endswith("Wk.bias"):        # exactly-zero true gradient (softmax shift invariance): rounding noise on both sides
             continue
         dn = float((sd[k].double() - p0[k].double()).norm())
         assert abs(dn - rn) <= 0.15 * rn + 1e-12, (k, dn, rn)
+
+
+def test_g12_tamed_g2_shape_every_gradient_vs_reference(golden_dir):
+    """G2's shape (V=309, 2 layers, d=128, L=32, trailing pads) with tamed logits (embedding and E scaled by 0.25; fixture
+    G12 is the reference's own fp32 forward / loss / backward): every parameter gradient of the HIP path is held to the
+    fp32 reference at cosine >= 0.995 and rel-L2 <= 0.06 -- measured worst 0.9987 / 0.051 (FFN_pre.weight of the last layer;
+    tools/tol_probe.py).  SURVEY 8c asks 0.999 / 2e-2 for kernels against an oracle fed the same bf16 inputs; here the
+    model's bf16 activations are part of the error.  G2 itself (test_g2_logits_loss_grads) is a
+    raw random-init model with attention logits of ~50 -- the worst case for bf16 -- and keeps its looser fp32 bound."""
+    from musicgeneration_amd.criterion import SmoothCrossEntropyLoss
+    from musicgeneration_amd.network import MusicTransformer
+    g = _load(golden_dir, "g12_model_d128_tamed.npz")
+    p, (V, d, nl, L, B) = _params_from_oracle_init(g["shape"], int(g["seed"]), float(g["scale"]))
+    chk = float(sum(v.double().abs().sum().item() for v in p.values()))
+    assert abs(chk - float(g["p_checksum"])) <= 1e-9 * chk, "initialiser drifted: regenerate the fixture"
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0)
+    mt.load_state_dict(p)
+    mt = mt.cuda().train()
+    x = torch.from_numpy(g["x"]).cuda()
+    logits = mt(x[:, :-1].to(torch.int32))
+    ref = torch.from_numpy(g["logits"])
+    assert (logits.float().cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    loss = SmoothCrossEntropyLoss(0.1, V, V - 1)(logits, x[:, 1:].to(torch.int32))
+    assert abs(loss.item() - float(g["loss"])) <= 2e-3 * float(g["loss"])
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = {}
+    for name, prm in mt.named_parameters():
+        ref_g = torch.from_numpy(g["g." + name])
+        got = prm.grad.cpu()
+        if name.endswith("Wk.bias"):      # exactly-zero true gradient (softmax shift invariance): noise on both sides
+            continue
+        worst[name] = (_cos(got, ref_g), _rel(got, ref_g))
+    bad = {k: v for k, v in worst.items() if not (v[0] >= 0.995 and v[1] <= 0.06)}
+    assert not bad, bad
 
 
 def test_g11_d256_model_vs_reference(golden_dir):
