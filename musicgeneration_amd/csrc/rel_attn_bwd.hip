@@ -508,13 +508,13 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     __syncthreads();
     const int band_base = OFF_BAND + w * 8192;
     char* band = smem + band_base;
-    // band (plain [32 query rows][64 distances] fp32): QE[ar][t] of chunk q is written at column 32(q&1) + t; the tile reads
-    // column (D + ar - bl) & 63 of row ar = crow(r,hh).  rd[r] = ABSOLUTE LDS address for D/32 even; odd flips address bit 7
-    // (row bases are multiples of 256): one VALU per read.
+    // band (plain [32 query rows][32 merged distances] fp32, 4 KB per wave; the 8 KB slot also serves as the epilogue's store
+    // patch): merged[ar][t] is written at column t (lane-linear, conflict-free); the tile reads column (ar - bl) & 31 of row
+    // ar = crow(r,hh) (a permutation of the 32 banks).  rd[r] = ABSOLUTE LDS address of that element.
     uint32_t rd[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rd[r] = lds_addr_of(smem) + band_base + crow(r, hh) * 256 + (((crow(r, hh) - bl) & 63) << 2);
-    const uint32_t wr0 = lds_addr_of(smem) + band_base + hh * 1024 + bl * 4;      // + crow(r,0)*256 as the immediate
+    for (int r = 0; r < 16; ++r) rd[r] = lds_addr_of(smem) + band_base + crow(r, hh) * 128 + (((crow(r, hh) - bl) & 31) << 2);
+    const uint32_t wr0 = lds_addr_of(smem) + band_base + hh * 512 + bl * 4;       // + crow(r,0)*128 as the immediate
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
     // ---- one query tile.  cur = t & 1 (LDS buffers), PAR = E slot of the hi chunk; MASKED: diagonal / padded-key masks ----
@@ -525,39 +525,31 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         bf16x8 qa[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_R(qr, bl, hh, ks);
-        // QE for chunks dq and dq-1: rows = query a, cols = t
-        {
-            f32x16 qe = zero16();
+        // Q.Er^T for chunks dq ("hi": keys bl <= query, t = a - bl) and dq-1 ("lo": keys bl > query, t = 32 + a - bl); rows =
+        // query a, columns = t.  A tile reads column (a - bl) & 31 of row a and needs the hi chunk there for t <= a and the lo
+        // chunk for t > a: the two products are MERGED in registers (one v_cndmask per element) and stored once -- 16 band
+        // stores per tile instead of 32, a 4 KB band per wave instead of an 8 KB ring, and no parity in any address (this
+        // kernel computes both chunks for every tile anyway: unlike the forward / dQ kernels nothing is reused by the next tile).
+        f32x16 qe = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR][ks], qe);
-            // PHYSICAL parity of chunk dq = (chunk + wk) & 1 = t & 1: constant per step.  The base stays a register of its own
-            // (opaque to the optimiser): folded into the immediates, 128 + 256 k is no multiple of 64 dwords and the sixteen
-            // stores no longer pair into eight ds_write2st64_b32
-            uint32_t wa = wr0 + (cur << 7);
-            asm volatile("" : "+v"(wa));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lds_store_f32(wa + crow(r, 0) * 256, qe[r]);
-        }
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR][ks], qe);
         if (!MASKED || dq >= 1) {
-            f32x16 qe = zero16();
+            f32x16 ql = zero16();
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR ^ 1][ks], qe);
-            uint32_t wa = wr0 + ((cur ^ 1) << 7);
-            asm volatile("" : "+v"(wa));
+            for (int ks = 0; ks < 4; ++ks) ql = mfma(qa[ks], e[PAR ^ 1][ks], ql);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) lds_store_f32(wa + crow(r, 0) * 256, qe[r]);
+            for (int r = 0; r < 16; ++r) qe[r] = (bl <= crow(r, hh)) ? qe[r] : ql[r];
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds_store_f32(wr0 + crow(r, 0) * 128, qe[r]);
         // the lo slot is free now: fetch the next step's hi chunk into it
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
         if (!MASKED) __builtin_amdgcn_sched_barrier(0x78F);    // VMEM may not sink below: needed at the top of the next step
         wave_lds_fence();
         f32x16 c;
-        {
-            const uint32_t tog = (uint32_t)cur << 7;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = *(lds_f32_ptr)(uintptr_t)(rd[r] ^ tog);
-        }
+        for (int r = 0; r < 16; ++r) c[r] = *(lds_f32_ptr)(uintptr_t)rd[r];
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c = mfma(qa[ks], kf[ks], c);
