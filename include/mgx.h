@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64] */
-#define MGX_ABI_VERSION 11
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad) */
+#define MGX_ABI_VERSION 12
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -146,6 +146,12 @@ int mgx_linear_ln_fwd(const uint16_t* X, const uint16_t* RES, const float* gamma
                       const uint16_t* W, const float* bias, uint16_t* C, uint16_t* Z, int M, int N, int K, int act,
                       void* stream);
 
+/* Decode-step fusion (ABI 12; M <= 32 rows): H bf16 [M,K] = table[tok]*sqrt(K) + pe[t] (layers.py:226-229) and
+ * C bf16 [M,N] = H W^T + bias in one launch (the embedding rides in the first QKV projection of a decode step).          */
+int mgx_decode_embed_linear(const int32_t* tok, const float* table, const float* pe, const int32_t* pos_dev,
+                            const uint16_t* W, const float* bias, uint16_t* C, uint16_t* H, int M, int N, int K, int V,
+                            void* stream);
+
 /* backward of the above (autograd of the same reference lines):
  * dX bf16 [M,K] = dY bf16 [M,N] @ W bf16 [N,K]; if relu_y (bf16 [M,K]) is given, dX is zeroed where
  * relu_y <= 0 (the backward of a ReLU fused into the producer of this layer's input); if addend
@@ -187,6 +193,8 @@ int mgx_decode_embed(const int32_t* tok, const float* table, const float* pe, co
 /* Long caches are split over several workgroups per (b,h) whose partial results a second kernel merges: workspace =
  * caller scratch >= mgx_rel_attn_decode_workspace(B, Lmax, d) bytes (0 for short caches: NULL is accepted then).      */
 size_t mgx_rel_attn_decode_workspace(int B, int Lmax, int d);
+/* key splits per (b,h) for this cache length (1 = no workspace, no merge launch).                                    */
+int mgx_rel_attn_decode_splits(int B, int Lmax, int d);
 int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, uint16_t* vcache, const uint16_t* E,
                         const int32_t* pos_dev, uint16_t* ctx, void* workspace, size_t ws_bytes,
                         int B, int Lmax, int d, int M, void* stream);

@@ -13,7 +13,7 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 # the ABI the SIGNATURES table below was written for (MGX_ABI_VERSION of include/mgx.h).  A left-over
 # libmgx.so of another ABI still exports the same names: calling it with this table would shift arguments.
-EXPECTED_ABI = 11
+EXPECTED_ABI = 12
 
 # name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
 SIGNATURES = {
@@ -48,6 +48,8 @@ SIGNATURES = {
     "mgx_dropout_bf16": [_vp, _vp, _sz, _f, _u64, _vp],
     "mgx_scatter_add_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_linear_ln_fwd": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_decode_embed_linear": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_decode_splits": [_i, _i, _i],
     "mgx_linear_dw_grouped": [_vp, _i, _i, _vp, _sz, _vp],
     "mgx_linear_dw_grouped_workspace": [_vp, _i, _i],     # returns size_t
     "mgx_linear_dw": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const int32_t* __rest
 // partial (m, l, acc[64]) and a tiny second kernel merges them by their maxima.  The new row t is taken from qkv_new by
 // whichever split covers it (another workgroup appends it to the cache in the same launch).
 constexpr int DEC_WAVES = 8;
-constexpr int DEC_PART = 66;                                   // floats per partial: m, l, acc[64]
+constexpr int DEC_PART = 68;                                   // floats per partial: acc[64], m, l, 2 pad (16-byte aligned rows)
 __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
     const uint16_t* __restrict__ qkv_new, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
     const uint16_t* __restrict__ E, const int32_t* __restrict__ pos_dev, uint16_t* __restrict__ ctx,
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
             ctx[(size_t)b * d + hd * 64 + tid] = f32_to_bf16(o / ll);
         } else {                                                // an empty split leaves (m = -inf, l = 0, acc = 0)
             float* pp = partial + ((size_t)blockIdx.x * nsplit + sp) * DEC_PART;
-            if (tid == 0) { pp[0] = mm; pp[1] = ll; }
-            pp[2 + tid] = o;
+            if (tid == 0) { pp[64] = mm; pp[65] = ll; }
+            pp[tid] = o;
         }
     }
 }
@@ -147,13 +147,13 @@ __global__ __launch_bounds__(64) void rel_attn_decode_merge_kernel(const float* 
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = threadIdx.x;
     const float* pp = partial + (size_t)blockIdx.x * nsplit * DEC_PART;
     float mm = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, pp[s * DEC_PART]);
+    for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, pp[s * DEC_PART + 64]);
     float ll = 0.f, o = 0.f;
     for (int s = 0; s < nsplit; ++s) {
-        const float ms = pp[s * DEC_PART];
+        const float ms = pp[s * DEC_PART + 64];
         const float a = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - mm);
-        ll += pp[s * DEC_PART + 1] * a;
-        o += pp[s * DEC_PART + 2 + c] * a;
+        ll += pp[s * DEC_PART + 65] * a;
+        o += pp[s * DEC_PART + c] * a;
     }
     ctx[(size_t)b * d + hd * 64 + c] = f32_to_bf16(o / ll);
 }
@@ -309,6 +309,10 @@ static int decode_splits(int B, int Lmax, int d) {
     int s = 1;
     while (s < 8 && wgs * s < 1024 && Lmax / (2 * s) >= 512) s *= 2;
     return s;
+}
+
+extern "C" int mgx_rel_attn_decode_splits(int B, int Lmax, int d) {
+    return (B <= 0 || d <= 0 || Lmax <= 0) ? 0 : decode_splits(B, Lmax, d);
 }
 
 extern "C" size_t mgx_rel_attn_decode_workspace(int B, int Lmax, int d) {

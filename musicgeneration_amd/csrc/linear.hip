@@ -1248,6 +1248,60 @@ __global__ __launch_bounds__(256) void linear_skinny_ln_kernel(const uint16_t* _
     }
 }
 
+
+// =================================================================================================
+// Decode-step fusion (M <= 32 rows = the decode batch): linear_skinny_embed_kernel computes H = emb[tok] sqrt(d) + PE[t]
+// (layers.py:226-229) inside the first QKV projection (8.4 us against 4.7 + 5.2 us for the two launches).
+// Two further fusions were built and measured in round 3 and are NOT kept (profiles/README.md): the split-K attention merge
+// inside the output projection (16.7 us against 4.8 + 5.2: the fp32 partials are 8x the bytes of the bf16 context row and
+// every workgroup re-merges them) and LN1 + FFN_pre + ReLU + FFN_suf in one launch with the hidden layer recomputed per
+// workgroup (47 us against 9.4 + 5.2: 16 workgroups each stream all of W1 behind a 32-row operand with ~8 KB in flight per
+// wave -- the chain is bound by dependent L2 round trips, and recomputation multiplies them).
+// =================================================================================================
+__global__ __launch_bounds__(256) void linear_skinny_embed_kernel(const int32_t* __restrict__ tok, const float* __restrict__ table,
+                                                                  const float* __restrict__ pe, const int32_t* __restrict__ pos_dev,
+                                                                  const uint16_t* __restrict__ W, const float* __restrict__ bias,
+                                                                  uint16_t* __restrict__ C, uint16_t* __restrict__ H, int M, int N,
+                                                                  int K, int V, float scale) {
+    __shared__ float part[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n0 = blockIdx.x * 32;
+    const int kq = K >> 2;
+    const int nrow = n0 + l31, mrow = l31;
+    const bool nv = nrow < N, mv = mrow < M;
+    int t = tok[mv ? mrow : 0];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    const int pos = pos_dev[0];
+    const float* tp = table + (size_t)t * K + w * kq + hh * 8;
+    const float* pp = pe + (size_t)pos * K + w * kq + hh * 8;
+    const uint16_t* wp = W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    f32x16 acc = zero16();
+    for (int k0 = 0; k0 < kq; k0 += 16) {
+        const u32x4 wf = nv ? *(const u32x4*)(wp + k0) : u32x4{0, 0, 0, 0};
+        const f32x4 a0 = *(const f32x4*)(tp + k0), a1 = *(const f32x4*)(tp + k0 + 4);
+        const f32x4 p0 = *(const f32x4*)(pp + k0), p1 = *(const f32x4*)(pp + k0 + 4);
+        const float f[8] = {a0.x * scale + p0.x, a0.y * scale + p0.y, a0.z * scale + p0.z, a0.w * scale + p0.w,
+                            a1.x * scale + p1.x, a1.y * scale + p1.y, a1.z * scale + p1.z, a1.w * scale + p1.w};
+        const u32x4 xf = mv ? pack8(f) : u32x4{0, 0, 0, 0};
+        if (blockIdx.x == 0 && mv) *(u32x4*)(H + (size_t)mrow * K + w * kq + hh * 8 + k0) = xf;
+        acc = mfma(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[w][crow(r, hh)][l31] = acc[r];
+    __syncthreads();
+    const int n = tid >> 3, m4 = (tid & 7) * 4;
+    if (n0 + n < N) {
+        const float bv = bias ? bias[n0 + n] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = m4 + k;
+            if (m < M) C[(size_t)m * N + n0 + n] = f32_to_bf16(part[0][n][m] + part[1][n][m] + part[2][n][m] + part[3][n][m] + bv);
+        }
+    }
+}
+
 static bool g_attr_set = false;
 static void set_attrs() {
     if (g_attr_set) return;
@@ -1468,3 +1522,15 @@ extern "C" int mgx_linear_ln_fwd(const uint16_t* X, const uint16_t* RES, const f
     return MGX_OK;
 }
 
+
+extern "C" int mgx_decode_embed_linear(const int32_t* tok, const float* table, const float* pe, const int32_t* pos_dev,
+                                       const uint16_t* W, const float* bias, uint16_t* C, uint16_t* H, int M, int N, int K,
+                                       int V, void* stream) {
+    MGX_REQUIRE(tok && table && pe && pos_dev && W && C && H, MGX_ERR_NULL, "mgx_decode_embed_linear: NULL pointer");
+    MGX_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 64 == 0 && V > 0, MGX_ERR_SHAPE,
+                "mgx_decode_embed_linear: need 0<M<=32, K%%64==0 (got M=%d N=%d K=%d)", M, N, K);
+    hipLaunchKernelGGL(linear_skinny_embed_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, tok, table, pe, pos_dev,
+                       W, bias, C, H, M, N, K, V, sqrtf((float)K));
+    MGX_CHECK_LAUNCH("mgx_decode_embed_linear");
+    return MGX_OK;
+}

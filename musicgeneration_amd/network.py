@@ -7,6 +7,8 @@ fallback: ``forward`` on a CPU tensor raises.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import List, Optional
 
@@ -259,13 +261,17 @@ class MusicTransformer(torch.nn.Module):
             allow = torch.as_tensor(np.ascontiguousarray(grammar).view(np.int32) if isinstance(grammar, np.ndarray) else grammar)
             allow = allow.to(device=dev, dtype=torch.int32).contiguous()
 
-        # decode-size batches: every LayerNorm rides in the projection that consumes it (mgx_linear_ln_fwd), 34 launches
-        # per token instead of 46
+        # decode-size batches: every LayerNorm rides in the projection that consumes it (mgx_linear_ln_fwd) and the embedding in
+        # the first QKV projection (mgx_decode_embed_linear): 39 launches per token instead of 46
         fuse_ln = B <= 32 and d <= 1024
 
         def step(sample_into_out: bool):
-            h = ops.decode_embed(tok, Pm["Decoder.embedding.weight"].data, pe, pos, hbuf)
-            qkv = ops.linear_fwd(h, layers[0]["wqkv"], layers[0]["bqkv"], 0)
+            if fuse_ln:
+                qkv, h = ops.decode_embed_linear(tok, Pm["Decoder.embedding.weight"].data, pe, pos, layers[0]["wqkv"],
+                                                 layers[0]["bqkv"], hbuf)
+            else:
+                h = ops.decode_embed(tok, Pm["Decoder.embedding.weight"].data, pe, pos, hbuf)
+                qkv = ops.linear_fwd(h, layers[0]["wqkv"], layers[0]["bqkv"], 0)
             for i, ly in enumerate(layers):
                 ops.rel_attn_decode(qkv, kc[i], vc[i], ly["E"], pos, ctxbuf, attn_ws)
                 a = ops.linear_fwd(ctxbuf, ly["wfc"], ly["bfc"], 0)

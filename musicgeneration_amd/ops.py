@@ -325,6 +325,21 @@ def decode_embed(tok, table, pe, pos_dev, out):
     return out
 
 
+def decode_embed_linear(tok, table, pe, pos_dev, w, bias, hout):
+    """h = table[tok]*sqrt(d) + pe[t] (written to ``hout`` bf16 [B,d]) and c bf16 [B,N] = h w^T + bias in one launch"""
+    _need_cuda(tok, table, pe, pos_dev, w, bias, hout)
+    V, d = table.shape
+    N = w.shape[0]
+    c = torch.empty(tok.numel(), N, dtype=torch.bfloat16, device=w.device)
+    check(_lib.load().mgx_decode_embed_linear(ptr(tok), ptr(table), ptr(pe), ptr(pos_dev), ptr(w), ptr(bias), ptr(c), ptr(hout),
+                                              tok.numel(), N, d, V, stream_ptr()), "mgx_decode_embed_linear")
+    return c, hout
+
+
+def rel_attn_decode_splits(B, Lmax, d) -> int:
+    return int(_lib.load().mgx_rel_attn_decode_splits(B, Lmax, d))
+
+
 def rel_attn_decode_workspace(B, Lmax, d, device):
     """scratch for the split-K partials of mgx_rel_attn_decode (None when the cache is short enough for one workgroup per
     (b,h)); allocate once per generation: the decode step is graph-captured, so the buffer must outlive the graph"""
