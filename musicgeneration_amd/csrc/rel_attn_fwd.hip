@@ -358,7 +358,13 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
     }
     const int bg = batch_group(B, L, d);
     dim3 grid(bg * (d / 64), ((L + 127) / 128) * (B / bg));
-    hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
+    static const int occ_lds = [] {        // experiment: MGX_FWD_LDS pads the dynamic LDS to lower the residency (timing only)
+        const char* e = getenv("MGX_FWD_LDS");
+        const int v = e ? atoi(e) : 0;
+        if (v > LDS_BYTES) hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        return v > LDS_BYTES ? v : LDS_BYTES;
+    }();
+    hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), occ_lds, (hipStream_t)stream, qkv,
                        (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d, bg);
     MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");
     return MGX_OK;
