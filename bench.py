@@ -229,7 +229,7 @@ def pmc_traffic(kernel, B, L, d):
     FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
     Only reported when this run has the shape the counters were collected on (cfg2, per-GPU batch 32)."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(prof, f) for f in ("r02_traffic_cfg2_b32.json", "r01_traffic_cfg2_b32.json")
+    path = next((os.path.join(prof, f) for f in ("r03_traffic_cfg2_b32.json", "r02_traffic_cfg2_b32.json", "r01_traffic_cfg2_b32.json")
                  if os.path.exists(os.path.join(prof, f))), None)
     if path is None or (B, L, d) != (32, 2048, 512):
         return {"traffic": None}

@@ -25,6 +25,7 @@ if a.kernel == "fwd":
         ctx, rec = ops.rel_attn_fwd(qkv, E, None)
 else:
     os.environ["MGX_ATTN_FWD64"] = "0"
+    os.environ["MGX_ATTN_DQ64"] = "1"
     ctx, lse = ops.rel_attn_fwd(qkv, E, None)
     lib = ops._lib.load()
     ws = torch.empty(lib.mgx_rel_attn_bwd_workspace(a.B, a.L, a.d), dtype=torch.uint8, device=dev)
