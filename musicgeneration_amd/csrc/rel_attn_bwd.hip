@@ -401,6 +401,174 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
 }
 
 // ================================================================================================
+// K1L: dQ from STORED dS.  When dK/dV and dQ are both wanted, the dK/dV kernel runs first and leaves every dS tile in the
+// workspace (bf16, its own operand registers); dq = dS (K + Er-band) / 8 then needs no S / Q.Er^T / exp / dP at all: 8 MFMA
+// per 32x32 tile instead of 28, fed by a 2 KB tile load.  Same sweep and ownership as K1 (workgroup = 128 query rows, wave =
+// 32 rows, key tiles 0..diagonal, K staged through LDS); HBM-bound (the causal half of dS, read once).
+//   stored tile: lane (j = lane&31, hh) holds dS[i = crow(8ss+k,hh)][j]: queries on registers, keys on lanes.
+//   * dqs^T[c][i] += K^T[c][j] dS^T[j][i]: the tile is parked row-major [j][i] in a wave-private image-T patch and read back
+//     with transposing LDS reads as the B operand (k order kappa, matching frag_T_onR of the K tile);
+//   * the same registers are scattered into the (query, distance & 63) band exactly as K1 does; the completed chunk is the
+//     B operand of dqs^T += ErT . dS_rel^T and (EXPORT_REL) goes to the workspace for the dE kernel.
+// ================================================================================================
+namespace k1l {
+constexpr int OFF_KR = 0;                                  // 2 x 4K  K image R (tile t in slot t & 1)
+constexpr int OFF_ET = OFF_KR + 2 * TILE_BYTES;            // 8 x 4K  ErT chunk fragments, ring: chunk Q0 - k in slot k & 7
+constexpr int XROW = 72;                                   // bytes per row of the dS^T patch: 32 queries + pad (lane-per-row writes and the
+                                                           // transposing reads both hit distinct 8-byte bank groups)
+constexpr int OFF_X = OFF_ET + 8 * 4096;                   // 4 x 2,304 B  dS^T tile [32 j][32 i]
+constexpr int DB_STRIDE = 144;
+constexpr int OFF_DBAND = OFF_X + WAVES * 32 * XROW;       // 4 x 4,608 B bf16 [32][72]: dS by (query, delta&63)
+constexpr int LDS_BYTES = OFF_DBAND + WAVES * 32 * DB_STRIDE;   // 68,608 B -> 2 workgroups per CU
+constexpr int DEPTH = 4;                                   // dS tiles in flight per wave (2 KB each)
+}  // namespace k1l
+
+template <bool EXPORT_REL>
+__global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
+    const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfT, const uint16_t* __restrict__ dst,
+    uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel, int L, int d, int bgroup) {
+    using namespace k1l;
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a = lane & 31, hh = lane >> 5;
+    const int heads = d >> 6;
+    const int nqb = (L + 127) >> 7;
+    const int b = (blockIdx.y / nqb) * bgroup + blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int qb = nqb - 1 - (blockIdx.y % nqb);           // heaviest query blocks first
+    const int I0 = qb * 128, Q0 = I0 >> 5;
+    const int nchunk = L >> 5;
+    const bool wave_on = I0 + w * 32 < L;
+    const int q0 = wave_on ? Q0 + w : nchunk - 1;          // a wave beyond the end runs on clamped data and stores nothing
+    const int i0 = q0 * 32;
+    const int ntw = min(Q0 + 4, nchunk);
+    const size_t ld = (size_t)3 * d;
+    const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
+
+    // Per step the workgroup fetches ONE K tile and ONE ErT chunk (4 KB each, 16 bytes per thread) for its four waves -- wave w
+    // multiplies with chunk Q0 + w - s, i.e. the chunk wave 0 used w steps earlier -- and each wave its own 2 KB dS tile.  Item k
+    // (K tile k / chunk Q0 - k) is requested at the end of step k - 3, parked in registers for two steps, written to LDS at the
+    // end of step k - 1 and read from step k on.
+    const int srow = tid >> 3, sch = tid & 7;
+    const int st_offR = imgR_off(srow, sch);
+    const char* k_base = (const char*)(qkv_b + d + hd * 64);
+    const uint32_t k_voff = (uint32_t)((srow * ld + sch * 8) * 2);
+    const uint32_t tile_bytes = (uint32_t)(32 * ld * 2);
+    auto k_tile = [&](int t) { return *(const u32x4*)(k_base + (size_t)min(t, ntw - 1) * tile_bytes + k_voff); };
+    const uint32_t tid16 = (uint32_t)tid * 16u, lane16 = (uint32_t)lane * 16u;
+    auto e_item = [&](int k) {                             // this thread's 16 bytes of chunk Q0 - k (fragment-ordered copy of ErT)
+        return *(const u32x4*)((const char*)EfT + (size_t)min(max(Q0 - k, 0), nchunk - 1) * 4096 + tid16);
+    };
+    const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
+    const size_t row_tiles = ((size_t)b * heads + hd) * ntri + (size_t)q0 * (q0 + 1) / 2;      // tile (b,h, I = q0, 0)
+    const char* ds_row = (const char*)(dst + row_tiles * 1024);
+    // read once: streamed past L2 (K / ErT stay); index clamped to the wave's diagonal, clamped tiles are never used
+    auto ds_load = [&](int J, int ss) {
+        return __builtin_nontemporal_load((const u32x4*)(ds_row + (size_t)min(J, q0) * 2048 + ss * 1024 + lane16));
+    };
+
+    u32x4 dsr[DEPTH][2];
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) { dsr[j][0] = ds_load(j, 0); dsr[j][1] = ds_load(j, 1); }
+    *(u32x4*)(smem + OFF_KR + st_offR) = k_tile(0);
+#pragma unroll
+    for (int k = -3; k <= 0; ++k) *(u32x4*)(smem + OFF_ET + (k & 7) * 4096 + tid16) = e_item(k);
+    u32x4 kq[2] = {k_tile(1), k_tile(2)}, eq[2] = {e_item(1), e_item(2)};
+    for (int o = tid * 16; o < WAVES * 32 * DB_STRIDE; o += 256 * 16) *(u32x4*)(smem + OFF_DBAND + o) = u32x4{0, 0, 0, 0};
+    __syncthreads();
+
+    char* xt = smem + OFF_X + w * (32 * XROW);
+    char* dband = smem + OFF_DBAND + w * (32 * DB_STRIDE);
+    const int xw0 = a * XROW + 8 * hh;                    // + 16 * (2ss + jq): the 8-byte piece (ss, jq) of this lane's row
+    const int xi = lane & 15, xg = lane >> 4;
+    const int xr0 = ((xi >> 2) + 4 * hh) * XROW + 32 * (xg & 1) + 8 * (xi & 3);     // transposing read, + (16s + 8jq) * XROW
+    int dwa0[16], dwa1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        dwa0[r] = crow(r, hh) * DB_STRIDE + (((crow(r, hh) - a) & 63) << 1);
+        dwa1[r] = crow(r, hh) * DB_STRIDE + (((crow(r, hh) - a + 32) & 63) << 1);
+    }
+    f32x16 dq0 = zero16(), dq1 = zero16();
+    char* rel_base = nullptr;
+    const uint32_t rel_voff = (uint32_t)(a * 16 + hh * 8) * 2u;
+    if (EXPORT_REL) rel_base = (char*)(dsrel + row_tiles * 1024);
+
+    // dS^T patch -> B operand (k order kappa): X[16s + 8jq + 4hh + rq][lane&31]
+    auto frag_X = [&](int s) {
+        bf16x8 out;
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+            const bf16x4 t4 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(xt + xr0 + (16 * s + 8 * jq) * XROW));
+            out[4 * jq + 0] = t4[0]; out[4 * jq + 1] = t4[1]; out[4 * jq + 2] = t4[2]; out[4 * jq + 3] = t4[3];
+        }
+        return out;
+    };
+    auto compute = [&](int dq, int p, const char* kt, const char* ec, const u32x4 (&t)[2]) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            *(u32x2*)(xt + xw0 + 16 * (2 * ss)) = u32x2{t[ss].x, t[ss].y};
+            *(u32x2*)(xt + xw0 + 16 * (2 * ss + 1)) = u32x2{t[ss].z, t[ss].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r0 = 8 * ss + 2 * j;
+                *(uint16_t*)(dband + (p ? dwa1[r0] : dwa0[r0])) = (uint16_t)t[ss][j];
+                *(uint16_t*)(dband + (p ? dwa1[r0 + 1] : dwa0[r0 + 1])) = (uint16_t)(t[ss][j] >> 16);
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 df = frag_X(ss);
+            dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df, dq0);
+            dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df, dq1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + (p * 32 + 16 * ks + 8 * hh) * 2);
+            dq0 = mfma(*(const bf16x8*)(ec + (2 * ks) * 1024 + lane16), gq, dq0);
+            dq1 = mfma(*(const bf16x8*)(ec + (2 * ks + 1) * 1024 + lane16), gq, dq1);
+            if (EXPORT_REL)
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, gq), (u32x4*)(rel_base + (size_t)dq * 2048 + 1024 * ks + rel_voff));
+        }
+        wave_lds_fence();                                  // the patch and the band half are rewritten by the next step
+    };
+    // one step: SLOT = s & 3 (registers of the dS tile), PAR = s & 1 (K slot, physical parity of the completed chunk)
+    auto step = [&](int s, auto slot_tag, bool active) {
+        constexpr int SLOT = decltype(slot_tag)::value, PAR = SLOT & 1;
+        const u32x4 t[2] = {dsr[SLOT][0], dsr[SLOT][1]};
+        dsr[SLOT][0] = ds_load(s + DEPTH, 0);
+        dsr[SLOT][1] = ds_load(s + DEPTH, 1);
+        if (active) compute(q0 - s, PAR, smem + OFF_KR + PAR * TILE_BYTES, smem + OFF_ET + ((s - w) & 7) * 4096, t);
+        // items s+1 (requested two steps ago): the K slot was last read in step s-1, the chunk slot in step s-4
+        *(u32x4*)(smem + OFF_KR + (PAR ^ 1) * TILE_BYTES + st_offR) = kq[PAR];
+        *(u32x4*)(smem + OFF_ET + ((s + 1) & 7) * 4096 + tid16) = eq[PAR];
+        // the freed registers take items s+3 (no register rotation: a move of a register with a load in flight is a wait)
+        kq[PAR] = k_tile(s + 3);
+        eq[PAR] = e_item(s + 3);
+        __syncthreads();
+    };
+    using S0_ = std::integral_constant<int, 0>; using S1_ = std::integral_constant<int, 1>;
+    using S2_ = std::integral_constant<int, 2>; using S3_ = std::integral_constant<int, 3>;
+    static_assert(DEPTH == 4, "the loops below are unrolled by DEPTH");
+    // entered with loads in flight the loop gets an s_waitcnt vmcnt(0) at its top (the compiler merges the unknown entry state
+    // into every trip): drain once here, the loop then keeps its own four steps of requests outstanding
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int s = 0;
+    for (; s < Q0; s += 4) {                               // tiles strictly below every wave's diagonal (Q0 is a multiple of 4)
+        step(s, S0_{}, true);
+        step(s + 1, S1_{}, true);
+        step(s + 2, S2_{}, true);
+        step(s + 3, S3_{}, true);
+    }
+    // the diagonal 128 x 128 block (s = Q0 here): a wave is full / on its diagonal / done
+    step(s, S0_{}, q0 - s >= 0);
+    if (s + 1 < ntw) step(s + 1, S1_{}, q0 - s - 1 >= 0);
+    if (s + 2 < ntw) step(s + 2, S2_{}, q0 - s - 2 >= 0);
+    if (s + 3 < ntw) step(s + 3, S3_{}, q0 - s - 3 >= 0);
+    if (wave_on) store_rows_lds(dqkv + ((size_t)b * L + i0) * ld + hd * 64, ld, dq0, dq1, lane, 0.125f, dband);
+}
+
+// ================================================================================================
 // K2: dK, dV.  workgroup = 128 keys (wave = 32 keys, K/V row fragments in registers), sweeps query
 // tiles i0 = J0, J0+32, ...  orientation: queries on registers, keys on lanes (S, P, dP, dS);
 // accumulators dK^T[c][b], dV^T[c][b].
@@ -420,10 +588,11 @@ constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 66,064 B -> 2 work
 // the next "lo" chunk), so E needs no LDS here.
 }  // namespace k2
 
+template <bool EXPORT_DS>
 __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
-    uint16_t* __restrict__ dqkv, int L, int d, int bgroup) {
+    uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dst, int L, int d, int bgroup) {
     using namespace k2;
     extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band reads XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x, lane = tid & 63;
@@ -516,9 +685,27 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     for (int r = 0; r < 16; ++r) rd[r] = lds_addr_of(smem) + band_base + crow(r, hh) * 128 + (((crow(r, hh) - bl) & 31) << 2);
     const uint32_t wr0 = lds_addr_of(smem) + band_base + hh * 512 + bl * 4;       // + crow(r,0)*128 as the immediate
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    // EXPORT_DS: every dS tile goes to the workspace as the operand registers this wave multiplies with q (bf16, the dK
+    // product's own rounding): tile (b,h, I = query tile, J = key tile <= I) is 2 KB at ((bh*T + I(I+1)/2 + J)*1024 elements,
+    // T = nchunk(nchunk+1)/2 (causal half); inside a tile unit (ss, lane) = 16 bytes at ss*512 + lane*8 elements holds
+    // dS[i = crow(8ss+k, hh)][j = lane&31], k = 0..7 -- one wave store instruction writes 1 KB contiguously.  The dQ kernel
+    // (dq_lite) and the dE kernel read these tiles instead of recomputing S / P / dP.
+    char* ds_col = nullptr;                               // wave-uniform: tile (b,h, I = 0, J = j0/32)
+    if (EXPORT_DS) {
+        const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
+        ds_col = (char*)(dst + (((size_t)b * heads + hd) * ntri + (size_t)(j0 >> 5)) * 1024) + lane16;
+    }
+    auto ds_tile = [&](int t) -> char* {                  // query tile I = J0/32 + t
+        if (!EXPORT_DS) return nullptr;
+        const size_t I = (size_t)(J0 >> 5) + t;
+#ifdef MGX_DKV_SMALLSTORE
+        return ds_col - (size_t)(j0 >> 5) * 2048 + (I & 1) * 2048;      // timing experiment: every tile of a (b,h) lands on the same 4 KB
+#endif
+        return ds_col + (I * (I + 1) / 2) * 2048;
+    };
 
     // ---- one query tile.  cur = t & 1 (LDS buffers), PAR = E slot of the hi chunk; MASKED: diagonal / padded-key masks ----
-    auto tile = [&](int dq, int cur, auto par_tag, auto masked_tag) {
+    auto tile = [&](int dq, int cur, auto par_tag, auto masked_tag, char* dsp) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool MASKED = decltype(masked_tag)::value;
         const char* qr = smem + OFF_QR + cur * TILE_BYTES;
@@ -586,6 +773,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         }
         const char* ot = smem + OFF_OT + cur * TILE_BYTES;
         const char* qt = smem + OFF_QT + cur * TILE_BYTES;
+        u32x4 dfx[2];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const bf16x8 pf = acc_to_frag(c, ss);
@@ -594,7 +782,19 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             dv1 = mfma(frag_T(ot, lane, ss, 1), pf, dv1);
             dk0 = mfma(frag_T(qt, lane, ss, 0), df, dk0);
             dk1 = mfma(frag_T(qt, lane, ss, 1), df, dk1);
+            dfx[ss] = __builtin_bit_cast(u32x4, df);
         }
+#ifndef MGX_DKV_NOSTORE
+        if (EXPORT_DS) {
+#ifdef MGX_DKV_PLAINSTORE
+            *(u32x4*)dsp = dfx[0];
+            *(u32x4*)(dsp + 1024) = dfx[1];
+#else
+            __builtin_nontemporal_store(dfx[0], (u32x4*)dsp);
+            __builtin_nontemporal_store(dfx[1], (u32x4*)(dsp + 1024));
+#endif
+        }
+#endif
     };
     // prefetch of the next query tile (registers) and its publication into the other LDS buffers
     u32x4 qreg, oreg;
@@ -621,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         prefetch(t);
         const int dq = t - wk;
         if (dq >= 0) {
-            tile(dq, t & 1, std::integral_constant<int, 0>{}, std::true_type{});
+            tile(dq, t & 1, std::integral_constant<int, 0>{}, std::true_type{}, ds_tile(t));
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { const bf16x8 x = e[0][ks]; e[0][ks] = e[1][ks]; e[1][ks] = x; }
         }
@@ -635,11 +835,11 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     //      that the LDS buffer and the E slot of each step are compile-time constants -----------------------------------------
     for (; t + 1 < nT; t += 2) {
         prefetch(t);
-        tile(t - wk, 0, std::integral_constant<int, 0>{}, std::false_type{});
+        tile(t - wk, 0, std::integral_constant<int, 0>{}, std::false_type{}, ds_tile(t));
         publish(1);
         __syncthreads();
         prefetch(t + 1);
-        tile(t + 1 - wk, 1, std::integral_constant<int, 1>{}, std::false_type{});
+        tile(t + 1 - wk, 1, std::integral_constant<int, 1>{}, std::false_type{}, ds_tile(t + 1));
         publish(0);
         __syncthreads();
     }
@@ -992,6 +1192,157 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
     }
 }
 
+// ================================================================================================
+// K3t: dE from the dS tiles the dK/dV kernel stored (by query tile x key tile, NOT yet un-skewed):
+//     dEr[delta][c] = 1/8 sum_{b,h} sum_{i >= delta} dS[b,h][i][i-delta] q[b,i,h,c]
+// Same sweep as K3s (workgroup = 128 distances [32 c0, +128) x 64 columns, a fixed number of 64-row steps of the flattened
+// (b, h, i-block) sweep, fp32 atomics at the end); the skew happens while a step's tiles are parked in LDS: query tile I
+// needs key tiles J = I - c0 - m, m = 0..4 (distances 32(c0+m) -31..+31), and element (i, j) of tile m goes to row i,
+// column 32(m+1) + i - j of a [64 rows][192 distances] image -- every write lands inside the row (no predication, no
+// wrap), the products read columns 32..159.  5 tiles per query tile for 4 chunks of distances: 1.25 x the bytes of K3s,
+// but no second L x L object and no export from the dQ kernel.
+// ================================================================================================
+namespace k3t {
+constexpr int DT = 128, RS = 64, STEPS = 32;
+constexpr int AROW = 416;                                  // bytes per image row: 192 bf16 + pad (4 consecutive rows -> 4 bank groups)
+constexpr int OFF_A = 0;                                   // [64 i][192 distance columns]
+constexpr int OFF_Q = RS * AROW;                           // q tile [64 i][64 c]: 2 sub-tiles image T
+constexpr int LDS_BYTES = OFF_Q + 2 * TILE_BYTES;          // 34,816 B -> 4 workgroups per CU
+constexpr int SLOTS = 3;                                   // tiles per wave and step: 10 tiles on 4 waves
+}  // namespace k3t
+
+__global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dst, float* __restrict__ dEr /* = dE + (M-L)*64 */,
+    int bgroup, int wg_per_group, int L, int d) {
+    using namespace k3t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int heads = d >> 6, nbh = bgroup * heads;
+    const size_t ld = (size_t)3 * d;
+    int t = 0, first = 0, ns = 0;
+    const int grp = blockIdx.x / wg_per_group;
+    {
+        int rest = blockIdx.x - grp * wg_per_group;
+        const int ntile = (L + DT - 1) / DT;
+        for (t = 0; t < ntile; ++t) {
+            ns = (L - t * DT + RS - 1) / RS;
+            const int nwg = (nbh * ns + STEPS - 1) / STEPS;
+            if (rest < nwg) break;
+            rest -= nwg;
+        }
+        if (t == ntile) return;
+        first = rest * STEPS;
+    }
+    const int total = nbh * ns;
+    const int last = min(total, first + STEPS);
+    const int d0 = t * DT, c0 = d0 >> 5;
+    const int nchunk = L >> 5;
+    const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
+    const int qrow = tid >> 3, qch = tid & 7;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    // slot k of this wave = tile idx = w + 4k of the step: query tile rb = idx / 5 (of 2), key tile offset m = idx % 5
+    int s_rb[SLOTS], s_m[SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) { const int idx = w + 4 * k; s_rb[k] = idx / 5; s_m[k] = idx % 5; }
+    // scatter address of register r (query crow(r,hh), key l31): row crow*AROW, column 32(m+1) + crow - l31
+    const int sc_lane = hh * 4 * (AROW + 2) - 2 * l31;      // + crow(r,0) * (AROW + 2) as the immediate
+    u32x4 areg[SLOTS][2], qreg[2];
+    bool a_ok[SLOTS], q_ok[2];
+    auto load_tiles = [&](int g) {
+        const int bhl = g / ns, i0 = d0 + (g - bhl * ns) * RS;
+        const int bh = grp * nbh + bhl;
+        const int bb = bh / heads, hd = bh - bb * heads;
+        const int I0 = i0 >> 5;
+        const char* tp = (const char*)(dst + (size_t)bh * ntri * 1024) + lane16;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int I = I0 + s_rb[k], J = I - c0 - s_m[k];
+            a_ok[k] = (w + 4 * k < 10) && I < nchunk && J >= 0;
+            const size_t Ic = (size_t)min(I, nchunk - 1), Jc = (size_t)max(J, 0);      // clamped: a valid address either way
+            const char* p = tp + (Ic * (Ic + 1) / 2 + min(Jc, Ic)) * 2048;
+            areg[k][0] = __builtin_nontemporal_load((const u32x4*)p);
+            areg[k][1] = __builtin_nontemporal_load((const u32x4*)(p + 1024));
+        }
+        const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + qch * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = qrow + 32 * i;
+            q_ok[i] = i0 + r < L;
+            qreg[i] = *(const u32x4*)(qp + (size_t)min(r, L - 1 - i0) * ld);
+        }
+    };
+    auto store_tiles = [&]() {
+        const u32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            if (w + 4 * k < 10) {                          // wave-uniform
+                char* base = smem + OFF_A + s_rb[k] * 32 * AROW + 64 * (s_m[k] + 1) + sc_lane;
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const u32x4 v = a_ok[k] ? areg[k][ss] : zero;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r0 = 8 * ss + 2 * j;
+                        *(uint16_t*)(base + crow(r0, 0) * (AROW + 2)) = (uint16_t)v[j];
+                        *(uint16_t*)(base + crow(r0 + 1, 0) * (AROW + 2)) = (uint16_t)(v[j] >> 16);
+                    }
+                }
+            }
+        }
+        char* qt = smem + OFF_Q;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = qrow + 32 * i;
+            *(u32x4*)(qt + (r >> 5) * TILE_BYTES + imgT_off(r & 31, qch)) = q_ok[i] ? qreg[i] : zero;
+        }
+    };
+    f32x16 de0 = zero16(), de1 = zero16();
+    // A fragment: A[m = distance 32w + (lane&31)][k = i = 16ks + 8hh + j] from the [i][distance] image (transposing reads)
+    const int fa_i = lane & 15, fa_g = lane >> 4;
+    const int fa_off = (fa_i >> 2) * AROW + (32 + 32 * w) * 2 + (2 * (fa_g & 1) + ((fa_i & 3) >> 1)) * 16 + 8 * (fa_i & 1) + 8 * hh * AROW;
+    auto multiply = [&]() {
+        const char* at = smem + OFF_A + fa_off;
+        const char* qt = smem + OFF_Q;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af;
+#pragma unroll
+            for (int jq = 0; jq < 2; ++jq) {
+                const bf16x4 tq = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(at + (16 * ks + 4 * jq) * AROW));
+                af[4 * jq + 0] = tq[0]; af[4 * jq + 1] = tq[1]; af[4 * jq + 2] = tq[2]; af[4 * jq + 3] = tq[3];
+            }
+            const char* qs = qt + (ks >> 1) * TILE_BYTES;
+            de0 = mfma(af, frag_Tn(qs, lane, ks & 1, 0), de0);
+            de1 = mfma(af, frag_Tn(qs, lane, ks & 1, 1), de1);
+        }
+    };
+    if (first < last) {
+        load_tiles(first);
+        store_tiles();
+    }
+    __syncthreads();
+    for (int g = first; g + 1 < last; ++g) {
+        load_tiles(g + 1);
+        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the products
+        multiply();
+        __syncthreads();                                // every wave has read the image
+        store_tiles();
+        __syncthreads();
+    }
+    if (first < last) multiply();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int dl = d0 + 32 * w + crow(r, hh);
+        if (dl < L) {
+            float* row = dEr + (size_t)(L - 1 - dl) * 64;
+            atomicAdd(row + l31, 0.125f * de0[r]);
+            atomicAdd(row + 32 + l31, 0.125f * de1[r]);
+        }
+    }
+}
+
 // batch rows per grid group: the largest divisor of B whose q/k/v/dO/ctx bytes stay near 100 MB (rel_attn_fwd.hip)
 static int bwd_batch_group(int B, int L, int d) {
     const double per_row = (double)L * d * 2 * 5;
@@ -1004,11 +1355,16 @@ static size_t ws_delta_bytes(int B, int L, int d) { return (((size_t)B * (d / 64
 
 static size_t ws_ert_bytes(int L) { return 2 * er_frag_bytes(L); }   // EfA | EfT
 
+static size_t ws_ds_bytes(int B, int L, int d) {
+    const size_t nchunk = (size_t)L / 32;
+    return (size_t)B * (d / 64) * (nchunk * (nchunk + 1) / 2) * 2048;
+}
+
 extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
     if (B <= 0 || L <= 0 || d <= 0) return 0;
     // delta f32 [B,h,L] | fragment-ordered Er (EfA, EfT) | causal half of dS by (query, distance) bf16 [B,h,L,L]
-    const size_t nchunk = (size_t)L / 32;
-    return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * (nchunk * (nchunk + 1) / 2) * 2048;
+    // | the same causal half once more: dS by (query tile, key tile), left by the dK/dV kernel for the dQ kernel
+    return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + 2 * ws_ds_bytes(B, L, d);
 }
 
 // parts: 1 pre-pass (delta, E transpose) | 2 dQ (also leaves dS for 8) | 4 dK/dV | 8 dE streamed from the dS the dQ
@@ -1028,9 +1384,13 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_lite_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1l::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_lite_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1l::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3s::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_de_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3t::LDS_BYTES);
         return true;
     }();
     (void)attr_once;
@@ -1041,9 +1401,14 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     u32x4* EfA = (u32x4*)((char*)workspace + ws_delta_bytes(B, L, d));
     u32x4* EfT = (u32x4*)((char*)EfA + er_frag_bytes(L));
     uint16_t* dsrel = (uint16_t*)((char*)EfA + ws_ert_bytes(L));
+    uint16_t* dst = (uint16_t*)((char*)dsrel + ws_ds_bytes(B, L, d));
     // delta = rowsum(dO o O): when the dQ kernel runs in this call it computes and publishes delta itself (its waves own
     // the rows); the stand-alone kernel is only needed when dK/dV or the recompute dE kernel run without it
-    const bool dq_makes_delta = (parts & 1) && (parts & 2);
+    // dQ and dK/dV both wanted: the dK/dV kernel runs FIRST and stores its dS tiles, the dQ kernel (dq_lite) reads them
+    // instead of recomputing S / Q.Er^T / P / dP (MGX_ATTN_BWD_PIPE=0: the two independent recompute kernels, for A/B runs)
+    const int pipe_env = env_digit("MGX_ATTN_BWD_PIPE", 1);
+    const bool pipe = (parts & 2) && (parts & 4) && ((parts & 8) || !(parts & 16)) && pipe_env != 0;
+    const bool dq_makes_delta = (parts & 1) && (parts & 2) && !pipe;
     if (parts & 1) {
         if (!dq_makes_delta) {
             const long total = (long)B * L * heads * 8;
@@ -1058,7 +1423,13 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     // MGX_ATTN_DQ64=1 and L % 256 == 0: the software-pipelined dQ kernel with 64 query rows per wave (rel_attn_bwd2.hip), in
     // the configuration the training step uses (dS export + own delta).  Opt-in: 0.72 ms against 0.60 ms for the kernel below
     // at cfg2 (profiles/README.md, round 3).
-    if ((parts & 2) && L % 256 == 0 && export_ds && dq_makes_delta && env_is_one("MGX_ATTN_DQ64")) {
+    if (pipe) {
+        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
+        if (pipe_env == 2)      // dQ also exports dS by (query, distance) for the K3s dE kernel (A/B against K3t)
+            hipLaunchKernelGGL(rel_attn_dq_lite_kernel<true>, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, dsrel, L, d, bg);
+        else
+            hipLaunchKernelGGL(rel_attn_dq_lite_kernel<false>, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, dsrel, L, d, bg);
+    } else if ((parts & 2) && L % 256 == 0 && export_ds && dq_makes_delta && env_is_one("MGX_ATTN_DQ64")) {
         if (int rc = dq64_launch(qkv, EfA, EfT, padbits, dctx, lse, delta, dqkv, dsrel, ctx, B, L, d, stream)) return rc;
     } else if (parts & 2) {
 #define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, \
@@ -1067,8 +1438,16 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
         else           { if (dq_makes_delta) MGX_DQ_LAUNCH(false, true); else MGX_DQ_LAUNCH(false, false); }
 #undef MGX_DQ_LAUNCH
     }
-    if (parts & 4) hipLaunchKernelGGL(rel_attn_dkv_kernel, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, L, d, bg);
-    if (parts & 8) {
+    if ((parts & 4) && !pipe)
+        hipLaunchKernelGGL(rel_attn_dkv_kernel<false>, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
+    if ((parts & 8) && pipe && pipe_env != 2) {
+        long nwg = 0;                                   // workgroups of ONE batch group
+        for (int t = 0; t < (L + k3t::DT - 1) / k3t::DT; ++t)
+            nwg += ((long)bg * heads * ((L - t * k3t::DT + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
+        MGX_REQUIRE(nwg * (B / bg) < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
+        hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)(nwg * (B / bg))), dim3(256), k3t::LDS_BYTES, s, qkv, dst,
+                           dE + (size_t)(M - L) * 64, bg, (int)nwg, L, d);
+    } else if (parts & 8) {
         long nwg = 0;                                   // workgroups of ONE batch group
         for (int t = 0; t < (L + k3s::DT - 1) / k3s::DT; ++t)
             nwg += ((long)bg * heads * ((L - t * k3s::DT + k3s::RS - 1) / k3s::RS) + k3s::STEPS - 1) / k3s::STEPS;

@@ -113,8 +113,8 @@ def test_cfg2_model_step_is_finite_and_learns():
 
 
 def test_full_size_dE_two_ways_and_grouped_dW():
-    """At the bench's per-GPU shape (B=16 here, L=2048, d=512): the streamed dE (from the dQ kernel's dS tiles) equals the
-    full-recompute dE kernel, and the grouped dW launch equals four separate launches -- independent implementations /
+    """At the bench's per-GPU shape (B=16 here, L=2048, d=512): the streamed dE (from the dS tiles the dK/dV kernel stores) equals
+    the full-recompute dE kernel, dQ from those tiles equals the recompute dQ kernel to bf16 rounding, and the grouped dW launch equals four separate launches -- independent implementations /
     schedules of the same sums, agreeing to fp32 accumulation order."""
     from musicgeneration_amd import ops
     dev = torch.device("cuda")
@@ -125,12 +125,16 @@ def test_full_size_dE_two_ways_and_grouped_dW():
     dctx = torch.randn(B, L, d, generator=g).to(torch.bfloat16).to(dev)
     ctx, lse = ops.rel_attn_fwd(qkv, E, None)
     dE1, dE2 = torch.zeros(L, 64, device=dev), torch.zeros(L, 64, device=dev)
-    dq1 = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE1)                     # pre + dQ + dK/dV + streamed dE
-    dq2 = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE2, parts=1 | 2 | 4 | 16)   # recompute dE, dQ without export
+    dq1 = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE1)                     # pre + dK/dV (stores dS) + dQ and dE from the tiles
+    dq2 = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE2, parts=1 | 2 | 4 | 16)   # dQ and dE by recomputation
     torch.cuda.synchronize()
     assert torch.isfinite(dE1).all() and dE1.abs().max() > 0
     assert _rel(dE1, dE2) < 2e-5
-    assert torch.equal(dq1, dq2)                                                    # the export does not perturb dQ/dK/dV
+    # the same dK/dV kernel, but delta = rowsum(dO o O) comes from the pre-pass kernel in one call and from the recompute dQ
+    # kernel in the other (different fp32 summation order): equal to a few bf16 roundings of the outputs
+    assert _rel(dq1[..., d:].float(), dq2[..., d:].float()) < 1e-3
+    # two derivations of dS (the dK/dV kernel's and the recompute dQ kernel's own): equal up to the bf16 rounding of dS
+    assert _rel(dq1[..., :d].float(), dq2[..., :d].float()) < 4e-3
     M = B * L
     shapes = [(3 * d, d), (d, d), (d // 2, d), (d, d // 2)]
     probs, sep = [], []

@@ -7,7 +7,7 @@ from musicgeneration_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=8); ap.add_argument("--L", type=int, default=2048)
 ap.add_argument("--d", type=int, default=512); ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--parts", type=int, default=63, help="bit0 fwd, bit1 delta, bit2 dq, bit3 dkv, bit4 de (streamed), bit5 de (recompute)")
+ap.add_argument("--parts", type=int, default=63, help="bit0 fwd, bit1 delta, bit2 dq, bit3 dkv, bit4 de (streamed), bit5 de (recompute), bit6 whole backward (both pipelines)")
 ap.add_argument("--rounds", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -53,3 +53,8 @@ if a.parts & 8:
         timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
 if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de")
 if a.parts & 32: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 16, dqkv, ws), 6, "de_rec")
+if a.parts & 64:
+    for _ in range(a.rounds):
+        # the whole backward as the training step calls it (parts 15): two recompute kernels vs dK/dV-first pipeline
+        for mode, name in (("0", "bwd_rec"), ("1", "bwd_pipe"), ("2", "bwd_p_nx")):
+            timed(with_env("MGX_ATTN_BWD_PIPE", mode, lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, ws)), 12, name)
