@@ -1195,23 +1195,24 @@ __global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
 // ================================================================================================
 // K3t: dE from the dS tiles the dK/dV kernel stored (by query tile x key tile, NOT yet un-skewed):
 //     dEr[delta][c] = 1/8 sum_{b,h} sum_{i >= delta} dS[b,h][i][i-delta] q[b,i,h,c]
-// Same sweep as K3s (workgroup = 128 distances [32 c0, +128) x 64 columns, a fixed number of 64-row steps of the flattened
-// (b, h, i-block) sweep, fp32 atomics at the end); the skew happens while a step's tiles are parked in LDS: query tile I
-// needs key tiles J = I - c0 - m, m = 0..4 (distances 32(c0+m) -31..+31), and element (i, j) of tile m goes to row i,
-// column 32(m+1) + i - j of a [64 rows][192 distances] image -- every write lands inside the row (no predication, no
-// wrap), the products read columns 32..159.  5 tiles per query tile for 4 chunks of distances: 1.25 x the bytes of K3s,
-// but no second L x L object and no export from the dQ kernel.
+// A workgroup owns four tile DIAGONALS I - J = c0 + m, m = 0..3, for a fixed number of 64-row steps of the flattened
+// (b, h, i-block) sweep, so every stored tile is read exactly once by this kernel.  Tile m holds the distances
+// 32(c0+m) - 31 .. + 31: the four diagonals touch FIVE chunks of 32 distances, c0-1 .. c0+3 (the first and the last only
+// through one triangle of their tiles; the neighbouring workgroups add the other triangles -- dE is summed with atomics
+// anyway).  The skew happens while a step's tiles are parked in LDS: element (i, j) of tile m goes to row i, column
+// 32(m+1) + i - j of a [64 rows][160 distances] image -- every write lands inside the row (no predication, no wrap);
+// positions no tile writes are zeroed once and stay zero.  Wave w (of 5) multiplies columns 32w .. 32w+31 = chunk c0-1+w.
 // ================================================================================================
 namespace k3t {
-constexpr int DT = 128, RS = 64, STEPS = 32;
-constexpr int AROW = 416;                                  // bytes per image row: 192 bf16 + pad (4 consecutive rows -> 4 bank groups)
-constexpr int OFF_A = 0;                                   // [64 i][192 distance columns]
+constexpr int DIAGS = 4, RS = 64, STEPS = 32, NW = 5;
+constexpr int AROW = 352;                                  // bytes per image row: 160 bf16 + pad (4 consecutive rows -> 4 bank groups)
+constexpr int OFF_A = 0;                                   // [64 i][160 distance columns]
 constexpr int OFF_Q = RS * AROW;                           // q tile [64 i][64 c]: 2 sub-tiles image T
-constexpr int LDS_BYTES = OFF_Q + 2 * TILE_BYTES;          // 34,816 B -> 4 workgroups per CU
-constexpr int SLOTS = 3;                                   // tiles per wave and step: 10 tiles on 4 waves
+constexpr int LDS_BYTES = OFF_Q + 2 * TILE_BYTES;          // 30,720 B
+constexpr int SLOTS = 2;                                   // tiles per wave and step: 8 tiles on waves 0..3
 }  // namespace k3t
 
-__global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
+__global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dst, float* __restrict__ dEr /* = dE + (M-L)*64 */,
     int bgroup, int wg_per_group, int L, int d) {
     using namespace k3t;
@@ -1221,13 +1222,16 @@ __global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
     const int l31 = lane & 31, hh = lane >> 5;
     const int heads = d >> 6, nbh = bgroup * heads;
     const size_t ld = (size_t)3 * d;
+    const int nchunk = L >> 5;
+    // workgroup -> (batch group, diagonal group t, slice of its flattened (bh, row-block) sweep); inside a batch group the
+    // diagonal groups are laid out longest sweep first
     int t = 0, first = 0, ns = 0;
     const int grp = blockIdx.x / wg_per_group;
     {
         int rest = blockIdx.x - grp * wg_per_group;
-        const int ntile = (L + DT - 1) / DT;
+        const int ntile = (nchunk + DIAGS - 1) / DIAGS;
         for (t = 0; t < ntile; ++t) {
-            ns = (L - t * DT + RS - 1) / RS;
+            ns = (L - t * DIAGS * 32 + RS - 1) / RS;       // row blocks i0 = 32 c0, +64, ... < L (query tiles I >= c0)
             const int nwg = (nbh * ns + STEPS - 1) / STEPS;
             if (rest < nwg) break;
             rest -= nwg;
@@ -1237,15 +1241,12 @@ __global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
     }
     const int total = nbh * ns;
     const int last = min(total, first + STEPS);
-    const int d0 = t * DT, c0 = d0 >> 5;
-    const int nchunk = L >> 5;
+    const int c0 = t * DIAGS, d0 = c0 * 32;
     const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
-    const int qrow = tid >> 3, qch = tid & 7;
+    const int qrow = tid >> 3, qch = tid & 7;              // threads 0..255 stage q
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    // slot k of this wave = tile idx = w + 4k of the step: query tile rb = idx / 5 (of 2), key tile offset m = idx % 5
-    int s_rb[SLOTS], s_m[SLOTS];
-#pragma unroll
-    for (int k = 0; k < SLOTS; ++k) { const int idx = w + 4 * k; s_rb[k] = idx / 5; s_m[k] = idx % 5; }
+    // slot k of wave w < 4 = tile idx = w + 4k of the step: query tile rb = idx / 4 (of 2), diagonal m = idx % 4 = w
+    const int wm = w & 3;
     // scatter address of register r (query crow(r,hh), key l31): row crow*AROW, column 32(m+1) + crow - l31
     const int sc_lane = hh * 4 * (AROW + 2) - 2 * l31;      // + crow(r,0) * (AROW + 2) as the immediate
     u32x4 areg[SLOTS][2], qreg[2];
@@ -1257,28 +1258,28 @@ __global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
         const int I0 = i0 >> 5;
         const char* tp = (const char*)(dst + (size_t)bh * ntri * 1024) + lane16;
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            const int I = I0 + s_rb[k], J = I - c0 - s_m[k];
-            a_ok[k] = (w + 4 * k < 10) && I < nchunk && J >= 0;
+        for (int k = 0; k < SLOTS; ++k) {                  // slot k = query tile I0 + k; wave 4 loads (clamped) data it never uses
+            const int I = I0 + k, J = I - c0 - wm;
+            a_ok[k] = I < nchunk && J >= 0;
             const size_t Ic = (size_t)min(I, nchunk - 1), Jc = (size_t)max(J, 0);      // clamped: a valid address either way
             const char* p = tp + (Ic * (Ic + 1) / 2 + min(Jc, Ic)) * 2048;
             areg[k][0] = __builtin_nontemporal_load((const u32x4*)p);
             areg[k][1] = __builtin_nontemporal_load((const u32x4*)(p + 1024));
         }
-        const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + qch * 8;
+        const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + (qch & 7) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = qrow + 32 * i;
+            const int r = (qrow & 31) + 32 * i;
             q_ok[i] = i0 + r < L;
             qreg[i] = *(const u32x4*)(qp + (size_t)min(r, L - 1 - i0) * ld);
         }
     };
     auto store_tiles = [&]() {
         const u32x4 zero = {0, 0, 0, 0};
+        if (w < 4) {                                       // wave-uniform
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            if (w + 4 * k < 10) {                          // wave-uniform
-                char* base = smem + OFF_A + s_rb[k] * 32 * AROW + 64 * (s_m[k] + 1) + sc_lane;
+            for (int k = 0; k < SLOTS; ++k) {
+                char* base = smem + OFF_A + k * 32 * AROW + 64 * (wm + 1) + sc_lane;
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {
                     const u32x4 v = a_ok[k] ? areg[k][ss] : zero;
@@ -1290,18 +1291,18 @@ __global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
                     }
                 }
             }
-        }
-        char* qt = smem + OFF_Q;
+            char* qt = smem + OFF_Q;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = qrow + 32 * i;
-            *(u32x4*)(qt + (r >> 5) * TILE_BYTES + imgT_off(r & 31, qch)) = q_ok[i] ? qreg[i] : zero;
+            for (int i = 0; i < 2; ++i) {
+                const int r = qrow + 32 * i;
+                *(u32x4*)(qt + (r >> 5) * TILE_BYTES + imgT_off(r & 31, qch)) = q_ok[i] ? qreg[i] : zero;
+            }
         }
     };
     f32x16 de0 = zero16(), de1 = zero16();
-    // A fragment: A[m = distance 32w + (lane&31)][k = i = 16ks + 8hh + j] from the [i][distance] image (transposing reads)
+    // A fragment: A[m = distance column 32w + (lane&31)][k = i = 16ks + 8hh + j] from the [i][distance] image (transposing reads)
     const int fa_i = lane & 15, fa_g = lane >> 4;
-    const int fa_off = (fa_i >> 2) * AROW + (32 + 32 * w) * 2 + (2 * (fa_g & 1) + ((fa_i & 3) >> 1)) * 16 + 8 * (fa_i & 1) + 8 * hh * AROW;
+    const int fa_off = (fa_i >> 2) * AROW + (32 * w) * 2 + (2 * (fa_g & 1) + ((fa_i & 3) >> 1)) * 16 + 8 * (fa_i & 1) + 8 * hh * AROW;
     auto multiply = [&]() {
         const char* at = smem + OFF_A + fa_off;
         const char* qt = smem + OFF_Q;
@@ -1318,6 +1319,9 @@ __global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
             de1 = mfma(af, frag_Tn(qs, lane, ks & 1, 1), de1);
         }
     };
+    // image positions that no tile writes (the triangles that belong to the neighbouring diagonal groups) must read as zero
+    for (int o = tid * 16; o < RS * AROW; o += NW * 64 * 16) *(u32x4*)(smem + OFF_A + o) = u32x4{0, 0, 0, 0};
+    __syncthreads();
     if (first < last) {
         load_tiles(first);
         store_tiles();
@@ -1332,10 +1336,11 @@ __global__ __launch_bounds__(256, 4) void rel_attn_de_tiles_kernel(
         __syncthreads();
     }
     if (first < last) multiply();
+    // flush: rows = distances 32(c0-1+w) + crow(r,hh), columns on lanes; q was not pre-scaled -> 1/8 here
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int dl = d0 + 32 * w + crow(r, hh);
-        if (dl < L) {
+        const int dl = d0 - 32 + 32 * w + crow(r, hh);
+        if (dl >= 0 && dl < L) {
             float* row = dEr + (size_t)(L - 1 - dl) * 64;
             atomicAdd(row + l31, 0.125f * de0[r]);
             atomicAdd(row + 32 + l31, 0.125f * de1[r]);
@@ -1442,10 +1447,10 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
         hipLaunchKernelGGL(rel_attn_dkv_kernel<false>, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
     if ((parts & 8) && pipe && pipe_env != 2) {
         long nwg = 0;                                   // workgroups of ONE batch group
-        for (int t = 0; t < (L + k3t::DT - 1) / k3t::DT; ++t)
-            nwg += ((long)bg * heads * ((L - t * k3t::DT + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
+        for (int t = 0; t < (L / 32 + k3t::DIAGS - 1) / k3t::DIAGS; ++t)
+            nwg += ((long)bg * heads * ((L - t * k3t::DIAGS * 32 + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
         MGX_REQUIRE(nwg * (B / bg) < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
-        hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)(nwg * (B / bg))), dim3(256), k3t::LDS_BYTES, s, qkv, dst,
+        hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)(nwg * (B / bg))), dim3(64 * k3t::NW), k3t::LDS_BYTES, s, qkv, dst,
                            dE + (size_t)(M - L) * 64, bg, (int)nwg, L, d);
     } else if (parts & 8) {
         long nwg = 0;                                   // workgroups of ONE batch group
