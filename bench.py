@@ -93,9 +93,9 @@ def time_kernels(B, L, d, M, reps=10):
     # launches of the same MFMA-dense kernel (the chip then holds a lower clock than inside the training step and the
     # per-kernel times read 15-30 % long against the rocprofv3 trace of the step).
     calls = [("rel_attn_fwd_kernel", lambda: ops.rel_attn_fwd(qkv, E, None))]
-    # parts bits of mgx_rel_attn_bwd_parts; the dE kernel streams the dS tiles the dQ kernel left in `ws`
-    # (the dQ entry is timed as the real call runs it: with the E re-layout pre-pass and computing delta itself)
-    for name, bit in (("rel_attn_dq_kernel", 1 | 2), ("rel_attn_dkv_kernel", 4), ("rel_attn_de_stream_kernel", 8)):
+    # parts bits of mgx_rel_attn_bwd_parts; the dQ and dE kernels read the dS tiles the dK/dV kernel left in `ws`
+    # (the dK/dV entry is timed as the real call runs it: with the delta / E re-layout pre-pass, ~30 us)
+    for name, bit in (("rel_attn_dkv_kernel", 1 | 4), ("rel_attn_dq_lite_kernel", 2), ("rel_attn_de_tiles_kernel", 8)):
         calls.append((name, lambda bit=bit: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, bit, dqkv, ws)))
     for _, fn in calls:
         fn()
@@ -241,9 +241,9 @@ def pmc_traffic(kernel, B, L, d):
     ds_half = B * heads * (L // 32) * (L // 32 + 1) // 2 * 2048          # causal half of dS, bf16 32x32 tiles
     io = B * L * d * 2                                                   # one bf16 [B,L,d] tensor
     algo = {"rel_attn_fwd_kernel": 4 * io,                               # q,k,v in, ctx out
-            "rel_attn_dq_kernel": 6 * io + ds_half,                      # q,k,v,dO,O in, dq out + the dS export (by design)
-            "rel_attn_dkv_kernel": 6 * io,                               # q,k,v,dO in, dk,dv out
-            "rel_attn_de_stream_kernel": io + ds_half}[kernel]           # q in, dS in
+            "rel_attn_dkv_kernel": 6 * io + ds_half,                     # q,k,v,dO in, dk,dv out + the dS tiles (by design)
+            "rel_attn_dq_lite_kernel": 2 * io + ds_half,                 # k in, dq out, dS in
+            "rel_attn_de_tiles_kernel": io + ds_half}[kernel]            # q in, dS in
     tr = sum(k[n]["hbm_bytes_per_launch"] for n in match)
     return {"traffic": tr, "traffic_unit": f"bytes/launch (PMC, {os.path.basename(path)})",
             "algorithmic_bytes_per_launch": algo}
@@ -414,32 +414,35 @@ def main():
     if rank == 0 and not args.no_kernel_timing:
         kt = time_kernels(B, L, d, L)
         # credited (algorithmic) and executed product-units per kernel; 1 unit = B*L^2*d FLOPs
-        credited = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 2.5, "rel_attn_dkv_kernel": 2.5,
-                    "rel_attn_de_stream_kernel": 1.0}
-        executed = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dq_kernel": 5.0, "rel_attn_dkv_kernel": 6.0,
-                    "rel_attn_de_stream_kernel": 1.0}
+        # backward: dP, dV, dK (the dK/dV kernel, which also forms the dS everybody else reads), dq = dS K + dS_rel Er (dq_lite),
+        # dE (de_tiles) = 6 credited; executed adds the recomputed S and two Q.Er^T chunks in the dK/dV kernel and the fifth
+        # (half-empty) chunk product of de_tiles
+        credited = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dkv_kernel": 3.0, "rel_attn_dq_lite_kernel": 2.0,
+                    "rel_attn_de_tiles_kernel": 1.0}
+        executed = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dkv_kernel": 6.0, "rel_attn_dq_lite_kernel": 2.0,
+                    "rel_attn_de_tiles_kernel": 1.25}
         per_kernel = {k: {"ms": kt[k], "credited_tflops": attn_flops_per_launch(B, L, d, credited[k]) / (kt[k] * 1e-3) / 1e12,
                           "executed_tflops": attn_flops_per_launch(B, L, d, executed[k]) / (kt[k] * 1e-3) / 1e12}
                       for k in credited}
         # roofline: the single dominant KERNEL of the step by time (6 launches per step each).  Credited units are the
         # algorithmic share of the products it computes (no credit for recomputing S/P/dP or for the second Q.Er^T
         # chunk); executed units count every MFMA product it runs.  The op it belongs to (ONE C-ABI call,
-        # mgx_rel_attn_bwd = E re-layout + dQ + dK/dV + dE kernels, 6 credited units) is reported beside it.
-        kernel_symbol = {"rel_attn_fwd_kernel": "rel_attn_fwd_kernel<false>", "rel_attn_dq_kernel": "rel_attn_dq_kernel<true, true>",
-                         "rel_attn_dkv_kernel": "rel_attn_dkv_kernel", "rel_attn_de_stream_kernel": "rel_attn_de_stream_kernel"}
+        # mgx_rel_attn_bwd = pre-pass + dK/dV + dQ + dE kernels, 6 credited units) is reported beside it.
+        kernel_symbol = {"rel_attn_fwd_kernel": "rel_attn_fwd_kernel<false>", "rel_attn_dkv_kernel": "rel_attn_dkv_kernel<true>",
+                         "rel_attn_dq_lite_kernel": "rel_attn_dq_lite_kernel", "rel_attn_de_tiles_kernel": "rel_attn_de_tiles_kernel"}
         dom_k = max(kt, key=lambda k: kt[k])
         dom_ms = kt[dom_k]
         ach = attn_flops_per_launch(B, L, d, credited[dom_k]) / (dom_ms * 1e-3) / 1e12
         exe = attn_flops_per_launch(B, L, d, executed[dom_k]) / (dom_ms * 1e-3) / 1e12
-        bwd_ms = kt["rel_attn_dq_kernel"] + kt["rel_attn_dkv_kernel"] + kt["rel_attn_de_stream_kernel"]
+        bwd_ms = kt["rel_attn_dkv_kernel"] + kt["rel_attn_dq_lite_kernel"] + kt["rel_attn_de_tiles_kernel"]
         out["roofline"] = {"bound": "mfma", "kernel": kernel_symbol[dom_k], "achieved": ach, "peak": PEAK_BF16_TFLOPS,
                            "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
                            "launch_ms": dom_ms, "credited_units": credited[dom_k], "executed_units": executed[dom_k],
                            "unit_flops": attn_flops_per_launch(B, L, d, 1.0),
                            "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, credited[dom_k]),
                            "executed_tflops": exe, "executed_frac": exe / PEAK_BF16_TFLOPS,
-                           "op": {"name": "mgx_rel_attn_bwd (E re-layout + dq + dkv + de kernels)", "launch_ms": bwd_ms,
-                                  "credited_units": 6.0, "executed_units": 12.0,
+                           "op": {"name": "mgx_rel_attn_bwd (pre-pass + dkv + dq_lite + de_tiles kernels)", "launch_ms": bwd_ms,
+                                  "credited_units": 6.0, "executed_units": 9.25,
                                   "achieved": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12,
                                   "frac": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}}
         out["roofline"].update(pmc_traffic(dom_k, B, L, d))

@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad) */
-#define MGX_ABI_VERSION 12
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation */
+#define MGX_ABI_VERSION 13
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -79,18 +79,22 @@ int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t*
 /* backward of the above (autograd of layers.py:86-106).  dctx bf16 [B,L,d] -> dqkv bf16 [B,L,3d];
  * dE f32 [M,64] is ACCUMULATED into (caller zeroes it once per optimiser step).
  * workspace: caller-provided scratch, 256-byte aligned, >= mgx_rel_attn_bwd_workspace(B,L,d) bytes
- * (rowsum(dctx*ctx) [B,h,L] f32, two lane-ordered bf16 copies of E, and the causal half of dS by (query, relative
- * distance) in 32x32 bf16 tiles that the dQ kernel leaves for the dE kernel -- B*h*(L/32)(L/32+1)/2 * 2 KB,
+ * (rowsum(dctx*ctx) [B,h,L] f32, two lane-ordered bf16 copies of E, and the causal half of dS by (query tile, key tile)
+ * in 32x32 bf16 tiles that the dK/dV kernel leaves for the dQ and dE kernels -- B*h*(L/32)(L/32+1)/2 * 2 KB,
  * 0.55 GB at cfg2/B=16). */
 size_t mgx_rel_attn_bwd_workspace(int B, int L, int d);
 int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                      const uint16_t* ctx, const uint16_t* dctx, const float* lse,
                      uint16_t* dqkv, float* dE, void* workspace, size_t ws_bytes,
                      int B, int L, int d, int M, void* stream);
-/* same, running only the selected sub-kernels (bit0 pre-pass: delta + E transpose, bit1 dQ, bit2 dK+dV,
- * bit3 dE streamed from the dS that a bit1 run left in the SAME workspace, bit4 dE by full recomputation:
- * independent of bit1, used as a cross-check); bench.py times each kernel on its own this way.
- * parts == 15 is mgx_rel_attn_bwd.                                                                */
+/* same, running only the selected sub-kernels, in this order inside one call:
+ *   bit0 (1)  pre-pass: delta = rowsum(dctx*ctx), E re-layout
+ *   bit2 (4)  dK + dV; stores every dS tile in the workspace
+ *   bit1 (2)  dQ from the dS tiles a bit2 run (this call or an earlier one) left in the SAME workspace
+ *   bit5 (32) dQ by full recomputation instead (independent of the stored tiles: cross-check; not together with bit1)
+ *   bit3 (8)  dE from the stored dS tiles
+ *   bit4 (16) dE by full recomputation (independent of the stored tiles: cross-check)
+ * bench.py times each kernel on its own this way.  parts == 15 is mgx_rel_attn_bwd.                     */
 int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                            const uint16_t* ctx, const uint16_t* dctx, const float* lse,
                            uint16_t* dqkv, float* dE, void* workspace, size_t ws_bytes,

@@ -7,19 +7,19 @@
 //     dk_j    = sum_i dS[i,j] qs_i                 dv_j = sum_i P[i,j] dO_i
 //     dEr[dl] = sum_{b,h} sum_i dS[i,i-dl] qs_i
 //
-// Every output has a different "owner" axis (query row / key row / relative distance).  Summing a
-// non-owned output across workgroups with float atomics would cost >= 150 MB of atomic traffic per
-// layer at cfg2 (~1.3 TB/s chip-wide => > 100 us, more than the MFMA time), so dQ and dK/dV each get
-// a kernel that keeps its output in registers for the whole sweep and recomputes P (flash style):
-//   K1 dq_kernel   : workgroup = 128 query rows, sweeps key tiles    (20 MFMA / 32x32 tile); it also
-//                    stores every dS tile, already un-skewed to (query, distance), to the workspace
-//   K2 dkv_kernel  : workgroup = 128 keys,       sweeps query tiles  (24 MFMA / tile)
-//   K3s de_stream  : dE as a plain TN product streamed from those dS tiles (HBM-bound, no recompute)
-//   K3 de_kernel   : dE by full recomputation (8 waves = 8 chunks of 32 distances along the diagonal
-//                    band, 24 MFMA / tile) -- kept as an independent cross-check (parts bit 4)
-// The skew / un-skew between (i,j) tiles and (i,delta) chunks is done through per-wave LDS band
-// buffers (see rel_attn_common.hpp); the only L x L object that ever exists is the bf16 dS workspace
-// (causal half, tile-blocked), written once and read once per layer.
+// Every output has a different "owner" axis (query row / key row / relative distance), and summing a non-owned output
+// across workgroups with float atomics would cost several GB of atomic traffic per layer at cfg2.  So ONE kernel
+// recomputes P and dS flash-style -- the dK/dV kernel, whose outputs need both -- and stores every bf16 dS tile (the operand
+// registers of its own dK product) in the workspace; dQ and dE only need dS and are computed from the stored tiles:
+//   K2  dkv_kernel   : workgroup = 128 keys, sweeps query tiles (24 MFMA / 32x32 tile); stores dS by (query tile, key tile)
+//   K1L dq_lite      : workgroup = 128 query rows, sweeps the stored tiles of its rows (8 MFMA / tile, HBM-bound)
+//   K3t de_tiles     : workgroup = 4 tile diagonals, un-skews the stored tiles in LDS (8 MFMA / 64 rows, HBM-bound)
+//   K1  dq_kernel    : dQ by full recomputation (20 MFMA / tile) -- the round-2 kernel, kept as an independent cross-check
+//   K3  de_kernel    : dE by full recomputation (24 MFMA / tile) -- cross-check (parts bit 4)
+// Until round 3 dQ and dK/dV each recomputed P (two kernels x ~0.6 ms per layer at cfg2); reading dS back costs the dQ side
+// 0.26 ms instead (profiles/r03_bwd_pipeline_ab.txt).  The skew between (i,j) tiles and (i,delta) chunks is done through LDS
+// (rel_attn_common.hpp); the only L x L object that ever exists is the bf16 dS workspace (causal half, tile-blocked),
+// written once and read twice per layer.
 #include <type_traits>
 #include "rel_attn_common.hpp"
 
@@ -77,7 +77,8 @@ MGX_DEV bf16x8 frag_Tn(const char* tile, int lane, int ks, int ct) {
 }
 
 // ================================================================================================
-// K1: dQ.  Same sweep as the forward (query-block owner, key tiles 0..diagonal).
+// K1: dQ by recomputation (cross-check of K1L; parts bit 5).  Same sweep as the forward (query-block owner, key tiles
+//   0..diagonal).
 //   orientation: keys on registers, queries on lanes (S^T, P^T, dP^T, dS^T), dqs^T[c][a] accumulators.
 //   E never touches LDS here: the Er row fragments (B operand of Q.Er^T) and the fragments of the
 //   transposed copy ErT[c][delta] (A operand of dqs^T += ErT . dQE^T) are loaded from global/L2.
@@ -94,12 +95,10 @@ constexpr int OFF_FLAG = OFF_PAD + 1024;                   // "this batch row ha
 constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 70,672 B -> 2 workgroups per CU
 }  // namespace k1
 
-template <bool EXPORT_DS, bool OWN_DELTA>
 __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const u32x4* __restrict__ EfT,
     const uint32_t* __restrict__ padbits, const uint16_t* __restrict__ dctx, const float* __restrict__ lse,
-    float* __restrict__ delta, uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel,
-    const uint16_t* __restrict__ ctx, int L, int d, int bgroup) {
+    const float* __restrict__ delta, uint16_t* __restrict__ dqkv, int L, int d, int bgroup) {
     using namespace k1;
     extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band stores XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x, lane = tid & 63;
@@ -184,24 +183,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         }
         const size_t si = ((size_t)b * heads + hd) * L + i0 + a;
         lse2 = lse[si] * LOG2E;
-        if (OWN_DELTA) {
-            // delta_i = sum_c dO[i][c] O[i][c]: this wave owns the row, so it computes the value itself (no pre-pass
-            // kernel) and publishes it for the dK/dV kernel, which runs after this one on the stream
-            const uint16_t* op = ctx + ((size_t)b * L + i0 + a) * d + hd * 64 + hh * 8;
-            float acc_d = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                float o8[8], g8[8];
-                unpack8(*(const u32x4*)(op + ks * 16), o8);
-                unpack8(__builtin_bit_cast(u32x4, dof[ks]), g8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc_d += o8[k] * g8[k];
-            }
-            dlt = acc_d + __shfl_xor(acc_d, 32, 64);
-            if (hh == 0) delta[si] = dlt;
-        } else {
-            dlt = delta[si];
-        }
+        dlt = delta[si];
     }
     __syncthreads();
 
@@ -251,20 +233,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         for (int ks = 0; ks < 4; ++ks) e[ks] = e_frag(q0 - 1, ks);    // new chunk of step 0
     }
     f32x16 dq0 = zero16(), dq1 = zero16();
-    // dS by (query, relative distance) for the dE kernel, tile-blocked and PACKED to the causal half: query block I = i0/32
-    // only has chunks q <= I, so tile (b,h, I, q) is 2 KB at ((bh*T + I(I+1)/2 + q)*1024 elements, T = nchunk(nchunk+1)/2
-    // (half the memory of a full [I][q] grid; the consumer treats q > I as zeros).  Inside a tile the 16-byte unit of
-    // (row a, columns 16ks+8hh..+7) sits at ks*512 + a*16 + hh*8 elements -- each wave store instruction writes 1 KB
-    // contiguously.
-    char* ds_base = nullptr;                             // wave-uniform: tile (b,h, I = q0, chunk 0)
-    const uint32_t ds_voff = (uint32_t)(a * 16 + hh * 8) * 2u;
-    if (EXPORT_DS) {
-        const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
-        ds_base = (char*)(dsrel + (((size_t)b * heads + hd) * ntri + (size_t)q0 * (q0 + 1) / 2) * 1024);
-    }
     const int am = a - 4 * hh;                           // key crow(r,hh) is in the future of query a  <=>  crow(r,0) > am
 
-    // ---- one tile, from S^T (band term already in c) to the exported dS chunk ---------------------------------------
+    // ---- one tile, from S^T (band term already in c) to the dq accumulators ---------------------------------------
     // MASKED: apply the diagonal / key-padding masks (general body only)
     auto tile_tail = [&](f32x16& c, int dq, int p, int cur, uint32_t pw, auto masked_tag, const bf16x8 (&et)[4]) {
         constexpr bool MASKED = decltype(masked_tag)::value;
@@ -321,15 +292,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
             dq1 = mfma(et[2 * ks + 1], gq, dq1);
         }
     };
-    auto export_chunk = [&](int dq, int p) {
-        // completed chunk dq of dS[i][delta] -> workspace.  Last in the step: VMEM operations retire in order, so
-        // the wait for the NEXT step's K/V tiles then only covers stores that have had a whole step to drain.
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            __builtin_nontemporal_store(*(const u32x4*)(dband + a * DB_STRIDE + (p * 32 + 16 * ks + 8 * hh) * 2),
-                                        (u32x4*)(ds_base + (size_t)dq * 2048 + 1024 * ks + ds_voff));   // streamed: keep K/V/E in L2
-    };
-
     // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: branch-free, two steps per trip so that the
     //      LDS buffers and the band parities of a step are compile-time constants (nmain = Q0 is a multiple of 4) -------------
     const int nmain = anypad ? 0 : Q0;                    // Q0 <= ntw - 1: a next tile always exists inside this loop
@@ -356,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
         tile_tail(c, dq, PAR, PAR, 0u, std::false_type{}, et);
         *(u32x4*)(smem + OFF_KR + (PAR ^ 1) * TILE_BYTES + st_offR) = kreg;
         *(u32x4*)(smem + OFF_VR + (PAR ^ 1) * TILE_BYTES + st_offR) = vreg;
-        if (EXPORT_DS) export_chunk(dq, PAR);
         __syncthreads();
     };
     int s = 0;
@@ -394,7 +355,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
             *(u32x4*)(smem + OFF_KR + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
             *(u32x4*)(smem + OFF_VR + (cur ^ 1) * TILE_BYTES + st_offR) = vreg;
         }
-        if (EXPORT_DS && dq >= 0) export_chunk(dq, cur);
         __syncthreads();
     }
     if (wave_on) store_rows_lds(dqkv + ((size_t)b * L + i0) * ld + hd * 64, ld, dq0, dq1, lane, 0.125f, smem + band_base);
@@ -409,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
 //   * dqs^T[c][i] += K^T[c][j] dS^T[j][i]: the tile is parked row-major [j][i] in a wave-private image-T patch and read back
 //     with transposing LDS reads as the B operand (k order kappa, matching frag_T_onR of the K tile);
 //   * the same registers are scattered into the (query, distance & 63) band exactly as K1 does; the completed chunk is the
-//     B operand of dqs^T += ErT . dS_rel^T and (EXPORT_REL) goes to the workspace for the dE kernel.
+//     B operand of dqs^T += ErT . dS_rel^T.
 // ================================================================================================
 namespace k1l {
 constexpr int OFF_KR = 0;                                  // 2 x 4K  K image R (tile t in slot t & 1)
@@ -423,10 +383,9 @@ constexpr int LDS_BYTES = OFF_DBAND + WAVES * 32 * DB_STRIDE;   // 68,608 B -> 2
 constexpr int DEPTH = 4;                                   // dS tiles in flight per wave (2 KB each)
 }  // namespace k1l
 
-template <bool EXPORT_REL>
 __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfT, const uint16_t* __restrict__ dst,
-    uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dsrel, int L, int d, int bgroup) {
+    uint16_t* __restrict__ dqkv, int L, int d, int bgroup) {
     using namespace k1l;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -489,9 +448,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
         dwa1[r] = crow(r, hh) * DB_STRIDE + (((crow(r, hh) - a + 32) & 63) << 1);
     }
     f32x16 dq0 = zero16(), dq1 = zero16();
-    char* rel_base = nullptr;
-    const uint32_t rel_voff = (uint32_t)(a * 16 + hh * 8) * 2u;
-    if (EXPORT_REL) rel_base = (char*)(dsrel + row_tiles * 1024);
 
     // dS^T patch -> B operand (k order kappa): X[16s + 8jq + 4hh + rq][lane&31]
     auto frag_X = [&](int s) {
@@ -503,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
         }
         return out;
     };
-    auto compute = [&](int dq, int p, const char* kt, const char* ec, const u32x4 (&t)[2]) {
+    auto compute = [&](int p, const char* kt, const char* ec, const u32x4 (&t)[2]) {
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             *(u32x2*)(xt + xw0 + 16 * (2 * ss)) = u32x2{t[ss].x, t[ss].y};
@@ -527,8 +483,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
             const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + (p * 32 + 16 * ks + 8 * hh) * 2);
             dq0 = mfma(*(const bf16x8*)(ec + (2 * ks) * 1024 + lane16), gq, dq0);
             dq1 = mfma(*(const bf16x8*)(ec + (2 * ks + 1) * 1024 + lane16), gq, dq1);
-            if (EXPORT_REL)
-                __builtin_nontemporal_store(__builtin_bit_cast(u32x4, gq), (u32x4*)(rel_base + (size_t)dq * 2048 + 1024 * ks + rel_voff));
         }
         wave_lds_fence();                                  // the patch and the band half are rewritten by the next step
     };
@@ -538,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
         const u32x4 t[2] = {dsr[SLOT][0], dsr[SLOT][1]};
         dsr[SLOT][0] = ds_load(s + DEPTH, 0);
         dsr[SLOT][1] = ds_load(s + DEPTH, 1);
-        if (active) compute(q0 - s, PAR, smem + OFF_KR + PAR * TILE_BYTES, smem + OFF_ET + ((s - w) & 7) * 4096, t);
+        if (active) compute(PAR, smem + OFF_KR + PAR * TILE_BYTES, smem + OFF_ET + ((s - w) & 7) * 4096, t);
         // items s+1 (requested two steps ago): the K slot was last read in step s-1, the chunk slot in step s-4
         *(u32x4*)(smem + OFF_KR + (PAR ^ 1) * TILE_BYTES + st_offR) = kq[PAR];
         *(u32x4*)(smem + OFF_ET + ((s + 1) & 7) * 4096 + tid16) = eq[PAR];
@@ -588,7 +542,7 @@ constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 66,064 B -> 2 work
 // the next "lo" chunk), so E needs no LDS here.
 }  // namespace k2
 
-template <bool EXPORT_DS>
+template <bool EXPORT_DS>     // always true (one instantiation): as a plain function hipcc builds a 36 % longer main loop from the same source
 __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -685,22 +639,20 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     for (int r = 0; r < 16; ++r) rd[r] = lds_addr_of(smem) + band_base + crow(r, hh) * 128 + (((crow(r, hh) - bl) & 31) << 2);
     const uint32_t wr0 = lds_addr_of(smem) + band_base + hh * 512 + bl * 4;       // + crow(r,0)*128 as the immediate
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-    // EXPORT_DS: every dS tile goes to the workspace as the operand registers this wave multiplies with q (bf16, the dK
+    // Every dS tile goes to the workspace as the operand registers this wave multiplies with q (bf16, the dK
     // product's own rounding): tile (b,h, I = query tile, J = key tile <= I) is 2 KB at ((bh*T + I(I+1)/2 + J)*1024 elements,
     // T = nchunk(nchunk+1)/2 (causal half); inside a tile unit (ss, lane) = 16 bytes at ss*512 + lane*8 elements holds
     // dS[i = crow(8ss+k, hh)][j = lane&31], k = 0..7 -- one wave store instruction writes 1 KB contiguously.  The dQ kernel
     // (dq_lite) and the dE kernel read these tiles instead of recomputing S / P / dP.
-    char* ds_col = nullptr;                               // wave-uniform: tile (b,h, I = 0, J = j0/32)
+    // (wave-uniform base: tile (b,h, I = 0, J = j0/32); a wave beyond the end of the sequence rewrites the last key block's
+    // tiles with identical data)
+    char* ds_col = nullptr;
     if (EXPORT_DS) {
         const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
         ds_col = (char*)(dst + (((size_t)b * heads + hd) * ntri + (size_t)(j0 >> 5)) * 1024) + lane16;
     }
-    auto ds_tile = [&](int t) -> char* {                  // query tile I = J0/32 + t
-        if (!EXPORT_DS) return nullptr;
+    auto ds_tile = [&](int t) {                           // query tile I = J0/32 + t
         const size_t I = (size_t)(J0 >> 5) + t;
-#ifdef MGX_DKV_SMALLSTORE
-        return ds_col - (size_t)(j0 >> 5) * 2048 + (I & 1) * 2048;      // timing experiment: every tile of a (b,h) lands on the same 4 KB
-#endif
         return ds_col + (I * (I + 1) / 2) * 2048;
     };
 
@@ -784,17 +736,12 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             dk1 = mfma(frag_T(qt, lane, ss, 1), df, dk1);
             dfx[ss] = __builtin_bit_cast(u32x4, df);
         }
-#ifndef MGX_DKV_NOSTORE
+        // streamed (read back from HBM by two later kernels): costs this kernel ~55 us of its 600 at cfg2, 35 of them HBM
+        // write traffic (stores to an L2-resident dummy: 20) -- profiles/README.md round 3
         if (EXPORT_DS) {
-#ifdef MGX_DKV_PLAINSTORE
-            *(u32x4*)dsp = dfx[0];
-            *(u32x4*)(dsp + 1024) = dfx[1];
-#else
             __builtin_nontemporal_store(dfx[0], (u32x4*)dsp);
             __builtin_nontemporal_store(dfx[1], (u32x4*)(dsp + 1024));
-#endif
         }
-#endif
     };
     // prefetch of the next query tile (registers) and its publication into the other LDS buffers
     u32x4 qreg, oreg;
@@ -1044,155 +991,6 @@ __global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
 }
 
 // ================================================================================================
-// K3s: dE from the stored dS.  The dQ kernel leaves dsrel[b,h][i][delta] = dS[i][i-delta] (bf16, the
-// exact operand it multiplied with Er itself), so
-//     dEr[delta][c] = 1/8 sum_{b,h} sum_{i >= delta} dsrel[b,h][i][delta] q[b,i,h,c]
-// is a plain "TN" product streamed from HBM: no recomputation of S / P / dP (the recompute kernel above
-// executes 6 product units for this 1).  Workgroup = 128 distances x 64 columns, a fixed number of
-// 64-row steps of the flattened (b, h, i-block) sweep; partial sums are flushed with fp32 atomics in
-// 128-byte row segments.  HBM-bound: 24 KB per step against 8 MFMAs per wave.
-// ================================================================================================
-namespace k3s {
-constexpr int DT = 128;                                    // distances per workgroup
-constexpr int RS = 64;                                     // query rows per step
-constexpr int STEPS = 32;                                  // steps per workgroup (768 KB streamed, 32 KB flushed)
-constexpr int OFF_A = 0;                                   // 2 x 16K  dS tile [64 i][128 delta]: 4 sub-tiles image T
-constexpr int OFF_Q = 2 * 4 * TILE_BYTES;                  // 2 x 8K   q tile  [64 i][64 c]:      2 sub-tiles image T
-constexpr int LDS_BYTES = OFF_Q + 2 * 2 * TILE_BYTES;      // 49,152 B -> 3 workgroups per CU
-}  // namespace k3s
-
-__global__ __launch_bounds__(256, 3) void rel_attn_de_stream_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dsrel, float* __restrict__ dEr /* = dE + (M-L)*64 */,
-    int bgroup, int wg_per_group, int L, int d) {
-    using namespace k3s;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hh = lane >> 5;
-    const int heads = d >> 6, nbh = bgroup * heads;        // (b,h) pairs of ONE batch group
-    const size_t ld = (size_t)3 * d;
-    // workgroup -> (batch group, distance tile, slice of the tile's flattened (bh, row-block) sweep).  Groups outermost:
-    // the 16 distance tiles of a group re-read that group's q rows (33 MB at cfg2) in quick succession instead of
-    // sweeping the whole batch's q once per distance tile; inside a group tiles are laid out heaviest first.
-    int t = 0, first = 0, ns = 0;
-    const int grp = blockIdx.x / wg_per_group;
-    {
-        int rest = blockIdx.x - grp * wg_per_group;
-        const int ntile = (L + DT - 1) / DT;
-        for (t = 0; t < ntile; ++t) {
-            ns = (L - t * DT + RS - 1) / RS;               // row blocks i0 = t*DT, +64, ... < L
-            const int nwg = (nbh * ns + STEPS - 1) / STEPS;
-            if (rest < nwg) break;
-            rest -= nwg;
-        }
-        if (t == ntile) return;
-        first = rest * STEPS;
-    }
-    const int total = nbh * ns;
-    const int last = min(total, first + STEPS);
-    const int d0 = t * DT;
-
-    // staging.  dS: a step's [64 i][128 delta] block = 2 query blocks x 4 chunks = 8 stored tiles of 2 KB (the 4 chunk
-    // tiles of one query block are adjacent: 8 KB runs); thread -> 16-byte units u = tid + 256 i: tile u>>7, unit u&127
-    // = (ks, row a, half hh) as the dQ kernel wrote them.  q: rows of 128 B (8 lanes x 16 B).
-    const int nchunk = L >> 5;
-    const int qrow = tid >> 3, qch = tid & 7;              // rows qrow + 32 i
-    int a_src[4], a_dst[4], a_qq[4];
-    bool a_colok[4];
-    const size_t ntri = (size_t)nchunk * (nchunk + 1) / 2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int u = tid + 256 * i;
-        const int tt = u >> 7, v = u & 127;
-        const int rb = tt >> 2, qq = tt & 3;               // query block (of 2), chunk (of 4) inside the step
-        const int ks = v >> 6, ar = (v >> 1) & 31, h2 = v & 1;
-        a_src[i] = qq * 1024 + v * 8;                      // elements, relative to tile (bh, I0 + rb, d0/32) of the packed grid
-        const int ch16 = 4 * qq + 2 * ks + h2;             // 16-byte column chunk 0..15 of the 128 distances
-        a_dst[i] = (rb * 2 + (ch16 >> 3)) * TILE_BYTES + imgT_off(ar, ch16 & 7);
-        a_colok[i] = (d0 >> 5) + qq < nchunk;
-        a_qq[i] = qq;
-    }
-    u32x4 areg[4], qreg[2];
-    bool a_ok[4], q_ok[2];
-    auto load_tiles = [&](int g) {
-        const int bhl = g / ns, i0 = d0 + (g - bhl * ns) * RS;
-        const int bh = grp * nbh + bhl;                    // (b,h) index in the whole batch
-        const int bb = bh / heads, hd = bh - bb * heads;
-        // packed causal grid: row block I holds chunks 0..I at (bh*T + I(I+1)/2 + q) * 1024; chunks q > I are zeros
-        const int I0 = i0 >> 5;
-        const uint16_t* ap = dsrel + ((size_t)bh * ntri + (size_t)I0 * (I0 + 1) / 2 + (d0 >> 5)) * 1024;
-        const size_t rb1 = (size_t)(I0 + 1) * 1024;        // row block I0+1 starts I0+1 tiles further
-        const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + qch * 8;
-        const bool second = i0 + 32 < L;                   // L % 64 may be 32: the step's second query block is absent
-        // Every load is unconditional (a guarded load is an exec-mask branch, and where it rejoins the compiler drains the
-        // VMEM queue): units that do not exist -- chunk above the row block's diagonal, second query block beyond L -- read a
-        // valid address instead (the step's first tile / the last row) and are zeroed when they are written to LDS.
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rb = i >> 1;                         // units 0,1 -> first query block, 2,3 -> second (u = tid + 256 i)
-            a_ok[i] = a_colok[i] && (rb == 0 || second) && ((d0 >> 5) + a_qq[i] <= I0 + rb);
-            const size_t off = a_ok[i] ? (size_t)a_src[i] + (rb ? rb1 : 0) : (size_t)(a_src[i] & 1023);
-            areg[i] = __builtin_nontemporal_load((const u32x4*)(ap + off));      // read once: do not displace q in L2
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = qrow + 32 * i;
-            q_ok[i] = i0 + r < L;
-            qreg[i] = *(const u32x4*)(qp + (size_t)min(r, L - 1 - i0) * ld);
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        char* at = smem + OFF_A + buf * 4 * TILE_BYTES;
-        char* qt = smem + OFF_Q + buf * 2 * TILE_BYTES;
-        const u32x4 zero = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(at + a_dst[i]) = a_ok[i] ? areg[i] : zero;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = qrow + 32 * i;
-            *(u32x4*)(qt + (r >> 5) * TILE_BYTES + imgT_off(r & 31, qch)) = q_ok[i] ? qreg[i] : zero;
-        }
-    };
-    f32x16 de0 = zero16(), de1 = zero16();
-    if (first < last) {
-        load_tiles(first);
-        store_tiles(0);
-    }
-    __syncthreads();
-    auto multiply = [&](int cur) {
-        const char* at = smem + OFF_A + cur * 4 * TILE_BYTES;
-        const char* qt = smem + OFF_Q + cur * 2 * TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 af = frag_Tn(at + ((ks >> 1) * 2 + (w >> 1)) * TILE_BYTES, lane, ks & 1, w & 1);
-            const char* qs = qt + (ks >> 1) * TILE_BYTES;
-            de0 = mfma(af, frag_Tn(qs, lane, ks & 1, 0), de0);
-            de1 = mfma(af, frag_Tn(qs, lane, ks & 1, 1), de1);
-        }
-    };
-    // all steps but the last: branch-free body (prefetch the next step's tiles first, multiply, publish)
-    for (int g = first; g + 1 < last; ++g) {
-        const int cur = (g - first) & 1;
-        load_tiles(g + 1);
-        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the products
-        multiply(cur);
-        store_tiles(cur ^ 1);
-        __syncthreads();
-    }
-    if (first < last) multiply((last - 1 - first) & 1);
-    // flush: rows = distances 32w + crow(r,hh) of the tile, columns on lanes; q was not pre-scaled -> 1/8 here
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int dl = d0 + 32 * w + crow(r, hh);
-        if (dl < L) {
-            float* row = dEr + (size_t)(L - 1 - dl) * 64;
-            atomicAdd(row + l31, 0.125f * de0[r]);
-            atomicAdd(row + 32 + l31, 0.125f * de1[r]);
-        }
-    }
-}
-
-// ================================================================================================
 // K3t: dE from the dS tiles the dK/dV kernel stored (by query tile x key tile, NOT yet un-skewed):
 //     dEr[delta][c] = 1/8 sum_{b,h} sum_{i >= delta} dS[b,h][i][i-delta] q[b,i,h,c]
 // A workgroup owns four tile DIAGONALS I - J = c0 + m, m = 0..3, for a fixed number of 64-row steps of the flattened
@@ -1360,20 +1158,16 @@ static size_t ws_delta_bytes(int B, int L, int d) { return (((size_t)B * (d / 64
 
 static size_t ws_ert_bytes(int L) { return 2 * er_frag_bytes(L); }   // EfA | EfT
 
-static size_t ws_ds_bytes(int B, int L, int d) {
-    const size_t nchunk = (size_t)L / 32;
-    return (size_t)B * (d / 64) * (nchunk * (nchunk + 1) / 2) * 2048;
-}
-
 extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
     if (B <= 0 || L <= 0 || d <= 0) return 0;
-    // delta f32 [B,h,L] | fragment-ordered Er (EfA, EfT) | causal half of dS by (query, distance) bf16 [B,h,L,L]
-    // | the same causal half once more: dS by (query tile, key tile), left by the dK/dV kernel for the dQ kernel
-    return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + 2 * ws_ds_bytes(B, L, d);
+    // delta f32 [B,h,L] | fragment-ordered Er (EfA, EfT) | causal half of dS by (query tile, key tile) bf16: B*h*T tiles of 2 KB
+    const size_t nchunk = (size_t)L / 32;
+    return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * (nchunk * (nchunk + 1) / 2) * 2048;
 }
 
-// parts: 1 pre-pass (delta, E transpose) | 2 dQ (also leaves dS for 8) | 4 dK/dV | 8 dE streamed from the dS the dQ
-// kernel left in the workspace | 16 dE by the recompute kernel (independent of 2; cross-check / A-B timing).
+// parts: 1 pre-pass (delta, E re-layout) | 4 dK/dV (stores the dS tiles) | 2 dQ from the stored tiles | 8 dE from the stored
+// tiles | 16 dE by recomputation | 32 dQ by recomputation (16, 32: independent of the stored tiles; cross-checks / A-B
+// timing).  Launch order inside one call: 1, 4, 2 (or 32), 8, 16.
 extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                                       const uint16_t* ctx, const uint16_t* dctx, const float* lse, uint16_t* dqkv,
                                       float* dE, void* workspace, size_t ws_bytes, int B, int L, int d, int M,
@@ -1384,17 +1178,12 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     MGX_REQUIRE(ws_bytes >= mgx_rel_attn_bwd_workspace(B, L, d) && ((uintptr_t)workspace & 255) == 0, MGX_ERR_SHAPE,
                 "mgx_rel_attn_bwd: workspace must be 256-byte aligned and >= mgx_rel_attn_bwd_workspace() = %zu bytes (got %zu)",
                 mgx_rel_attn_bwd_workspace(B, L, d), ws_bytes);
+    MGX_REQUIRE(!((parts & 2) && (parts & 32)), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: parts 2 and 32 both write dq");
     static const bool attr_once = [] {                  // thread-safe one-time init (C++11 function-local static)
-        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dq_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k1::LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_dq_lite_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k1l::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k2::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dq_lite_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, k1l::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_dq_lite_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, k1l::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3::LDS_BYTES);
-        hipFuncSetAttribute((const void*)rel_attn_de_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3s::LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_de_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, k3t::LDS_BYTES);
         return true;
     }();
@@ -1405,59 +1194,28 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     float* delta = (float*)workspace;
     u32x4* EfA = (u32x4*)((char*)workspace + ws_delta_bytes(B, L, d));
     u32x4* EfT = (u32x4*)((char*)EfA + er_frag_bytes(L));
-    uint16_t* dsrel = (uint16_t*)((char*)EfA + ws_ert_bytes(L));
-    uint16_t* dst = (uint16_t*)((char*)dsrel + ws_ds_bytes(B, L, d));
-    // delta = rowsum(dO o O): when the dQ kernel runs in this call it computes and publishes delta itself (its waves own
-    // the rows); the stand-alone kernel is only needed when dK/dV or the recompute dE kernel run without it
-    // dQ and dK/dV both wanted: the dK/dV kernel runs FIRST and stores its dS tiles, the dQ kernel (dq_lite) reads them
-    // instead of recomputing S / Q.Er^T / P / dP (MGX_ATTN_BWD_PIPE=0: the two independent recompute kernels, for A/B runs)
-    const int pipe_env = env_digit("MGX_ATTN_BWD_PIPE", 1);
-    const bool pipe = (parts & 2) && (parts & 4) && ((parts & 8) || !(parts & 16)) && pipe_env != 0;
-    const bool dq_makes_delta = (parts & 1) && (parts & 2) && !pipe;
+    uint16_t* dst = (uint16_t*)((char*)EfA + ws_ert_bytes(L));
     if (parts & 1) {
-        if (!dq_makes_delta) {
-            const long total = (long)B * L * heads * 8;
-            hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
-        }
+        // delta = rowsum(dO o O) for the kernels that form dS (dK/dV and the two recompute cross-checks)
+        const long total = (long)B * L * heads * 8;
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
         launch_er_frag(Er, EfA, EfT, L, s);
     }
     const int bg = bwd_batch_group(B, L, d);
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
     const dim3 gq(bg * heads, ((L + 127) / 128) * (B / bg));
-    const bool export_ds = (parts & 8) || !(parts & 16);
-    // MGX_ATTN_DQ64=1 and L % 256 == 0: the software-pipelined dQ kernel with 64 query rows per wave (rel_attn_bwd2.hip), in
-    // the configuration the training step uses (dS export + own delta).  Opt-in: 0.72 ms against 0.60 ms for the kernel below
-    // at cfg2 (profiles/README.md, round 3).
-    if (pipe) {
+    if (parts & 4)
         hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
-        if (pipe_env == 2)      // dQ also exports dS by (query, distance) for the K3s dE kernel (A/B against K3t)
-            hipLaunchKernelGGL(rel_attn_dq_lite_kernel<true>, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, dsrel, L, d, bg);
-        else
-            hipLaunchKernelGGL(rel_attn_dq_lite_kernel<false>, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, dsrel, L, d, bg);
-    } else if ((parts & 2) && L % 256 == 0 && export_ds && dq_makes_delta && env_is_one("MGX_ATTN_DQ64")) {
-        if (int rc = dq64_launch(qkv, EfA, EfT, padbits, dctx, lse, delta, dqkv, dsrel, ctx, B, L, d, stream)) return rc;
-    } else if (parts & 2) {
-#define MGX_DQ_LAUNCH(EXP, OWN) hipLaunchKernelGGL((rel_attn_dq_kernel<EXP, OWN>), gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, \
-                                                   padbits, dctx, lse, delta, dqkv, dsrel, ctx, L, d, bg)
-        if (export_ds) { if (dq_makes_delta) MGX_DQ_LAUNCH(true, true); else MGX_DQ_LAUNCH(true, false); }
-        else           { if (dq_makes_delta) MGX_DQ_LAUNCH(false, true); else MGX_DQ_LAUNCH(false, false); }
-#undef MGX_DQ_LAUNCH
-    }
-    if ((parts & 4) && !pipe)
-        hipLaunchKernelGGL(rel_attn_dkv_kernel<false>, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
-    if ((parts & 8) && pipe && pipe_env != 2) {
+    if (parts & 2)
+        hipLaunchKernelGGL(rel_attn_dq_lite_kernel, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, L, d, bg);
+    if (parts & 32)
+        hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, padbits, dctx, lse, delta, dqkv, L, d, bg);
+    if (parts & 8) {
         long nwg = 0;                                   // workgroups of ONE batch group
         for (int t = 0; t < (L / 32 + k3t::DIAGS - 1) / k3t::DIAGS; ++t)
             nwg += ((long)bg * heads * ((L - t * k3t::DIAGS * 32 + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
         MGX_REQUIRE(nwg * (B / bg) < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
         hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)(nwg * (B / bg))), dim3(64 * k3t::NW), k3t::LDS_BYTES, s, qkv, dst,
-                           dE + (size_t)(M - L) * 64, bg, (int)nwg, L, d);
-    } else if (parts & 8) {
-        long nwg = 0;                                   // workgroups of ONE batch group
-        for (int t = 0; t < (L + k3s::DT - 1) / k3s::DT; ++t)
-            nwg += ((long)bg * heads * ((L - t * k3s::DT + k3s::RS - 1) / k3s::RS) + k3s::STEPS - 1) / k3s::STEPS;
-        MGX_REQUIRE(nwg * (B / bg) < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
-        hipLaunchKernelGGL(rel_attn_de_stream_kernel, dim3((unsigned)(nwg * (B / bg))), dim3(256), k3s::LDS_BYTES, s, qkv, dsrel,
                            dE + (size_t)(M - L) * 64, bg, (int)nwg, L, d);
     }
     if (parts & 16) {

@@ -219,8 +219,5 @@ int fwd64_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, 
                  void* stream);   // rel_attn_fwd2.hip
 int fwdpp_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, uint16_t* ctx, float* lse, int B, int L, int d,
                  void* stream);   // rel_attn_fwd3.hip
-int dq64_launch(const uint16_t* qkv, const void* EfA, const void* EfT, const uint32_t* padbits, const uint16_t* dctx,
-                const float* lse, float* delta, uint16_t* dqkv, uint16_t* dsrel, const uint16_t* ctx, int B, int L, int d,
-                void* stream);    // rel_attn_bwd2.hip
 
 }  // namespace relattn

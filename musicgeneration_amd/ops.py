@@ -97,11 +97,11 @@ def _side_streams(dev):
 
 
 def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None, concurrent=None) -> torch.Tensor:
-    """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench).
-    parts: 1 pre-pass | 2 dQ (leaves dS in the workspace) | 4 dK/dV | 8 dE streamed from that dS | 16 dE by recompute.
-    concurrent (opt-in, MGX_CONCURRENT_BWD=1): after dQ, the HBM-bound dE stream kernel runs on a second stream next to
-    the latency-bound dK/dV kernel (measured +0.9 % end to end).  Default is one stream, which keeps per-kernel
-    profiles comparable."""
+    """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench, cross-checks):
+    1 pre-pass | 4 dK/dV (stores its dS tiles in the workspace) | 2 dQ from those tiles | 8 dE from those tiles |
+    16 dE by recomputation | 32 dQ by recomputation (instead of 2).
+    concurrent (opt-in, MGX_CONCURRENT_BWD=1): after dK/dV, the two HBM-bound readers of the dS tiles (dQ, dE) run on two
+    streams.  Default is one stream, which keeps per-kernel profiles comparable."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)
     B, L, d3 = qkv.shape
     d = d3 // 3
@@ -117,16 +117,14 @@ def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, works
     if not concurrent:
         check(lib.mgx_rel_attn_bwd_parts(*args, int(parts), stream_ptr()), "mgx_rel_attn_bwd")
         return dqkv
-    # dQ first (it produces the dS tiles), then the HBM-bound dE stream kernel on a side stream next to the
-    # latency-bound dK/dV kernel: they want different resources
     main = torch.cuda.current_stream()
     s1, _ = _side_streams(qkv.device)
-    check(lib.mgx_rel_attn_bwd_parts(*args, 1 | 2, main.cuda_stream), "mgx_rel_attn_bwd(pre, dQ)")
+    check(lib.mgx_rel_attn_bwd_parts(*args, 1 | 4, main.cuda_stream), "mgx_rel_attn_bwd(pre, dKV)")
     ready = torch.cuda.Event()
     ready.record(main)
     s1.wait_event(ready)
     check(lib.mgx_rel_attn_bwd_parts(*args, 8, s1.cuda_stream), "mgx_rel_attn_bwd(dE)")
-    check(lib.mgx_rel_attn_bwd_parts(*args, 4, main.cuda_stream), "mgx_rel_attn_bwd(dKV)")
+    check(lib.mgx_rel_attn_bwd_parts(*args, 2, main.cuda_stream), "mgx_rel_attn_bwd(dQ)")
     main.wait_stream(s1)
     return dqkv
 

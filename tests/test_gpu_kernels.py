@@ -284,12 +284,16 @@ def test_rel_attn_bwd_matches_oracle_autograd(B, L, d, M, padcase):
     # rows of E that no (i,j) pair can reach (index < M-L) must stay exactly zero
     if M > L:
         assert (dE[:M - L] == 0).all()
-    # two independent dE implementations (streamed from the dQ kernel's dS vs full recomputation) agree to
+    # two independent dE implementations (from the dS tiles the dK/dV kernel stored vs full recomputation) agree to
     # fp32 summation order: both multiply the same bf16 dS and q values
     dE2 = torch.zeros(M, 64, device=dev)
-    ops.rel_attn_bwd(qd, Ed, bits, ctx, dctx.to(dev), lse, dE2, parts=1 | 16)
+    dq2 = ops.rel_attn_bwd(qd, Ed, bits, ctx, dctx.to(dev), lse, dE2, parts=1 | 16 | 32)
     torch.cuda.synchronize()
     assert (dE2.cpu() - dE).abs().max().item() <= 1e-4 * max(1.0, dE.abs().max().item())
+    # ... and two dQ implementations (from the stored tiles vs the recompute kernel, which forms its own dS): bf16 rounding of dS
+    dq2 = dq2[..., :d].float().cpu()
+    assert (dq2 - dqkv[..., :d]).abs().max().item() <= 2e-2 * dq2.abs().max().item()
+    assert _relerr(dqkv[..., :d], dq2) < 5e-3
 
 
 @pytest.mark.parametrize("M,N,K,act", [(128, 128, 64, 0), (300, 340, 128, 0), (1000, 1536, 512, 0),

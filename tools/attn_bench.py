@@ -7,7 +7,7 @@ from musicgeneration_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=8); ap.add_argument("--L", type=int, default=2048)
 ap.add_argument("--d", type=int, default=512); ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--parts", type=int, default=63, help="bit0 fwd, bit1 delta, bit2 dq, bit3 dkv, bit4 de (streamed), bit5 de (recompute), bit6 whole backward (both pipelines)")
+ap.add_argument("--parts", type=int, default=63, help="bit0 fwd, bit1 pre-pass, bit2 dq (from tiles / recompute), bit3 dkv, bit4 de (from tiles), bit5 de (recompute), bit6 whole backward")
 ap.add_argument("--rounds", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda")
@@ -42,19 +42,16 @@ if a.parts & 1:
         timed(with_env("MGX_ATTN_FWD64", "1", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd64")
         timed(with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwdpp")
         timed(with_env("MGX_ATTN_PP_RIGID", "1", with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None))), 3, "fwdpp_r")
-if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, ws), 0, "delta")
+if a.parts & 2: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1, dqkv, ws), 0, "pre")
 if a.parts & 4:
     for _ in range(a.rounds):
-        # parts 1|2 = what the training step launches: E fragment pre-pass (5 us) + the dQ kernel that makes its own delta
-        timed(with_env("MGX_ATTN_DQ64", "0", lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 3, dqkv, ws)), 5, "dq32")
-        timed(with_env("MGX_ATTN_DQ64", "1", lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 3, dqkv, ws)), 5, "dq64")
+        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 2, dqkv, ws), 2, "dq_lite")     # from the stored dS tiles
+        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 32, dqkv, ws), 5, "dq_rec")     # recompute (cross-check kernel)
 if a.parts & 8:
     for _ in range(a.rounds):
         timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
-if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de")
+if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de_tiles")
 if a.parts & 32: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 16, dqkv, ws), 6, "de_rec")
 if a.parts & 64:
     for _ in range(a.rounds):
-        # the whole backward as the training step calls it (parts 15): two recompute kernels vs dK/dV-first pipeline
-        for mode, name in (("0", "bwd_rec"), ("1", "bwd_pipe"), ("2", "bwd_p_nx")):
-            timed(with_env("MGX_ATTN_BWD_PIPE", mode, lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, ws)), 12, name)
+        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 15, dqkv, ws), 9, "bwd")       # the whole backward as the step calls it

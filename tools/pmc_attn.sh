@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 B=${1:-16}
 ROOT=$(pwd)
 OUT=${2:-gpurun_out/pmc_attn.json}
-PARTS=${PARTS:-15}
+PARTS=${PARTS:-65}     # attn_bench.py parts: forward + the whole backward
 TAG=pmcattn_$$
 mkdir -p gpurun_out
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \

@@ -17,10 +17,10 @@ cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_cfg2_b3
 python3 tools/stats_summary.py $OUT/${TAG}_bench_cfg2_b32_kernel_stats.csv 7 | head -14
 echo "== PMC utilisation of the attention kernels"; bash tools/pmc_attn.sh 32 $OUT/${TAG}_pmc_attn_b32.json | tail -8 || exit 1
 echo "== PMC traffic"; bash tools/traffic.sh $OUT/${TAG}_traffic_cfg2_b32.json | head -12 || exit 1
-echo "== attention variants A/B"; timeout -k 10 300 python3 tools/attn_bench.py --B 32 --parts 31 --reps 10 --rounds 2 2>&1 | grep -v amdgpu.ids | tee $OUT/${TAG}_attn_variants.txt
+echo "== attention variants A/B"; timeout -k 10 300 python3 tools/attn_bench.py --B 32 --parts 125 --reps 10 --rounds 2 2>&1 | grep -v amdgpu.ids | tee $OUT/${TAG}_attn_variants.txt
 for v in 81000 160000; do echo "MGX_FWD_LDS=$v"; MGX_FWD_LDS=$v timeout -k 10 300 python3 tools/attn_bench.py --B 32 --parts 1 --reps 10 --rounds 2 2>&1 | grep fwd32; done | tee -a $OUT/${TAG}_attn_variants.txt
 if [ -f musicgeneration_amd/libmgx_stamp.so ]; then
-  echo "== stamps"; for k in fwd dq; do MGX_LIB_PATH=musicgeneration_amd/libmgx_stamp.so timeout -k 10 300 python3 tools/attn64_stamp.py --kernel $k 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_stamps_${k}64.txt; tail -3 $OUT/${TAG}_stamps_${k}64.txt; done
+  echo "== stamps"; for k in fwd; do MGX_LIB_PATH=musicgeneration_amd/libmgx_stamp.so timeout -k 10 300 python3 tools/attn64_stamp.py --kernel $k 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_stamps_${k}64.txt; tail -3 $OUT/${TAG}_stamps_${k}64.txt; done
 fi
 echo "== decode trace"
 rm -rf /tmp/dt && (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dt -- python3 $ROOT/tools/decode_bench.py --L 8192 > /tmp/dt.log 2>&1) || { tail -5 /tmp/dt.log; exit 1; }
