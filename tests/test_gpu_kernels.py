@@ -247,9 +247,13 @@ def test_adam_matches_torch():
 
 @pytest.mark.parametrize("B,L,d,M,padcase", [(1, 32, 64, 32, 0), (2, 64, 128, 64, 1), (1, 160, 64, 192, 0),
                                               (2, 256, 128, 256, 1), (1, 512, 128, 512, 0), (3, 416, 128, 416, 1),
-                                              (3, 96, 192, 96, 1), (5, 32, 64, 40, 0)])
+                                              (3, 96, 192, 96, 1), (5, 32, 64, 40, 0),
+                                              # long sweeps with L % 128 == 32: every main loop of dq_lite / dK/dV plus their tails,
+                                              # nine diagonal groups of de_tiles with a ragged last one
+                                              (1, 1056, 64, 1056, 1), (2, 800, 64, 1024, 0)])
 def test_rel_attn_bwd_matches_oracle_autograd(B, L, d, M, padcase):
-    """dq/dk/dv/dE of the three backward kernels vs autograd through the oracle (fp32, same bf16 inputs)."""
+    """dq/dk/dv/dE of the backward kernels (dK/dV storing dS, dQ and dE from the stored tiles) vs autograd through the oracle
+    (fp32, same bf16 inputs)."""
     from musicgeneration_amd import ops
     from oracle import ref_cpu as R
     dev = _dev()
