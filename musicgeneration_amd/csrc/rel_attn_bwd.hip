@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
 //   * the same registers are scattered into the (query, distance & 63) band exactly as K1 does; the completed chunk is the
 //     B operand of dqs^T += ErT . dS_rel^T.
 // ================================================================================================
+#ifndef MGX_DQL_PEEL
+#define MGX_DQL_PEEL 0      // timing experiments only (tools/peel_dq_lite.sh): bits drop parts of the dq_lite step, results are then wrong
+#endif                    // 1 dS^T patch stores | 2 three quarters of the band stores | 4 half of dS K | 8 half of dS_rel ErT | 16 K / ErT ring refills
 namespace k1l {
 constexpr int OFF_KR = 0;                                  // 2 x 4K  K image R (tile t in slot t & 1)
 constexpr int OFF_ET = OFF_KR + 2 * TILE_BYTES;            // 8 x 4K  ErT chunk fragments, ring: chunk Q0 - k in slot k & 7
@@ -462,10 +465,12 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
     auto compute = [&](int p, const char* kt, const char* ec, const u32x4 (&t)[2]) {
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            *(u32x2*)(xt + xw0 + 16 * (2 * ss)) = u32x2{t[ss].x, t[ss].y};
-            *(u32x2*)(xt + xw0 + 16 * (2 * ss + 1)) = u32x2{t[ss].z, t[ss].w};
+            if (!(MGX_DQL_PEEL & 1)) {
+                *(u32x2*)(xt + xw0 + 16 * (2 * ss)) = u32x2{t[ss].x, t[ss].y};
+                *(u32x2*)(xt + xw0 + 16 * (2 * ss + 1)) = u32x2{t[ss].z, t[ss].w};
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < ((MGX_DQL_PEEL & 2) ? 1 : 4); ++j) {
                 const int r0 = 8 * ss + 2 * j;
                 *(uint16_t*)(dband + (p ? dwa1[r0] : dwa0[r0])) = (uint16_t)t[ss][j];
                 *(uint16_t*)(dband + (p ? dwa1[r0 + 1] : dwa0[r0 + 1])) = (uint16_t)(t[ss][j] >> 16);
@@ -473,13 +478,13 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
         }
         wave_lds_fence();
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
+        for (int ss = 0; ss < ((MGX_DQL_PEEL & 4) ? 1 : 2); ++ss) {
             const bf16x8 df = frag_X(ss);
             dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df, dq0);
             dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df, dq1);
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < ((MGX_DQL_PEEL & 8) ? 1 : 2); ++ks) {
             const bf16x8 gq = *(const bf16x8*)(dband + a * DB_STRIDE + (p * 32 + 16 * ks + 8 * hh) * 2);
             dq0 = mfma(*(const bf16x8*)(ec + (2 * ks) * 1024 + lane16), gq, dq0);
             dq1 = mfma(*(const bf16x8*)(ec + (2 * ks + 1) * 1024 + lane16), gq, dq1);
@@ -494,11 +499,13 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
         dsr[SLOT][1] = ds_load(s + DEPTH, 1);
         if (active) compute(PAR, smem + OFF_KR + PAR * TILE_BYTES, smem + OFF_ET + ((s - w) & 7) * 4096, t);
         // items s+1 (requested two steps ago): the K slot was last read in step s-1, the chunk slot in step s-4
-        *(u32x4*)(smem + OFF_KR + (PAR ^ 1) * TILE_BYTES + st_offR) = kq[PAR];
-        *(u32x4*)(smem + OFF_ET + ((s + 1) & 7) * 4096 + tid16) = eq[PAR];
-        // the freed registers take items s+3 (no register rotation: a move of a register with a load in flight is a wait)
-        kq[PAR] = k_tile(s + 3);
-        eq[PAR] = e_item(s + 3);
+        if (!(MGX_DQL_PEEL & 16)) {
+            *(u32x4*)(smem + OFF_KR + (PAR ^ 1) * TILE_BYTES + st_offR) = kq[PAR];
+            *(u32x4*)(smem + OFF_ET + ((s + 1) & 7) * 4096 + tid16) = eq[PAR];
+            // the freed registers take items s+3 (no register rotation: a move of a register with a load in flight is a wait)
+            kq[PAR] = k_tile(s + 3);
+            eq[PAR] = e_item(s + 3);
+        }
         __syncthreads();
     };
     using S0_ = std::integral_constant<int, 0>; using S1_ = std::integral_constant<int, 1>;
