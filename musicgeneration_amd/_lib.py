@@ -13,7 +13,7 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 # the ABI the SIGNATURES table below was written for (MGX_ABI_VERSION of include/mgx.h).  A left-over
 # libmgx.so of another ABI still exports the same names: calling it with this table would shift arguments.
-EXPECTED_ABI = 13
+EXPECTED_ABI = 14
 
 # name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
 SIGNATURES = {
@@ -45,6 +45,8 @@ SIGNATURES = {
     "mgx_linear_dx": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_gru_cell_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_gru_cell_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mgx_gru_step_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mgx_gru_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_dropout_bf16": [_vp, _vp, _sz, _f, _u64, _vp],
     "mgx_scatter_add_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_linear_ln_fwd": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -26,16 +26,43 @@ def _pad_cols(w: torch.Tensor, k: int) -> torch.Tensor:
     return out.contiguous()
 
 
+def _captured(ws, key, body, use_graph):
+    """Run ``body()`` (a fixed sequence of kernel launches on buffers that live in ``ws``) -- through a hipGraph captured on
+    first use when ``use_graph``: a layer's T time steps are T dependent launches of ~5 us each, issued from Python they
+    are launch-bound (the interpreter + ctypes cost more than the kernels)."""
+    if not use_graph:
+        body()
+        return
+    g = ws["graphs"].get(key)
+    if g is None:
+        body()                                              # warm-up run (also the result of this call)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        ws["graphs"][key] = g
+        return
+    g.replay()
+
+
 class _GRUSeq(torch.autograd.Function):
     """Teacher-forced multi-layer GRU + output projection over a whole sequence (network.py:63-84 SeqForward with the
     primary step folded in as step 0), forward and backward-through-time on the libmgx kernels.
 
-    forward(tokens int32 [T,B], h0 f32 [layers,B,H], pk (packed bf16 operands), p_drop, seed, *params)
-    -> logits f32 [T,B,V].  ``params`` = embedding, (w_ih, w_hh, b_ih, b_hh) per layer, output weight, output bias:
-    they are only there so that autograd routes the gradients this node returns into their ``.grad``."""
+    forward(tokens int32 [T,B], h0 f32 [layers,B,H], pk (packed bf16 operands), ws (per-(T,B) buffers + graphs), p_drop, seed,
+    *params) -> logits f32 [T,B,V].  ``params`` = embedding, (w_ih, w_hh, b_ih, b_hh) per layer, output weight, output bias:
+    they are only there so that autograd routes the gradients this node returns into their ``.grad``.
+
+    Per layer: ONE GEMM for the input projections of all time steps, then T fused step kernels (recurrent projection +
+    cell, ``mgx_gru_step_fwd``) replayed from a hipGraph; backward-through-time is T fused step kernels the other way
+    (``mgx_gru_step_bwd``: d_rec = dgh_{t+1} W_hh, then the cell backward), weight gradients batched over the sequence."""
 
     @staticmethod
-    def forward(ctx, tokens, h0, pk, p_drop, seed, *params):
+    def forward(ctx, tokens, h0, pk, ws, p_drop, seed, *params):
         T, B = tokens.shape
         nl, H = h0.shape[0], h0.shape[2]
         dev = h0.device
@@ -43,31 +70,36 @@ class _GRUSeq(torch.autograd.Function):
         x = torch.empty(T * B, pk["Ep"], dtype=BF16, device=dev)
         check(_load().mgx_gather_rows(ptr(tok), ptr(pk["emb"]), ptr(x), T * B, pk["Ep"], pk["emb"].shape[0], stream_ptr()),
               "mgx_gather_rows")
-        saved = []
+        ws["gen"] += 1
+        xs = []
         for l, ly in enumerate(pk["layers"]):
-            gi = ops.linear_fwd(x, ly["wih"], ly["bih"], 0).view(T, B, 3 * H)       # all time steps in one GEMM
-            h_all = torch.empty(T + 1, B, H, dtype=torch.float32, device=dev)
-            hp = torch.empty(T + 1, B, H, dtype=BF16, device=dev)                   # hp[t] = bf16(h_{t-1}); y = hp[1:]
+            wl = ws["layers"][l]
+            gi, gh, h_all, hp = wl["gi"], wl["gh"], wl["h_all"], wl["hp"]
+            gi.view(T * B, 3 * H).copy_(ops.linear_fwd(x, ly["wih"], ly["bih"], 0))     # all time steps in one GEMM
             h_all[0].copy_(h0[l])
-            hp[0].copy_(h0[l])
-            gh = []
-            for t in range(T):
-                g = ops.linear_fwd(hp[t], ly["whh"], ly["bhh"], 0)
-                ops.gru_cell_fwd(gi[t], g, h_all[t], h_all[t + 1], hp[t + 1])
-                gh.append(g)
-            saved.append((x, gi, gh, h_all, hp))
+            hp[0].copy_(h0[l])                               # hp[t] = bf16(h_{t-1}); y = hp[1:]
+
+            def steps(gi=gi, gh=gh, h_all=h_all, hp=hp, ly=ly):
+                for t in range(T):
+                    ops.gru_step_fwd(gi[t], hp[t], h_all[t], ly["whh"], ly["bhh"], h_all[t + 1], hp[t + 1], gh[t])
+            _captured(ws, ("fwd", l), steps, ws["use_graph"])
+            xs.append(x)
             x = hp[1:].reshape(T * B, H)
             if l < nl - 1:
                 x = ops.dropout_bf16(x, p_drop, seed + l)
         logits = ops.linear_fwd(x, pk["wo"], pk["bo"], 0)
-        ctx.pk, ctx.saved, ctx.cfg, ctx.x_last, ctx.tok = pk, saved, (T, B, H, nl, p_drop, seed), x, tok
+        ctx.pk, ctx.ws, ctx.gen, ctx.xs = pk, ws, ws["gen"], xs
+        ctx.cfg, ctx.x_last, ctx.tok = (T, B, H, nl, p_drop, seed), x, tok
         ctx.shapes = [p.shape for p in params]
         V = params[0].shape[0]
         return logits[:, :V].float().view(T, B, V)
 
     @staticmethod
     def backward(ctx, dlogits):
-        pk, saved = ctx.pk, ctx.saved
+        pk, ws = ctx.pk, ctx.ws
+        if ws["gen"] != ctx.gen:
+            raise RuntimeError("Event_Melody_RNN.Train: the sequence buffers of this forward were overwritten by a later Train() "
+                               "call with the same shape; call backward() before the next forward")
         T, B, H, nl, p_drop, seed = ctx.cfg
         dev = dlogits.device
         V, Vp = ctx.shapes[0][0], pk["wo"].shape[0]
@@ -80,27 +112,27 @@ class _GRUSeq(torch.autograd.Function):
         dh0 = torch.empty(nl, B, H, device=dev)
         layer_grads = [None] * nl
         for l in reversed(range(nl)):
-            ly = pk["layers"][l]
-            x_in, gi, gh, h_all, hp = saved[l]
+            ly, wl = pk["layers"][l], ws["layers"][l]
+            gi, gh, h_all, hp = wl["gi"], wl["gh"], wl["h_all"], wl["hp"]
+            dgi, dgh, dy, dh_dir, dh0_l = wl["dgi"], wl["dgh"], wl["dy"], wl["dh"], wl["dh0"]
             if l < nl - 1:
                 dx = ops.dropout_bf16(dx, p_drop, seed + l)
-            dy = dx.view(T, B, H)
-            dgi = torch.empty(T, B, 3 * H, dtype=BF16, device=dev)
-            dgh = torch.empty(T, B, 3 * H, dtype=BF16, device=dev)
-            dh_dir = [torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)]
-            d_rec = None
-            for t in reversed(range(T)):
-                cur = dh_dir[t & 1]
-                ops.gru_cell_bwd(gi[t], gh[t], h_all[t], None if t == T - 1 else dh_dir[(t + 1) & 1], d_rec, dy[t], dgi[t],
-                                 dgh[t], cur)
-                d_rec = ops.linear_dx(dgh[t], ly["whh"])
-            dh0[l] = dh_dir[0] + d_rec.float()
+            dy.view(T * B, H).copy_(dx)
+
+            def steps(gi=gi, gh=gh, h_all=h_all, dgi=dgi, dgh=dgh, dy=dy, dh_dir=dh_dir, dh0_l=dh0_l, ly=ly):
+                for t in reversed(range(T)):
+                    last = t == T - 1
+                    ops.gru_step_bwd(gi[t], gh[t], h_all[t], None if last else dh_dir[(t + 1) & 1], None if last else dgh[t + 1],
+                                     ly["whhT"], dy[t], dgi[t], dgh[t], dh_dir[t & 1])
+                ops.gru_step_bwd(None, None, None, dh_dir[0], dgh[0], ly["whhT"], None, None, None, dh0_l, final=True)
+            _captured(ws, ("bwd", l), steps, ws["use_graph"])
+            dh0[l] = dh0_l
             in_p = ly["wih"].shape[1]
             g_wih = torch.zeros(3 * H, in_p, device=dev)
             g_whh = torch.zeros(3 * H, H, device=dev)
             g_bih = torch.zeros(3 * H, device=dev)
             g_bhh = torch.zeros(3 * H, device=dev)
-            ops.linear_dw_grouped([(dgi.view(T * B, 3 * H), x_in, g_wih, g_bih),
+            ops.linear_dw_grouped([(dgi.view(T * B, 3 * H), ctx.xs[l], g_wih, g_bih),
                                    (dgh.view(T * B, 3 * H), hp[:-1].reshape(T * B, H), g_whh, g_bhh)])
             layer_grads[l] = (g_wih, g_whh, g_bih, g_bhh)
             dx = ops.linear_dx(dgi.view(T * B, 3 * H), ly["wih"])                   # gradient of the layer's input
@@ -111,8 +143,8 @@ class _GRUSeq(torch.autograd.Function):
             g_wih, g_whh, g_bih, g_bhh = layer_grads[l]
             grads += [g_wih[:, : ctx.shapes[1 + 4 * l][1]], g_whh, g_bih, g_bhh]
         grads += [g_wo[:V], g_bo[:V]]
-        ctx.saved = None
-        return (None, dh0, None, None, None) + tuple(grads)
+        ctx.xs = None
+        return (None, dh0, None, None, None, None) + tuple(grads)
 
 
 class Event_Melody_RNN(nn.Module):
@@ -133,33 +165,67 @@ class Event_Melody_RNN(nn.Module):
         if hidden_dim % 64:
             raise ValueError("hidden_dim must be a multiple of 64 for the MFMA projections")
         self._packed = None
+        self._train_ws = {}
 
-    # ---- bf16 operand pack (rebuilt when parameters change) -----------------------------------------
+    # ---- bf16 operand pack (refreshed in place when parameters change) -----------------------------------------
     def _pack(self):
+        """bf16 operand copies of the parameters.  The buffers are allocated ONCE per device and refreshed in place when a
+        parameter changes, so that hipGraphs that captured their addresses (generate's step, Train's time loops) stay valid
+        across optimiser steps."""
         ver = tuple(p._version for p in self.parameters())
         dev = self.output_fc.weight.device
-        if self._packed is not None and self._packed["ver"] == ver and self._packed["dev"] == dev:
-            return self._packed
+        pk = self._packed
+        if pk is not None and pk["ver"] == ver and pk["dev"] == dev:
+            return pk
         if dev.type != "cuda":
             raise ops._lib.MgxError("Event_Melody_RNN runs on the MI355X kernels only: move it to a HIP device")
+        H, nl = self.hidden_dim, self.rnn_layers
         Ep = (self.event_dim + 63) // 64 * 64            # embedding width padded to the GEMM's K % 64
         Vp = (self.event_dim + 7) // 8 * 8               # output rows padded to N % 8 (forward needs 4, dX/dW 8)
-        pk = {"ver": ver, "dev": dev, "Ep": Ep, "Vp": Vp,
-              "emb": _pad_cols(self.event_embedding.weight.data, Ep), "layers": []}
-        for l in range(self.rnn_layers):
-            wih = getattr(self.rnn, f"weight_ih_l{l}").data
-            pk["layers"].append(dict(
-                wih=_pad_cols(wih, Ep) if l == 0 else wih.to(BF16).contiguous(),
-                whh=getattr(self.rnn, f"weight_hh_l{l}").data.to(BF16).contiguous(),
-                bih=getattr(self.rnn, f"bias_ih_l{l}").data.float().contiguous(),
-                bhh=getattr(self.rnn, f"bias_hh_l{l}").data.float().contiguous()))
-        wo = torch.zeros(Vp, self.hidden_dim, dtype=BF16, device=dev)
-        wo[: self.event_dim] = self.output_fc.weight.data.to(BF16)
-        bo = torch.zeros(Vp, dtype=torch.float32, device=dev)
-        bo[: self.event_dim] = self.output_fc.bias.data.float()
-        pk["wo"], pk["bo"] = wo, bo
+        if pk is None or pk["dev"] != dev:
+            pk = {"dev": dev, "Ep": Ep, "Vp": Vp, "emb": torch.zeros(self.event_dim, Ep, dtype=BF16, device=dev), "layers": [],
+                  "wo": torch.zeros(Vp, H, dtype=BF16, device=dev), "bo": torch.zeros(Vp, dtype=torch.float32, device=dev)}
+            for l in range(nl):
+                in_p = Ep if l == 0 else H
+                pk["layers"].append(dict(wih=torch.zeros(3 * H, in_p, dtype=BF16, device=dev),
+                                         whh=torch.empty(3 * H, H, dtype=BF16, device=dev),
+                                         whhT=torch.empty(H, 3 * H, dtype=BF16, device=dev),      # W_hh^T: fused backward step
+                                         bih=torch.empty(3 * H, dtype=torch.float32, device=dev),
+                                         bhh=torch.empty(3 * H, dtype=torch.float32, device=dev)))
+            self._train_ws = {}
+        with torch.no_grad():
+            pk["emb"][:, : self.event_dim].copy_(self.event_embedding.weight.data)
+            for l, ly in enumerate(pk["layers"]):
+                wih = getattr(self.rnn, f"weight_ih_l{l}").data
+                whh = getattr(self.rnn, f"weight_hh_l{l}").data
+                ly["wih"][:, : wih.shape[1]].copy_(wih)
+                ly["whh"].copy_(whh)
+                ly["whhT"].copy_(whh.t())
+                ly["bih"].copy_(getattr(self.rnn, f"bias_ih_l{l}").data)
+                ly["bhh"].copy_(getattr(self.rnn, f"bias_hh_l{l}").data)
+            pk["wo"][: self.event_dim].copy_(self.output_fc.weight.data)
+            pk["bo"][: self.event_dim].copy_(self.output_fc.bias.data)
+        pk["ver"] = ver
         self._packed = pk
         return pk
+
+    def _train_workspace(self, pk, T, B):
+        """sequence buffers of Train for one (T, B) -- they cross the boundary of the captured time loops, so they must keep
+        their addresses between calls -- and the hipGraphs of those loops.  At most four shapes are kept."""
+        import os
+        cache = self._train_ws
+        ws = cache.get((T, B))
+        if ws is None:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            dev, H = pk["dev"], self.hidden_dim
+            mk = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
+            ws = {"gen": 0, "graphs": {}, "use_graph": os.environ.get("MGX_GRU_GRAPH", "1") != "0", "layers": [
+                dict(gi=mk(T, B, 3 * H), gh=mk(T, B, 3 * H), h_all=mk(T + 1, B, H, dt=torch.float32), hp=mk(T + 1, B, H),
+                     dgi=mk(T, B, 3 * H), dgh=mk(T, B, 3 * H), dy=mk(T, B, H), dh=mk(2, B, H, dt=torch.float32),
+                     dh0=mk(B, H, dt=torch.float32)) for _ in range(self.rnn_layers)]}
+            cache[(T, B)] = ws
+        return ws
 
     # ---- reference API ------------------------------------------------------------------------------
     def get_primary_event(self, batch_size):
@@ -239,7 +305,8 @@ class Event_Melody_RNN(nn.Module):
             params += [getattr(self.rnn, f"{n}_l{l}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
         params += [self.output_fc.weight, self.output_fc.bias]
         seed = (torch.initial_seed() + 7919 * self._train_calls) & 0x7FFFFFFFFFFF
-        return _GRUSeq.apply(tokens, hidden, pk, p_drop, seed, *params)
+        ws = self._train_workspace(pk, tokens.shape[0], B)
+        return _GRUSeq.apply(tokens, hidden, pk, ws, p_drop, seed, *params)
 
     @torch.no_grad()
     def generate(self, init, steps, events=None, greedy=1.0, temperature=1.0, teacher_forcing_ratio=1.0,

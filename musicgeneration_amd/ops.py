@@ -257,6 +257,22 @@ def gru_cell_bwd(gi, gh, h_prev, dh_direct, d_rec, dy, dgi, dgh, dh_prev_direct)
                                        ptr(dh_prev_direct), B, H, stream_ptr()), "mgx_gru_cell_bwd")
 
 
+def gru_step_fwd(gi, h_prev_bf, h_prev, whh, bhh, h_next, y, gh_out):
+    """one fused time step: gh_out bf16 [B,3H] = h_prev_bf @ whh.T + bhh, then h_next f32 / y bf16 [B,H] = cell(gi, gh, h_prev)"""
+    _need_cuda(gi, h_prev_bf, h_prev, whh, bhh, h_next, y, gh_out)
+    B, H = h_prev.shape
+    check(_lib.load().mgx_gru_step_fwd(ptr(gi), ptr(h_prev_bf), ptr(h_prev), ptr(whh), ptr(bhh), ptr(h_next), ptr(y), ptr(gh_out),
+                                       B, H, stream_ptr()), "mgx_gru_step_fwd")
+
+
+def gru_step_bwd(gi, gh, h_prev, dh_direct, dgh_next, whh_t, dy, dgi, dgh, dh_out, final=False):
+    """one fused backward step: d_rec = dgh_next @ whh (whh_t = whh.T, bf16 [H,3H]), then the cell backward (see mgx.h)"""
+    _need_cuda(gi, gh, h_prev, dh_direct, dgh_next, whh_t, dy, dgi, dgh, dh_out)
+    B, H = dh_out.shape
+    check(_lib.load().mgx_gru_step_bwd(ptr(gi), ptr(gh), ptr(h_prev), ptr(dh_direct), ptr(dgh_next), ptr(whh_t), ptr(dy), ptr(dgi),
+                                       ptr(dgh), ptr(dh_out), B, H, 1 if final else 0, stream_ptr()), "mgx_gru_step_bwd")
+
+
 def dropout_bf16(x, p_drop, seed):
     """stateless inverted dropout; the same call on a gradient is the backward"""
     _need_cuda(x)

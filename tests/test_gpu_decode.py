@@ -419,3 +419,93 @@ def test_cfg5_sized_graph_replay_equals_eager_greedy():
     same = (a[:, P:] == b[:, P:]).float().mean().item()
     # greedy tokens are a deterministic function of the logits; the only run-to-run noise is none (no atomics on this path)
     assert same == 1.0, same
+
+
+@pytest.mark.parametrize("B,H", [(100, 512), (5, 64), (33, 128), (130, 64)])
+def test_gru_fused_step_kernels_match_the_two_kernel_path(B, H):
+    """mgx_gru_step_fwd / mgx_gru_step_bwd (recurrent projection + cell in one launch) against the kernels they replace
+    (mgx_linear_fwd / mgx_linear_dx + mgx_gru_cell_fwd / _bwd): the same bf16 rounding points, so they agree to the
+    fp32 summation order of the projection (one bf16 ulp where a rounding flips)."""
+    from musicgeneration_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * 7 + H)
+    bf = torch.bfloat16
+    whh = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(bf).to(dev)
+    bhh = (torch.randn(3 * H, generator=g) * 0.1).to(dev)
+    gi = torch.randn(B, 3 * H, generator=g).to(bf).to(dev)
+    h_prev = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    hp_bf = h_prev.to(bf)
+    # forward
+    gh_ref = ops.linear_fwd(hp_bf, whh, bhh, 0)
+    hn_ref, y_ref = torch.empty_like(h_prev), torch.empty_like(hp_bf)
+    ops.gru_cell_fwd(gi, gh_ref, h_prev, hn_ref, y_ref)
+    hn, y, gh = torch.empty_like(h_prev), torch.empty_like(hp_bf), torch.empty_like(gi)
+    ops.gru_step_fwd(gi, hp_bf, h_prev, whh, bhh, hn, y, gh)
+    torch.cuda.synchronize()
+    assert (gh.float() - gh_ref.float()).abs().max().item() <= 2 ** -7 * gh_ref.float().abs().max().item()
+    assert (hn - hn_ref).abs().max().item() <= 2e-2
+    assert ((hn - hn_ref).norm() / hn_ref.norm()).item() < 2e-3
+    # backward (a middle step: every input present) and the final d_h0 step
+    dgh_next = (torch.randn(B, 3 * H, generator=g) * 0.1).to(bf).to(dev)
+    dh_dir = (torch.randn(B, H, generator=g) * 0.1).to(dev)
+    dy = (torch.randn(B, H, generator=g) * 0.1).to(bf).to(dev)
+    d_rec = ops.linear_dx(dgh_next, whh)
+    dgi_r, dgh_r, dd_r = torch.empty_like(gi), torch.empty_like(gi), torch.empty_like(h_prev)
+    ops.gru_cell_bwd(gi, gh_ref, h_prev, dh_dir, d_rec, dy, dgi_r, dgh_r, dd_r)
+    dgi, dgh, dd, d0 = torch.empty_like(gi), torch.empty_like(gi), torch.empty_like(h_prev), torch.empty_like(h_prev)
+    whh_t = whh.t().contiguous()
+    ops.gru_step_bwd(gi, gh_ref, h_prev, dh_dir, dgh_next, whh_t, dy, dgi, dgh, dd)
+    ops.gru_step_bwd(None, None, None, dh_dir, dgh_next, whh_t, None, None, None, d0, final=True)
+    torch.cuda.synchronize()
+    for got, ref in ((dgi, dgi_r), (dgh, dgh_r), (dd, dd_r), (d0, dh_dir + d_rec.float())):
+        got, ref = got.float(), ref.float()
+        assert ((got - ref).norm() / ref.norm()).item() < 4e-3
+        assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    # first backward step of a sequence: no d_rec, no dh_direct
+    ops.gru_cell_bwd(gi, gh_ref, h_prev, None, None, dy, dgi_r, dgh_r, dd_r)
+    ops.gru_step_bwd(gi, gh_ref, h_prev, None, None, whh_t, dy, dgi, dgh, dd)
+    torch.cuda.synchronize()
+    for got, ref in ((dgi, dgi_r), (dgh, dgh_r), (dd, dd_r)):      # pure cell arithmetic: equal up to fma contraction
+        assert (got.float() - ref.float()).abs().max().item() <= 2 ** -7 * ref.float().abs().max().item()
+        assert ((got.float() - ref.float()).norm() / ref.float().norm()).item() < 1e-3
+
+
+def test_gru_train_graph_replay_equals_eager_and_survives_an_optimizer_step(monkeypatch):
+    """Train's time loops replayed from hipGraphs give the same logits and gradients as the eager launches, and the graphs
+    stay valid after the parameters change (the bf16 operand copies are refreshed in place); a second forward before the
+    backward of the first is refused."""
+    from musicgeneration_amd.melody_rnn import Event_Melody_RNN
+    torch.manual_seed(3)
+    V, H, B, T = 40, 64, 6, 9
+    net = Event_Melody_RNN(init_dim=8, event_dim=V, hidden_dim=H, rnn_layers=2, dropout=0.0).cuda()
+    init = torch.randn(B, 8, device="cuda")
+    ev = torch.randint(0, V, (T, B), device="cuda")
+
+    def grads():
+        net.zero_grad()
+        out = net.Train(init, ev)
+        (out.float() ** 2).mean().backward()
+        return out.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]
+
+    monkeypatch.setenv("MGX_GRU_GRAPH", "0")
+    net._train_ws = {}
+    out_e, g_e = grads()
+    monkeypatch.setenv("MGX_GRU_GRAPH", "1")
+    net._train_ws = {}
+    grads()                                                  # call 1 captures
+    out_g, g_g = grads()                                     # call 2 replays
+    assert torch.equal(out_e, out_g)
+    for a, b in zip(g_e, g_g):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)     # dW kernels add M-splits with fp32 atomics: order varies
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.01)
+    out_g2, _ = grads()                                      # replayed graphs read the refreshed operand copies
+    monkeypatch.setenv("MGX_GRU_GRAPH", "0")
+    net._train_ws = {}
+    out_e2, _ = grads()
+    assert torch.equal(out_e2, out_g2) and not torch.equal(out_e2, out_e)
+    o1 = net.Train(init, ev)
+    net.Train(init, ev)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        o1.sum().backward()
