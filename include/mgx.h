@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd */
 #define MGX_ABI_VERSION 14
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
@@ -232,12 +232,20 @@ int mgx_gru_cell_bwd(const uint16_t* gi, const uint16_t* gh, const float* h_prev
                      const uint16_t* d_rec, const uint16_t* dy, uint16_t* dgi, uint16_t* dgh,
                      float* dh_prev_direct, int B, int H, void* stream);
 /* Fused time step (ABI 14): the recurrent projection and the cell in ONE launch each way (H % 64 == 0).
- * forward: gh = h_prev_bf16 W_hh^T + b_hh (W_hh bf16 [3H,H], rounded to bf16 and stored in gh_out [B,3H] for the backward),
+ * The weights of these three entry points are bf16 in FRAGMENT ORDER: for a matrix W [N,K] (N % 32 == 0, K % 16 == 0) the
+ * 16-byte unit ((nt * K/16 + ks) * 64 + lane) holds W[32 nt + lane % 32][16 ks + 8 (lane / 32) .. +7] -- what lane `lane` feeds
+ * the MFMA for row tile nt and k-step ks, so a wave load is 1 KB contiguous (ops.pack_frag / melody_rnn._pack build it).
+ * forward: gh = h_prev_bf16 W_hh^T + b_hh (W_hh [3H,H] in fragment order, rounded to bf16 and stored in gh_out [B,3H] for the backward),
  *          then h_next f32, y bf16 [B,H] = cell(gi, gh, h_prev) exactly as mgx_gru_cell_fwd.                               */
 int mgx_gru_step_fwd(const uint16_t* gi, const uint16_t* h_prev_bf16, const float* h_prev, const uint16_t* Whh,
                      const float* bhh, float* h_next, uint16_t* y, uint16_t* gh_out, int B, int H, void* stream);
+/* sampling step of one layer: gi = x W_ih^T + b_ih (x bf16 [B,Kx], W_ih [3H,Kx] and W_hh in fragment order, Kx % 64 == 0), gh as above, the cell -- one
+ * launch instead of two projections + mgx_gru_gates.  NOT in place: h_next / y must differ from h_prev / h_prev_bf16.     */
+int mgx_gru_step_x_fwd(const uint16_t* x, const uint16_t* Wih, const float* bih, int Kx, const uint16_t* h_prev_bf16,
+                       const float* h_prev, const uint16_t* Whh, const float* bhh, float* h_next, uint16_t* y, int B, int H,
+                       void* stream);
 /* backward of step t: d_rec = dgh_next W_hh (dgh_next bf16 [B,3H] = step t+1's dgh, NULL at the last step; WhhT = W_hh^T
- * bf16 [H,3H]), then mgx_gru_cell_bwd with it: dgi, dgh bf16 [B,3H], dh_out f32 [B,H] = dh * z.  final != 0: no cell,
+ * [H,3H] in fragment order), then mgx_gru_cell_bwd with it: dgi, dgh bf16 [B,3H], dh_out f32 [B,H] = dh * z.  final != 0: no cell,
  * dh_out = dh_direct + d_rec (the gradient of the layer's initial state; gi/gh/h_prev/dgi/dgh may be NULL).           */
 int mgx_gru_step_bwd(const uint16_t* gi, const uint16_t* gh, const float* h_prev, const float* dh_direct,
                      const uint16_t* dgh_next, const uint16_t* WhhT, const uint16_t* dy, uint16_t* dgi, uint16_t* dgh,

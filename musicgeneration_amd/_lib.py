@@ -46,6 +46,7 @@ SIGNATURES = {
     "mgx_gru_cell_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_gru_cell_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_gru_step_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mgx_gru_step_x_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_gru_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_dropout_bf16": [_vp, _vp, _sz, _f, _u64, _vp],
     "mgx_scatter_add_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

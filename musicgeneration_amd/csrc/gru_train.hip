@@ -101,8 +101,10 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const uint16_t* __res
     const int mrow = m0 + l31;
     const bool mv = mrow < B;
     const uint16_t* xp = hp_bf + (size_t)(mv ? mrow : 0) * H + w * kq + hh * 8;
-    const uint16_t* wp = Whh + (size_t)(u0 + l31) * H + w * kq + hh * 8;  // gate g: + g * H * H
-    const size_t gstride = (size_t)H * H;
+    // W_hh in FRAGMENT order (mgx.h): the 16 bytes lane l feeds the MFMA for row tile nt, k-step ks sit at ((nt*K/16 + ks)*64 + l)*16,
+    // so a wave load is 1 KB contiguous (from the row-major matrix it touched 32 B of 32 different rows)
+    const uint16_t* wp = Whh + (((size_t)(u0 >> 5) * (H >> 4) + (size_t)(w * kq >> 4)) * 64 + lane) * 8;   // gate g: + g * gstride
+    const size_t gstride = (size_t)H * H;                    // H/32 row tiles of H/16 k-steps of 512 elements
     // the cell's own inputs (row tid >> 3, 4 units) are requested first: they arrive under the projection's round trip
     const int mr = tid >> 3, u4 = (tid & 7) * 4;
     const int m = m0 + mr, mc = m < B ? m : B - 1;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const uint16_t* __res
             const bool in = k0 + 16 * f < kq;
             xf[f] = (mv && in) ? *(const u32x4*)(xp + k0 + 16 * f) : u32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wf[g][f] = in ? *(const u32x4*)(wp + g * gstride + k0 + 16 * f) : u32x4{0, 0, 0, 0};
+            for (int g = 0; g < 3; ++g) wf[g][f] = in ? *(const u32x4*)(wp + g * gstride + (size_t)(k0 + 16 * f) * 32) : u32x4{0, 0, 0, 0};
         }
 #pragma unroll
         for (int f = 0; f < GRU_CH; ++f)
@@ -174,6 +176,119 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const uint16_t* __res
         *(u32x2*)(gh_out + go + g * H) = u32x2{pack_bf16x2(ghv[g][0], ghv[g][1]), pack_bf16x2(ghv[g][2], ghv[g][3])};
 }
 
+// Sampling step of one layer (Event_MelodyRNN/network.py:144-149 via gen_forward): BOTH projections and the cell in one launch --
+// gi = x W_ih^T + b_ih and gh = h_{t-1} W_hh^T + b_hh (each rounded to bf16 as the three-kernel path stores them), then the cell.
+// Same decomposition as the training step above; all fragment loads of both projections are requested before the first MFMA
+// (one L2 round trip), the two reductions go through the same LDS buffer one after the other.  h is NOT updated in place:
+// other workgroups still read h_{t-1} as their operand, the host alternates two state buffers.
+__global__ __launch_bounds__(256) void gru_step_x_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ Wih,
+                                                             const float* __restrict__ bih, int Kx,
+                                                             const uint16_t* __restrict__ hp_bf, const float* __restrict__ h_prev,
+                                                             const uint16_t* __restrict__ Whh, const float* __restrict__ bhh,
+                                                             float* __restrict__ h_next, uint16_t* __restrict__ y, int B, int H) {
+    __shared__ float part[4][96][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int u0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int kq = H >> 2, kx = Kx >> 2;                     // K per wave of the two projections (multiples of 16)
+    const int mrow = m0 + l31;
+    const bool mv = mrow < B;
+    const int mr = tid >> 3, u4 = (tid & 7) * 4;
+    const int m = m0 + mr, mc = m < B ? m : B - 1;
+    const size_t ho = (size_t)mc * H + u0 + u4;
+    float bi[3][4], bh[3][4];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const f32x4 a4 = *(const f32x4*)(bih + g * H + u0 + u4), b4 = *(const f32x4*)(bhh + g * H + u0 + u4);
+        bi[g][0] = a4.x; bi[g][1] = a4.y; bi[g][2] = a4.z; bi[g][3] = a4.w;
+        bh[g][0] = b4.x; bh[g][1] = b4.y; bh[g][2] = b4.z; bh[g][3] = b4.w;
+    }
+    const f32x4 hp4 = *(const f32x4*)(h_prev + ho);
+    // both projections: every fragment of the first chunks (8 k-steps = 128 columns per wave: all of them for Kx, H <= 512) is
+    // requested before the first MFMA, so the step costs one L2 round trip, not two
+    const uint16_t* xr = x + (size_t)(mv ? mrow : 0) * Kx + w * kx + hh * 8;
+    const uint16_t* wir = Wih + (((size_t)(u0 >> 5) * (Kx >> 4) + (size_t)(w * kx >> 4)) * 64 + lane) * 8;      // fragment order
+    const uint16_t* hr = hp_bf + (size_t)(mv ? mrow : 0) * H + w * kq + hh * 8;
+    const uint16_t* whr = Whh + (((size_t)(u0 >> 5) * (H >> 4) + (size_t)(w * kq >> 4)) * 64 + lane) * 8;
+    const size_t gsi = (size_t)H * Kx, gsh = (size_t)H * H;
+    f32x16_ ai[3], ah[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ai[g][r] = 0.f; ah[g][r] = 0.f; }
+    {
+        u32x4 xf[GRU_CH], wf[3][GRU_CH], hf[GRU_CH], vf[3][GRU_CH];
+#pragma unroll
+        for (int f = 0; f < GRU_CH; ++f) {
+            const bool ix = 16 * f < kx, ih = 16 * f < kq;
+            xf[f] = (mv && ix) ? *(const u32x4*)(xr + 16 * f) : u32x4{0, 0, 0, 0};
+            hf[f] = (mv && ih) ? *(const u32x4*)(hr + 16 * f) : u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                wf[g][f] = ix ? *(const u32x4*)(wir + g * gsi + (size_t)f * 512) : u32x4{0, 0, 0, 0};
+                vf[g][f] = ih ? *(const u32x4*)(whr + g * gsh + (size_t)f * 512) : u32x4{0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < GRU_CH; ++f)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ai[g] = mfma_(wf[g][f], xf[f], ai[g]);
+#pragma unroll
+        for (int f = 0; f < GRU_CH; ++f)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ah[g] = mfma_(vf[g][f], hf[f], ah[g]);
+    }
+    auto rest = [&](const uint16_t* xrow, const uint16_t* wrow, size_t gstride, int kw, f32x16_ (&acc)[3]) {     // K > 512 only
+        for (int k0 = 16 * GRU_CH; k0 < kw; k0 += 16 * GRU_CH) {
+            u32x4 xf[GRU_CH], wf[3][GRU_CH];
+#pragma unroll
+            for (int f = 0; f < GRU_CH; ++f) {
+                const bool in = k0 + 16 * f < kw;
+                xf[f] = (mv && in) ? *(const u32x4*)(xrow + k0 + 16 * f) : u32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wf[g][f] = in ? *(const u32x4*)(wrow + g * gstride + (size_t)(k0 + 16 * f) * 32) : u32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int f = 0; f < GRU_CH; ++f)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = mfma_(wf[g][f], xf[f], acc[g]);
+        }
+    };
+    rest(xr, wir, gsi, kx, ai);
+    rest(hr, whr, gsh, kq, ah);
+    float giv[3][4], ghv[3][4];
+    auto reduce = [&](const f32x16_ (&acc)[3], const float (&bias)[3][4], float (&out)[3][4]) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[w][g * 32 + crow_(r, hh)][l31] = acc[g][r];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int n = g * 32 + u4 + k;
+                out[g][k] = bf16_to_f32(f32_to_bf16(part[0][n][mr] + part[1][n][mr] + part[2][n][mr] + part[3][n][mr] + bias[g][k]));
+            }
+        __syncthreads();
+    };
+    reduce(ai, bi, giv);
+    reduce(ah, bh, ghv);
+    if (m >= B) return;
+    const float hpv[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+    float hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float r = sigm(giv[0][k] + ghv[0][k]);
+        const float z = sigm(giv[1][k] + ghv[1][k]);
+        const float n = tanhf(giv[2][k] + r * ghv[2][k]);
+        hv[k] = (1.f - z) * n + z * hpv[k];
+    }
+    *(f32x4*)(h_next + ho) = f32x4{hv[0], hv[1], hv[2], hv[3]};
+    *(u32x2*)(y + ho) = u32x2{pack_bf16x2(hv[0], hv[1]), pack_bf16x2(hv[2], hv[3])};
+}
+
 // NS waves split the reduction over the 3H gates.  final != 0: no cell, dh_out = dh_direct + dgh_next W_hh (the gradient of
 // the layer's initial state)
 template <int NS>
@@ -210,7 +325,7 @@ __global__ __launch_bounds__(64 * NS) void gru_step_bwd_kernel(const uint16_t* _
         const int mrow = m0 + l31;
         const bool mv = mrow < B;
         const uint16_t* xp = dgh_next + (size_t)(mv ? mrow : 0) * G3 + w * kq + hh * 8;
-        const uint16_t* wp = WhhT + (size_t)(u0 + l31) * G3 + w * kq + hh * 8;
+        const uint16_t* wp = WhhT + (((size_t)(u0 >> 5) * (G3 >> 4) + (size_t)(w * kq >> 4)) * 64 + lane) * 8;   // fragment order
         f32x16_ acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -220,7 +335,7 @@ __global__ __launch_bounds__(64 * NS) void gru_step_bwd_kernel(const uint16_t* _
             for (int f = 0; f < 12; ++f) {
                 const bool in = k0 + 16 * f < kq;
                 xf[f] = (mv && in) ? *(const u32x4*)(xp + k0 + 16 * f) : u32x4{0, 0, 0, 0};
-                wf[f] = in ? *(const u32x4*)(wp + k0 + 16 * f) : u32x4{0, 0, 0, 0};
+                wf[f] = in ? *(const u32x4*)(wp + (size_t)(k0 + 16 * f) * 32) : u32x4{0, 0, 0, 0};
             }
 #pragma unroll
             for (int f = 0; f < 12; ++f) acc = mfma_(wf[f], xf[f], acc);
@@ -373,5 +488,19 @@ extern "C" int mgx_gru_step_bwd(const uint16_t* gi, const uint16_t* gh, const fl
         hipLaunchKernelGGL(gru_step_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, gi, gh, h_prev, dh_direct, dgh_next, WhhT,
                            dy, dgi, dgh, dh_out, B, H, final);
     MGX_CHECK_LAUNCH("mgx_gru_step_bwd");
+    return MGX_OK;
+}
+
+extern "C" int mgx_gru_step_x_fwd(const uint16_t* x, const uint16_t* Wih, const float* bih, int Kx, const uint16_t* h_prev_bf,
+                                  const float* h_prev, const uint16_t* Whh, const float* bhh, float* h_next, uint16_t* y, int B,
+                                  int H, void* stream) {
+    MGX_REQUIRE(x && Wih && bih && h_prev_bf && h_prev && Whh && bhh && h_next && y, MGX_ERR_NULL, "mgx_gru_step_x_fwd: NULL pointer");
+    MGX_REQUIRE(h_next != h_prev && y != h_prev_bf, MGX_ERR_SHAPE, "mgx_gru_step_x_fwd: the state is not updated in place "
+                "(other workgroups still read h_prev): pass a second pair of buffers");
+    MGX_REQUIRE(B > 0 && H > 0 && H % 64 == 0 && Kx > 0 && Kx % 64 == 0, MGX_ERR_SHAPE,
+                "mgx_gru_step_x_fwd: need H %% 64 == 0 and Kx %% 64 == 0 (got B=%d H=%d Kx=%d)", B, H, Kx);
+    hipLaunchKernelGGL(gru_step_x_fwd_kernel, dim3(H / 32, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream, x, Wih, bih, Kx,
+                       h_prev_bf, h_prev, Whh, bhh, h_next, y, B, H);
+    MGX_CHECK_LAUNCH("mgx_gru_step_x_fwd");
     return MGX_OK;
 }

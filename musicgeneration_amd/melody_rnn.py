@@ -81,7 +81,7 @@ class _GRUSeq(torch.autograd.Function):
 
             def steps(gi=gi, gh=gh, h_all=h_all, hp=hp, ly=ly):
                 for t in range(T):
-                    ops.gru_step_fwd(gi[t], hp[t], h_all[t], ly["whh"], ly["bhh"], h_all[t + 1], hp[t + 1], gh[t])
+                    ops.gru_step_fwd(gi[t], hp[t], h_all[t], ly["whh_f"], ly["bhh"], h_all[t + 1], hp[t + 1], gh[t])
             _captured(ws, ("fwd", l), steps, ws["use_graph"])
             xs.append(x)
             x = hp[1:].reshape(T * B, H)
@@ -123,8 +123,8 @@ class _GRUSeq(torch.autograd.Function):
                 for t in reversed(range(T)):
                     last = t == T - 1
                     ops.gru_step_bwd(gi[t], gh[t], h_all[t], None if last else dh_dir[(t + 1) & 1], None if last else dgh[t + 1],
-                                     ly["whhT"], dy[t], dgi[t], dgh[t], dh_dir[t & 1])
-                ops.gru_step_bwd(None, None, None, dh_dir[0], dgh[0], ly["whhT"], None, None, None, dh0_l, final=True)
+                                     ly["whhT_f"], dy[t], dgi[t], dgh[t], dh_dir[t & 1])
+                ops.gru_step_bwd(None, None, None, dh_dir[0], dgh[0], ly["whhT_f"], None, None, None, dh0_l, final=True)
             _captured(ws, ("bwd", l), steps, ws["use_graph"])
             dh0[l] = dh0_l
             in_p = ly["wih"].shape[1]
@@ -145,6 +145,20 @@ class _GRUSeq(torch.autograd.Function):
         grads += [g_wo[:V], g_bo[:V]]
         ctx.xs = None
         return (None, dh0, None, None, None, None) + tuple(grads)
+
+
+class _GruState:
+    """hidden state of the sampling step: two (f32, bf16) buffer pairs used alternately -- the fused layer step
+    (mgx_gru_step_x_fwd) cannot update h in place, other workgroups still read h_{t-1} as their operand."""
+
+    def __init__(self, h32):
+        self.h32 = [h32.detach().float().contiguous().clone(), torch.empty_like(h32, dtype=torch.float32)]
+        self.hbf = [self.h32[0].to(BF16), torch.empty_like(h32, dtype=BF16)]
+        self.cur = 0
+
+    @property
+    def h(self):
+        return self.h32[self.cur]
 
 
 class Event_Melody_RNN(nn.Module):
@@ -189,7 +203,10 @@ class Event_Melody_RNN(nn.Module):
                 in_p = Ep if l == 0 else H
                 pk["layers"].append(dict(wih=torch.zeros(3 * H, in_p, dtype=BF16, device=dev),
                                          whh=torch.empty(3 * H, H, dtype=BF16, device=dev),
-                                         whhT=torch.empty(H, 3 * H, dtype=BF16, device=dev),      # W_hh^T: fused backward step
+                                         # fragment-ordered copies for the fused step kernels (ops.pack_frag)
+                                         wih_f=torch.zeros(3 * H, in_p, dtype=BF16, device=dev),
+                                         whh_f=torch.empty(3 * H, H, dtype=BF16, device=dev),
+                                         whhT_f=torch.empty(H, 3 * H, dtype=BF16, device=dev),
                                          bih=torch.empty(3 * H, dtype=torch.float32, device=dev),
                                          bhh=torch.empty(3 * H, dtype=torch.float32, device=dev)))
             self._train_ws = {}
@@ -200,7 +217,9 @@ class Event_Melody_RNN(nn.Module):
                 whh = getattr(self.rnn, f"weight_hh_l{l}").data
                 ly["wih"][:, : wih.shape[1]].copy_(wih)
                 ly["whh"].copy_(whh)
-                ly["whhT"].copy_(whh.t())
+                ly["wih_f"].copy_(ops.pack_frag(ly["wih"]))
+                ly["whh_f"].copy_(ops.pack_frag(whh))
+                ly["whhT_f"].copy_(ops.pack_frag(whh.t()))
                 ly["bih"].copy_(getattr(self.rnn, f"bias_ih_l{l}").data)
                 ly["bhh"].copy_(getattr(self.rnn, f"bias_hh_l{l}").data)
             pk["wo"][: self.event_dim].copy_(self.output_fc.weight.data)
@@ -238,18 +257,19 @@ class Event_Melody_RNN(nn.Module):
         return out.view(self.rnn_layers, batch_size, self.hidden_dim)
 
     @torch.no_grad()
-    def _step(self, pk, tok_i32, h32, hbf, xbuf):
-        """event int32 [B] -> logits bf16 [B,Vp]; h32 f32 [layers,B,H] and hbf bf16 [layers,B,H] updated in place"""
+    def _step(self, pk, tok_i32, st, xbuf):
+        """event int32 [B] -> logits bf16 [B,Vp]; ``st`` (_GruState, [layers,B,H]) advances one step: per layer ONE launch
+        (both projections + the cell, network.py:144-149), reading st's current buffers and writing the other pair."""
         lib = _load()
-        B, H = tok_i32.numel(), self.hidden_dim
+        B = tok_i32.numel()
         check(lib.mgx_gather_rows(ptr(tok_i32), ptr(pk["emb"]), ptr(xbuf), B, pk["Ep"], self.event_dim, stream_ptr()),
               "mgx_gather_rows")
         x = xbuf
+        c, n = st.cur, st.cur ^ 1
         for l, ly in enumerate(pk["layers"]):
-            gi = ops.linear_fwd(x, ly["wih"], ly["bih"], 0)
-            gh = ops.linear_fwd(hbf[l], ly["whh"], ly["bhh"], 0)
-            check(lib.mgx_gru_gates(ptr(gi), ptr(gh), ptr(h32[l]), ptr(hbf[l]), B, H, stream_ptr()), "mgx_gru_gates")
-            x = hbf[l]
+            ops.gru_step_x_fwd(x, ly["wih_f"], ly["bih"], st.hbf[c][l], st.h32[c][l], ly["whh_f"], ly["bhh"], st.h32[n][l], st.hbf[n][l])
+            x = st.hbf[n][l]
+        st.cur = n
         return ops.linear_fwd(x, pk["wo"], pk["bo"], 0)
 
     @torch.no_grad()
@@ -259,12 +279,10 @@ class Event_Melody_RNN(nn.Module):
         pk = self._pack()
         B = event.shape[1]
         dev = pk["dev"]
-        h32 = (torch.zeros(self.rnn_layers, B, self.hidden_dim, device=dev) if hidden is None
-               else hidden.detach().float().clone().contiguous())
-        hbf = h32.to(BF16).contiguous()
+        st = _GruState(torch.zeros(self.rnn_layers, B, self.hidden_dim, device=dev) if hidden is None else hidden.to(dev))
         xbuf = torch.empty(B, pk["Ep"], dtype=BF16, device=dev)
-        logits = self._step(pk, event[0].to(torch.int32).contiguous(), h32, hbf, xbuf)
-        return logits[:, : self.event_dim].float().unsqueeze(0), h32
+        logits = self._step(pk, event[0].to(torch.int32).contiguous(), st, xbuf)
+        return logits[:, : self.event_dim].float().unsqueeze(0), st.h
 
     def forward(self, event, hidden=None):
         return self.gen_forward(event, hidden)
@@ -321,8 +339,7 @@ class Event_Melody_RNN(nn.Module):
             events = events[:steps - 1]
         pk = self._pack()
         dev, V = pk["dev"], self.event_dim
-        h32 = self.init_to_hidden(init).detach().float().contiguous().clone()
-        hbf = h32.to(BF16).contiguous()
+        st = _GruState(self.init_to_hidden(init))
         xbuf = torch.empty(batch_size, pk["Ep"], dtype=BF16, device=dev)
         tok = torch.full((batch_size,), self.primary_event, dtype=torch.int32, device=dev)
         pos = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -335,7 +352,7 @@ class Event_Melody_RNN(nn.Module):
         out_tokens = torch.zeros(batch_size, steps + 1, dtype=torch.int32, device=dev) if plain else None
 
         def one(step_greedy):
-            logits = self._step(pk, tok, h32, hbf, xbuf)
+            logits = self._step(pk, tok, st, xbuf)
             ops.sample_topk_topp(logits, V, pos, tok, out_tokens, probs, temperature, 1 if step_greedy else 0, 1.0, seed,
                                  advance=True)
             return logits
@@ -344,7 +361,8 @@ class Event_Melody_RNN(nn.Module):
         for step in range(steps):
             g = bool(coins[step])
             if plain and use_graph and steps > 8 and step >= 2:
-                if g not in graphs:
+                key = (g, st.cur)                           # a graph reads one state-buffer pair and writes the other
+                if key not in graphs:
                     torch.cuda.synchronize()
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
@@ -353,8 +371,10 @@ class Event_Melody_RNN(nn.Module):
                         with torch.cuda.graph(gr, stream=side):
                             one(g)
                     torch.cuda.current_stream().wait_stream(side)
-                    graphs[g] = gr
-                graphs[g].replay()
+                    st.cur ^= 1                             # the capture only recorded the step
+                    graphs[key] = gr
+                graphs[key].replay()
+                st.cur ^= 1
                 continue
             logits = one(g)
             if output_type == 'index':
@@ -386,8 +406,7 @@ class Event_Melody_RNN(nn.Module):
         dev, V, nl, H = pk["dev"], self.event_dim, self.rnn_layers, self.hidden_dim
         B, K = init.shape[0], beam_size
         h32 = self.init_to_hidden(init).detach().float()                          # [layers, B, H]
-        h32 = h32[:, :, None, :].repeat(1, 1, K, 1).reshape(nl, B * K, H).contiguous()
-        hbf = h32.to(BF16).contiguous()
+        st = _GruState(h32[:, :, None, :].repeat(1, 1, K, 1).reshape(nl, B * K, H))
         xbuf = torch.empty(B * K, pk["Ep"], dtype=BF16, device=dev)
         tok = torch.full((B * K,), self.primary_event, dtype=torch.int32, device=dev)
         score = torch.full((B, K), float("-inf"), device=dev)
@@ -396,7 +415,7 @@ class Event_Melody_RNN(nn.Module):
         gen = torch.Generator(device=dev).manual_seed(seed)
         rows = torch.arange(B, device=dev)[:, None]
         for _ in range(steps):
-            logits = self._step(pk, tok, h32, hbf, xbuf)[:, :V].float()          # [B*K, V]
+            logits = self._step(pk, tok, st, xbuf)[:, :V].float()                 # [B*K, V]
             logp = torch.log_softmax(logits / temperature, -1).view(B, K, V)
             cand = (score[:, :, None] + logp).view(B, K * V)                      # all expansions of all live beams
             if stochastic:
@@ -408,8 +427,7 @@ class Event_Melody_RNN(nn.Module):
             parent, event = pick // V, pick % V                                   # [B, K]
             seqs = torch.cat([seqs[rows, parent], event[:, :, None]], -1)
             flat = (rows * K + parent).reshape(-1)
-            h32 = h32[:, flat].contiguous()
-            hbf = hbf[:, flat].contiguous()
+            st = _GruState(st.h[:, flat])                                         # surviving parents' states
             tok = event.reshape(-1).to(torch.int32).contiguous()
         best = seqs[torch.arange(B, device=dev), score.argmax(-1)]                # [B, steps]
         return best.t().contiguous()

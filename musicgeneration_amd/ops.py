@@ -257,16 +257,34 @@ def gru_cell_bwd(gi, gh, h_prev, dh_direct, d_rec, dy, dgi, dgh, dh_prev_direct)
                                        ptr(dh_prev_direct), B, H, stream_ptr()), "mgx_gru_cell_bwd")
 
 
+def pack_frag(w: torch.Tensor) -> torch.Tensor:
+    """W [N,K] (N % 32 == 0, K % 16 == 0) -> bf16 copy in MFMA fragment order (mgx.h, fused GRU step): unit
+    ((nt*K/16 + ks)*64 + lane) = W[32 nt + lane % 32][16 ks + 8 (lane // 32) .. +7]"""
+    N, K = w.shape
+    if N % 32 or K % 16:
+        raise ValueError("pack_frag: need N % 32 == 0 and K % 16 == 0")
+    return w.to(BF16).view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(N, K)
+
+
 def gru_step_fwd(gi, h_prev_bf, h_prev, whh, bhh, h_next, y, gh_out):
-    """one fused time step: gh_out bf16 [B,3H] = h_prev_bf @ whh.T + bhh, then h_next f32 / y bf16 [B,H] = cell(gi, gh, h_prev)"""
+    """one fused time step (whh = pack_frag(W_hh)): gh_out bf16 [B,3H] = h_prev_bf @ W_hh.T + bhh, then h_next f32 / y bf16 [B,H] = cell(gi, gh, h_prev)"""
     _need_cuda(gi, h_prev_bf, h_prev, whh, bhh, h_next, y, gh_out)
     B, H = h_prev.shape
     check(_lib.load().mgx_gru_step_fwd(ptr(gi), ptr(h_prev_bf), ptr(h_prev), ptr(whh), ptr(bhh), ptr(h_next), ptr(y), ptr(gh_out),
                                        B, H, stream_ptr()), "mgx_gru_step_fwd")
 
 
+def gru_step_x_fwd(x, wih, bih, h_prev_bf, h_prev, whh, bhh, h_next, y):
+    """sampling step of one GRU layer in one launch (wih, whh = pack_frag of the weights): both projections + the cell;
+    (h_next, y) must not alias (h_prev, h_prev_bf)"""
+    _need_cuda(x, wih, bih, h_prev_bf, h_prev, whh, bhh, h_next, y)
+    B, H = h_prev.shape
+    check(_lib.load().mgx_gru_step_x_fwd(ptr(x), ptr(wih), ptr(bih), wih.shape[1], ptr(h_prev_bf), ptr(h_prev), ptr(whh), ptr(bhh),
+                                         ptr(h_next), ptr(y), B, H, stream_ptr()), "mgx_gru_step_x_fwd")
+
+
 def gru_step_bwd(gi, gh, h_prev, dh_direct, dgh_next, whh_t, dy, dgi, dgh, dh_out, final=False):
-    """one fused backward step: d_rec = dgh_next @ whh (whh_t = whh.T, bf16 [H,3H]), then the cell backward (see mgx.h)"""
+    """one fused backward step: d_rec = dgh_next @ W_hh (whh_t = pack_frag(W_hh.T)), then the cell backward (see mgx.h)"""
     _need_cuda(gi, gh, h_prev, dh_direct, dgh_next, whh_t, dy, dgi, dgh, dh_out)
     B, H = dh_out.shape
     check(_lib.load().mgx_gru_step_bwd(ptr(gi), ptr(gh), ptr(h_prev), ptr(dh_direct), ptr(dgh_next), ptr(whh_t), ptr(dy), ptr(dgi),

@@ -440,7 +440,7 @@ def test_gru_fused_step_kernels_match_the_two_kernel_path(B, H):
     hn_ref, y_ref = torch.empty_like(h_prev), torch.empty_like(hp_bf)
     ops.gru_cell_fwd(gi, gh_ref, h_prev, hn_ref, y_ref)
     hn, y, gh = torch.empty_like(h_prev), torch.empty_like(hp_bf), torch.empty_like(gi)
-    ops.gru_step_fwd(gi, hp_bf, h_prev, whh, bhh, hn, y, gh)
+    ops.gru_step_fwd(gi, hp_bf, h_prev, ops.pack_frag(whh), bhh, hn, y, gh)
     torch.cuda.synchronize()
     assert (gh.float() - gh_ref.float()).abs().max().item() <= 2 ** -7 * gh_ref.float().abs().max().item()
     assert (hn - hn_ref).abs().max().item() <= 2e-2
@@ -453,7 +453,7 @@ def test_gru_fused_step_kernels_match_the_two_kernel_path(B, H):
     dgi_r, dgh_r, dd_r = torch.empty_like(gi), torch.empty_like(gi), torch.empty_like(h_prev)
     ops.gru_cell_bwd(gi, gh_ref, h_prev, dh_dir, d_rec, dy, dgi_r, dgh_r, dd_r)
     dgi, dgh, dd, d0 = torch.empty_like(gi), torch.empty_like(gi), torch.empty_like(h_prev), torch.empty_like(h_prev)
-    whh_t = whh.t().contiguous()
+    whh_t = ops.pack_frag(whh.t())
     ops.gru_step_bwd(gi, gh_ref, h_prev, dh_dir, dgh_next, whh_t, dy, dgi, dgh, dd)
     ops.gru_step_bwd(None, None, None, dh_dir, dgh_next, whh_t, None, None, None, d0, final=True)
     torch.cuda.synchronize()
@@ -509,3 +509,30 @@ def test_gru_train_graph_replay_equals_eager_and_survives_an_optimizer_step(monk
     net.Train(init, ev)
     with pytest.raises(RuntimeError, match="overwritten"):
         o1.sum().backward()
+
+
+@pytest.mark.parametrize("B,H,Kx", [(32, 512, 320), (5, 64, 64), (40, 128, 192)])
+def test_gru_fused_sampling_step_matches_the_three_kernel_path(B, H, Kx):
+    """mgx_gru_step_x_fwd (both projections + the cell, one launch) against mgx_linear_fwd x 2 + mgx_gru_gates."""
+    from musicgeneration_amd import ops
+    from musicgeneration_amd._lib import check, ptr, stream_ptr, load
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B + H + Kx)
+    bf = torch.bfloat16
+    wih = (torch.randn(3 * H, Kx, generator=g) / Kx ** 0.5).to(bf).to(dev)
+    whh = (torch.randn(3 * H, H, generator=g) / H ** 0.5).to(bf).to(dev)
+    bih, bhh = (torch.randn(3 * H, generator=g) * 0.1).to(dev), (torch.randn(3 * H, generator=g) * 0.1).to(dev)
+    x = torch.randn(B, Kx, generator=g).to(bf).to(dev)
+    h = (torch.randn(B, H, generator=g) * 0.5).to(dev)
+    hb = h.to(bf)
+    h_ref, hb_ref = h.clone(), hb.clone()
+    gi, gh = ops.linear_fwd(x, wih, bih, 0), ops.linear_fwd(hb_ref, whh, bhh, 0)
+    check(load().mgx_gru_gates(ptr(gi), ptr(gh), ptr(h_ref), ptr(hb_ref), B, H, stream_ptr()), "mgx_gru_gates")
+    hn, y = torch.empty_like(h), torch.empty_like(hb)
+    ops.gru_step_x_fwd(x, ops.pack_frag(wih), bih, hb, h, ops.pack_frag(whh), bhh, hn, y)
+    torch.cuda.synchronize()
+    assert (hn - h_ref).abs().max().item() <= 2e-2
+    assert ((hn - h_ref).norm() / h_ref.norm()).item() < 2e-3
+    assert (y.float() - hb_ref.float()).abs().max().item() <= 3e-2
+    with pytest.raises(ops._lib.MgxError):
+        ops.gru_step_x_fwd(x, ops.pack_frag(wih), bih, hb, h, ops.pack_frag(whh), bhh, h, y)      # in place is refused
