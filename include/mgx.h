@@ -34,7 +34,7 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag) */
 #define MGX_ABI_VERSION 14
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
@@ -155,6 +155,16 @@ int mgx_linear_ln_fwd(const uint16_t* X, const uint16_t* RES, const float* gamma
 int mgx_decode_embed_linear(const int32_t* tok, const float* table, const float* pe, const int32_t* pos_dev,
                             const uint16_t* W, const float* bias, uint16_t* C, uint16_t* H, int M, int N, int K, int V,
                             void* stream);
+/* The three decode-size projections with the weight in MFMA FRAGMENT ORDER (see the fused GRU step below for the layout; rows
+ * zero-padded to a multiple of 32): a wave load of weights is 1 KB contiguous instead of 32 bytes of 32 different rows.   */
+int mgx_skinny_fwd_frag(const uint16_t* A, const uint16_t* Wf, const float* bias, uint16_t* C, int M, int N, int K, int act,
+                        void* stream);                                    /* M <= 32; = mgx_linear_fwd otherwise */
+int mgx_linear_ln_fwd_frag(const uint16_t* X, const uint16_t* RES, const float* gamma, const float* beta, float eps,
+                           const uint16_t* Wf, const float* bias, uint16_t* C, uint16_t* Z, int M, int N, int K, int act,
+                           void* stream);
+int mgx_decode_embed_linear_frag(const int32_t* tok, const float* table, const float* pe, const int32_t* pos_dev,
+                                 const uint16_t* Wf, const float* bias, uint16_t* C, uint16_t* H, int M, int N, int K, int V,
+                                 void* stream);
 
 /* backward of the above (autograd of the same reference lines):
  * dX bf16 [M,K] = dY bf16 [M,N] @ W bf16 [N,K]; if relu_y (bf16 [M,K]) is given, dX is zeroed where

@@ -52,6 +52,9 @@ SIGNATURES = {
     "mgx_scatter_add_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_linear_ln_fwd": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_decode_embed_linear": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_decode_embed_linear_frag": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_skinny_fwd_frag": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mgx_linear_ln_fwd_frag": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_decode_splits": [_i, _i, _i],
     "mgx_linear_dw_grouped": [_vp, _i, _i, _vp, _sz, _vp],
     "mgx_linear_dw_grouped_workspace": [_vp, _i, _i],     # returns size_t

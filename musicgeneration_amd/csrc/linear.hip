@@ -1114,6 +1114,9 @@ __global__ __launch_bounds__(256) void dw_fixup_kernel(const DwRing g, const flo
 // MFMA fragments (no LDS staging, no barriers in the loop); the four partial tiles are combined in LDS.
 //   D[n][m] = sum_k W[n][k] x[m][k]   (A = W rows, B = x^T)
 // =================================================================================================
+// FRAG: W is in MFMA fragment order (mgx.h: unit ((nt*K/16 + ks)*64 + lane) = W[32 nt + lane%32][16 ks + 8 (lane/32) ..+7], rows
+// padded with zeros to a multiple of 32): a wave load is 1 KB contiguous instead of 32 B of 32 different rows.
+template <bool FRAG>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                             const float* __restrict__ bias, uint16_t* __restrict__ C,
                                                             int M, int N, int K, int act) {
@@ -1124,20 +1127,22 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __re
     const int n0 = blockIdx.x * 32;
     const int kq = K >> 2;                                   // K per wave (multiple of 16)
     const int nrow = n0 + l31, mrow = l31;
-    const bool nv = nrow < N, mv = mrow < M;
-    const uint16_t* wp = W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    const bool nv = FRAG || nrow < N, mv = mrow < M;
+    const uint16_t* wp = FRAG ? W + (((size_t)blockIdx.x * (K >> 4) + (size_t)(w * kq >> 4)) * 64 + lane) * 8
+                              : W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    const int wstep = FRAG ? 512 : 16;                       // elements between consecutive k-steps
     const uint16_t* xp = A + (size_t)(mv ? mrow : 0) * K + w * kq + hh * 8;
     f32x16 acc = zero16();
-    for (int k0 = 0; k0 < kq; k0 += 64) {                    // 4 k-steps per iteration, 8 loads in flight
-        u32x4 wf[4], xf[4];
+    for (int k0 = 0; k0 < kq; k0 += 128) {                   // 8 k-steps per trip: all 16 loads of a K <= 512 projection at once
+        u32x4 wf[8], xf[8];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < 8; ++ks) {
             const bool in = k0 + 16 * ks < kq;
-            wf[ks] = (nv && in) ? *(const u32x4*)(wp + k0 + 16 * ks) : u32x4{0, 0, 0, 0};
+            wf[ks] = (nv && in) ? *(const u32x4*)(wp + (size_t)((k0 >> 4) + ks) * wstep) : u32x4{0, 0, 0, 0};
             xf[ks] = (mv && in) ? *(const u32x4*)(xp + k0 + 16 * ks) : u32x4{0, 0, 0, 0};
         }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 8; ++ks)
             acc = mfma(__builtin_bit_cast(bf16x8, wf[ks]), __builtin_bit_cast(bf16x8, xf[ks]), acc);
     }
 #pragma unroll
@@ -1168,6 +1173,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const uint16_t* __re
 // the 12 LayerNorm launches of a decode step (each ~4.6 us at the launch floor).  K <= 1024.
 // =================================================================================================
 constexpr int SKLN_MAXF = 16;                              // 16-column fragments per wave: K/4/16 <= 16
+template <bool FRAG>
 __global__ __launch_bounds__(256) void linear_skinny_ln_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ RES,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, const uint16_t* __restrict__ W,
@@ -1181,16 +1187,18 @@ __global__ __launch_bounds__(256) void linear_skinny_ln_kernel(const uint16_t* _
     const int n0 = blockIdx.x * 32;
     const int kq = K >> 2, nf = kq >> 4;                     // fragments of 16 columns per wave
     const int nrow = n0 + l31, mrow = l31;
-    const bool nv = nrow < N, mv = mrow < M;
+    const bool nv = FRAG || nrow < N, mv = mrow < M;
     const size_t xoff = (size_t)(mv ? mrow : 0) * K + w * kq + hh * 8;
     float z[SKLN_MAXF][8];
     float s1 = 0.f, s2 = 0.f;
     // the weight fragments are requested first: their latency hides under the statistics
-    const uint16_t* wp = W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    const uint16_t* wp = FRAG ? W + (((size_t)blockIdx.x * (K >> 4) + (size_t)(w * kq >> 4)) * 64 + lane) * 8
+                              : W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    const int wstep = FRAG ? 512 : 16;
     u32x4 wf[SKLN_MAXF];
 #pragma unroll
     for (int f = 0; f < SKLN_MAXF; ++f)
-        if (f < nf) wf[f] = nv ? *(const u32x4*)(wp + 16 * f) : u32x4{0, 0, 0, 0};
+        if (f < nf) wf[f] = nv ? *(const u32x4*)(wp + (size_t)f * wstep) : u32x4{0, 0, 0, 0};
 #pragma unroll
     for (int f = 0; f < SKLN_MAXF; ++f) {
         if (f < nf) {
@@ -1258,6 +1266,7 @@ __global__ __launch_bounds__(256) void linear_skinny_ln_kernel(const uint16_t* _
 // workgroup (47 us against 9.4 + 5.2: 16 workgroups each stream all of W1 behind a 32-row operand with ~8 KB in flight per
 // wave -- the chain is bound by dependent L2 round trips, and recomputation multiplies them).
 // =================================================================================================
+template <bool FRAG>
 __global__ __launch_bounds__(256) void linear_skinny_embed_kernel(const int32_t* __restrict__ tok, const float* __restrict__ table,
                                                                   const float* __restrict__ pe, const int32_t* __restrict__ pos_dev,
                                                                   const uint16_t* __restrict__ W, const float* __restrict__ bias,
@@ -1270,16 +1279,18 @@ __global__ __launch_bounds__(256) void linear_skinny_embed_kernel(const int32_t*
     const int n0 = blockIdx.x * 32;
     const int kq = K >> 2;
     const int nrow = n0 + l31, mrow = l31;
-    const bool nv = nrow < N, mv = mrow < M;
+    const bool nv = FRAG || nrow < N, mv = mrow < M;
     int t = tok[mv ? mrow : 0];
     t = t < 0 ? 0 : (t >= V ? V - 1 : t);
     const int pos = pos_dev[0];
     const float* tp = table + (size_t)t * K + w * kq + hh * 8;
     const float* pp = pe + (size_t)pos * K + w * kq + hh * 8;
-    const uint16_t* wp = W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    const uint16_t* wp = FRAG ? W + (((size_t)blockIdx.x * (K >> 4) + (size_t)(w * kq >> 4)) * 64 + lane) * 8
+                              : W + (size_t)(nv ? nrow : 0) * K + w * kq + hh * 8;
+    const int wstep = FRAG ? 32 : 1;                         // elements per unit of k
     f32x16 acc = zero16();
     for (int k0 = 0; k0 < kq; k0 += 16) {
-        const u32x4 wf = nv ? *(const u32x4*)(wp + k0) : u32x4{0, 0, 0, 0};
+        const u32x4 wf = nv ? *(const u32x4*)(wp + (size_t)k0 * wstep) : u32x4{0, 0, 0, 0};
         const f32x4 a0 = *(const f32x4*)(tp + k0), a1 = *(const f32x4*)(tp + k0 + 4);
         const f32x4 p0 = *(const f32x4*)(pp + k0), p1 = *(const f32x4*)(pp + k0 + 4);
         const float f[8] = {a0.x * scale + p0.x, a0.y * scale + p0.y, a0.z * scale + p0.z, a0.w * scale + p0.w,
@@ -1345,7 +1356,7 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
     MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_fwd: act must be 0 (none) or 1 (ReLU)");
     set_attrs();
     if (M <= 32) {      // decode-size batches: weight-streaming skinny kernel
-        hipLaunchKernelGGL(linear_skinny_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, W, bias, C, M, N,
+        hipLaunchKernelGGL(linear_skinny_kernel<false>, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, W, bias, C, M, N,
                            K, act);
         MGX_CHECK_LAUNCH("mgx_linear_fwd");
         return MGX_OK;
@@ -1516,9 +1527,34 @@ extern "C" int mgx_linear_ln_fwd(const uint16_t* X, const uint16_t* RES, const f
     MGX_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 64 == 0 && K <= 64 * SKLN_MAXF, MGX_ERR_SHAPE,
                 "mgx_linear_ln_fwd: need 0<M<=32, K%%64==0, K<=%d (got M=%d N=%d K=%d)", 64 * SKLN_MAXF, M, N, K);
     MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_ln_fwd: act must be 0 (none) or 1 (ReLU)");
-    hipLaunchKernelGGL(linear_skinny_ln_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, X, RES, gamma, beta, eps, W,
+    hipLaunchKernelGGL(linear_skinny_ln_kernel<false>, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, X, RES, gamma, beta, eps, W,
                        bias, C, Z, M, N, K, act);
     MGX_CHECK_LAUNCH("mgx_linear_ln_fwd");
+    return MGX_OK;
+}
+
+// ---- decode-size projections with the weight in MFMA fragment order (mgx.h; rows zero-padded to a multiple of 32) --------------
+extern "C" int mgx_skinny_fwd_frag(const uint16_t* A, const uint16_t* Wf, const float* bias, uint16_t* C, int M, int N, int K,
+                                   int act, void* stream) {
+    MGX_REQUIRE(A && Wf && C, MGX_ERR_NULL, "mgx_skinny_fwd_frag: NULL pointer");
+    MGX_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 64 == 0, MGX_ERR_SHAPE,
+                "mgx_skinny_fwd_frag: need 0<M<=32, K%%64==0 (got M=%d N=%d K=%d)", M, N, K);
+    MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_skinny_fwd_frag: act must be 0 (none) or 1 (ReLU)");
+    hipLaunchKernelGGL(linear_skinny_kernel<true>, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, A, Wf, bias, C, M, N, K, act);
+    MGX_CHECK_LAUNCH("mgx_skinny_fwd_frag");
+    return MGX_OK;
+}
+
+extern "C" int mgx_linear_ln_fwd_frag(const uint16_t* X, const uint16_t* RES, const float* gamma, const float* beta, float eps,
+                                      const uint16_t* Wf, const float* bias, uint16_t* C, uint16_t* Z, int M, int N, int K, int act,
+                                      void* stream) {
+    MGX_REQUIRE(X && RES && gamma && beta && Wf && C && Z, MGX_ERR_NULL, "mgx_linear_ln_fwd_frag: NULL pointer");
+    MGX_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 64 == 0 && K <= 64 * SKLN_MAXF, MGX_ERR_SHAPE,
+                "mgx_linear_ln_fwd_frag: need 0<M<=32, K%%64==0, K<=%d (got M=%d N=%d K=%d)", 64 * SKLN_MAXF, M, N, K);
+    MGX_REQUIRE(act == 0 || act == 1, MGX_ERR_SHAPE, "mgx_linear_ln_fwd_frag: act must be 0 (none) or 1 (ReLU)");
+    hipLaunchKernelGGL(linear_skinny_ln_kernel<true>, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, X, RES, gamma, beta, eps,
+                       Wf, bias, C, Z, M, N, K, act);
+    MGX_CHECK_LAUNCH("mgx_linear_ln_fwd_frag");
     return MGX_OK;
 }
 
@@ -1529,8 +1565,20 @@ extern "C" int mgx_decode_embed_linear(const int32_t* tok, const float* table, c
     MGX_REQUIRE(tok && table && pe && pos_dev && W && C && H, MGX_ERR_NULL, "mgx_decode_embed_linear: NULL pointer");
     MGX_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 64 == 0 && V > 0, MGX_ERR_SHAPE,
                 "mgx_decode_embed_linear: need 0<M<=32, K%%64==0 (got M=%d N=%d K=%d)", M, N, K);
-    hipLaunchKernelGGL(linear_skinny_embed_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, tok, table, pe, pos_dev,
+    hipLaunchKernelGGL(linear_skinny_embed_kernel<false>, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, tok, table, pe, pos_dev,
                        W, bias, C, H, M, N, K, V, sqrtf((float)K));
     MGX_CHECK_LAUNCH("mgx_decode_embed_linear");
+    return MGX_OK;
+}
+
+extern "C" int mgx_decode_embed_linear_frag(const int32_t* tok, const float* table, const float* pe, const int32_t* pos_dev,
+                                            const uint16_t* Wf, const float* bias, uint16_t* C, uint16_t* H, int M, int N, int K,
+                                            int V, void* stream) {
+    MGX_REQUIRE(tok && table && pe && pos_dev && Wf && C && H, MGX_ERR_NULL, "mgx_decode_embed_linear_frag: NULL pointer");
+    MGX_REQUIRE(M > 0 && M <= 32 && N > 0 && K > 0 && K % 64 == 0 && V > 0, MGX_ERR_SHAPE,
+                "mgx_decode_embed_linear_frag: need 0<M<=32, K%%64==0 (got M=%d N=%d K=%d)", M, N, K);
+    hipLaunchKernelGGL(linear_skinny_embed_kernel<true>, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)stream, tok, table, pe,
+                       pos_dev, Wf, bias, C, H, M, N, K, V, sqrtf((float)K));
+    MGX_CHECK_LAUNCH("mgx_decode_embed_linear_frag");
     return MGX_OK;
 }

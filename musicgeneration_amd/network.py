@@ -264,26 +264,35 @@ class MusicTransformer(torch.nn.Module):
         # decode-size batches: every LayerNorm rides in the projection that consumes it (mgx_linear_ln_fwd) and the embedding in
         # the first QKV projection (mgx_decode_embed_linear): 39 launches per token instead of 46
         fuse_ln = B <= 32 and d <= 1024
+        if fuse_ln:
+            # ... and every projection weight is re-laid out once per call in MFMA fragment order (ops.FragWeight): a wave load of
+            # weights is then 1 KB contiguous instead of 32 B of 32 different rows
+            # (the batched prefill below keeps using the row-major matrices)
+            for ly in layers:
+                for k in ("wqkv", "wfc", "w1", "w2"):
+                    ly[k + "_f"] = ops.FragWeight(ly[k])
+            wv_f = ops.FragWeight(wv)
 
         def step(sample_into_out: bool):
             if fuse_ln:
-                qkv, h = ops.decode_embed_linear(tok, Pm["Decoder.embedding.weight"].data, pe, pos, layers[0]["wqkv"],
+                qkv, h = ops.decode_embed_linear(tok, Pm["Decoder.embedding.weight"].data, pe, pos, layers[0]["wqkv_f"],
                                                  layers[0]["bqkv"], hbuf)
             else:
                 h = ops.decode_embed(tok, Pm["Decoder.embedding.weight"].data, pe, pos, hbuf)
                 qkv = ops.linear_fwd(h, layers[0]["wqkv"], layers[0]["bqkv"], 0)
             for i, ly in enumerate(layers):
                 ops.rel_attn_decode(qkv, kc[i], vc[i], ly["E"], pos, ctxbuf, attn_ws)
-                a = ops.linear_fwd(ctxbuf, ly["wfc"], ly["bfc"], 0)
                 nxt = layers[i + 1] if i + 1 < nl else None
                 if fuse_ln:
-                    f, o1 = ops.linear_ln_fwd(a, h, ly["g1"], ly["b1"], ly["w1"], ly["bb1"], 1)
-                    f = ops.linear_fwd(f, ly["w2"], ly["bb2"], 0)
+                    a = ops.linear_fwd(ctxbuf, ly["wfc_f"], ly["bfc"], 0)
+                    f, o1 = ops.linear_ln_fwd(a, h, ly["g1"], ly["b1"], ly["w1_f"], ly["bb1"], 1)
+                    f = ops.linear_fwd(f, ly["w2_f"], ly["bb2"], 0)
                     if nxt is not None:
-                        qkv, h = ops.linear_ln_fwd(f, o1, ly["g2"], ly["b2"], nxt["wqkv"], nxt["bqkv"], 0)
+                        qkv, h = ops.linear_ln_fwd(f, o1, ly["g2"], ly["b2"], nxt["wqkv_f"], nxt["bqkv"], 0)
                     else:
-                        logits, h = ops.linear_ln_fwd(f, o1, ly["g2"], ly["b2"], wv, bv, 0)
+                        logits, h = ops.linear_ln_fwd(f, o1, ly["g2"], ly["b2"], wv_f, bv, 0)
                 else:
+                    a = ops.linear_fwd(ctxbuf, ly["wfc"], ly["bfc"], 0)
                     o1 = ops.add_ln_fwd(a, h, ly["g1"], ly["b1"], 1e-6)[0]
                     f = ops.linear_fwd(o1, ly["w1"], ly["bb1"], 1)
                     f = ops.linear_fwd(f, ly["w2"], ly["bb2"], 0)

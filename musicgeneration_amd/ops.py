@@ -197,13 +197,30 @@ def cast_bf16(p, shadow):
     check(_lib.load().mgx_cast_bf16(ptr(p), ptr(shadow), p.numel(), stream_ptr()), "mgx_cast_bf16")
 
 
+class FragWeight:
+    """a projection weight [N,K] kept in MFMA fragment order (pack_frag; rows zero-padded to a multiple of 32) for the
+    decode-size (<= 32 rows) projections: linear_fwd / linear_ln_fwd / decode_embed_linear take it in place of the matrix"""
+
+    def __init__(self, w: torch.Tensor):
+        N, K = w.shape
+        Np = (N + 31) // 32 * 32
+        wp = torch.zeros(Np, K, dtype=BF16, device=w.device)
+        wp[:N] = w
+        self.data, self.shape = pack_frag(wp), (N, K)
+
+
 def linear_fwd(a, w, bias, act=0):
-    """a bf16 [M,K], w bf16 [N,K], bias f32 [N] or None -> bf16 [M,N] = act(a @ w.T + bias)"""
-    _need_cuda(a, w, bias)
+    """a bf16 [M,K], w bf16 [N,K] (or a FragWeight, rows <= 32), bias f32 [N] or None -> bf16 [M,N] = act(a @ w.T + bias)"""
     K = a.shape[-1]
     Mrows = a.numel() // K
     N = w.shape[0]
     out = torch.empty(*a.shape[:-1], N, dtype=BF16, device=a.device)
+    if isinstance(w, FragWeight):
+        _need_cuda(a, w.data, bias)
+        check(_lib.load().mgx_skinny_fwd_frag(ptr(a), ptr(w.data), ptr(bias), ptr(out), Mrows, N, K, int(act), stream_ptr()),
+              "mgx_skinny_fwd_frag")
+        return out
+    _need_cuda(a, w, bias)
     check(_lib.load().mgx_linear_fwd(ptr(a), ptr(w), ptr(bias), ptr(out), Mrows, N, K, int(act), stream_ptr()),
           "mgx_linear_fwd")
     return out
@@ -211,11 +228,16 @@ def linear_fwd(a, w, bias, act=0):
 
 def linear_ln_fwd(x, res, gamma, beta, w, bias, act=0, eps=1e-6):
     """decode-size rows (<= 32): z = LayerNorm(x + res), c = act(z @ w^T + bias) in one launch -> (c, z)"""
-    _need_cuda(x, res, gamma, beta, w, bias)
     N, K = w.shape
     Mrows = x.numel() // K
     c = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
     z = torch.empty_like(x)
+    if isinstance(w, FragWeight):
+        _need_cuda(x, res, gamma, beta, w.data, bias)
+        check(_lib.load().mgx_linear_ln_fwd_frag(ptr(x), ptr(res), ptr(gamma), ptr(beta), float(eps), ptr(w.data), ptr(bias), ptr(c),
+                                                 ptr(z), Mrows, N, K, int(act), stream_ptr()), "mgx_linear_ln_fwd_frag")
+        return c, z
+    _need_cuda(x, res, gamma, beta, w, bias)
     check(_lib.load().mgx_linear_ln_fwd(ptr(x), ptr(res), ptr(gamma), ptr(beta), float(eps), ptr(w), ptr(bias), ptr(c), ptr(z),
                                         Mrows, N, K, int(act), stream_ptr()), "mgx_linear_ln_fwd")
     return c, z
@@ -359,10 +381,15 @@ def decode_embed(tok, table, pe, pos_dev, out):
 
 def decode_embed_linear(tok, table, pe, pos_dev, w, bias, hout):
     """h = table[tok]*sqrt(d) + pe[t] (written to ``hout`` bf16 [B,d]) and c bf16 [B,N] = h w^T + bias in one launch"""
-    _need_cuda(tok, table, pe, pos_dev, w, bias, hout)
     V, d = table.shape
     N = w.shape[0]
-    c = torch.empty(tok.numel(), N, dtype=torch.bfloat16, device=w.device)
+    c = torch.empty(tok.numel(), N, dtype=torch.bfloat16, device=hout.device)
+    if isinstance(w, FragWeight):
+        _need_cuda(tok, table, pe, pos_dev, w.data, bias, hout)
+        check(_lib.load().mgx_decode_embed_linear_frag(ptr(tok), ptr(table), ptr(pe), ptr(pos_dev), ptr(w.data), ptr(bias), ptr(c),
+                                                       ptr(hout), tok.numel(), N, d, V, stream_ptr()), "mgx_decode_embed_linear_frag")
+        return c, hout
+    _need_cuda(tok, table, pe, pos_dev, w, bias, hout)
     check(_lib.load().mgx_decode_embed_linear(ptr(tok), ptr(table), ptr(pe), ptr(pos_dev), ptr(w), ptr(bias), ptr(c), ptr(hout),
                                               tok.numel(), N, d, V, stream_ptr()), "mgx_decode_embed_linear")
     return c, hout
