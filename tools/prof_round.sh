@@ -14,9 +14,9 @@ cut -c1-400 $OUT/${TAG}_bench_line.json
 echo "== kernel trace of the step"
 rm -rf /tmp/kt && (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-decode > /tmp/kt.log 2>&1) || { tail -5 /tmp/kt.log; exit 1; }
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_cfg2_b32_kernel_stats.csv
-python3 tools/stats_summary.py $OUT/${TAG}_bench_cfg2_b32_kernel_stats.csv 7 | head -14
-echo "== PMC utilisation of the attention kernels"; bash tools/pmc_attn.sh 32 $OUT/${TAG}_pmc_attn_b32.json | tail -8 || exit 1
-echo "== PMC traffic"; bash tools/traffic.sh $OUT/${TAG}_traffic_cfg2_b32.json | head -12 || exit 1
+python3 tools/stats_summary.py $OUT/${TAG}_bench_cfg2_b32_kernel_stats.csv 7 > /tmp/kt_summary.txt; head -14 /tmp/kt_summary.txt
+echo "== PMC utilisation of the attention kernels"; bash tools/pmc_attn.sh 32 $OUT/${TAG}_pmc_attn_b32.json > /tmp/pmc_attn.txt || { tail -5 /tmp/pmc_attn.txt; exit 1; }; tail -8 /tmp/pmc_attn.txt
+echo "== PMC traffic"; bash tools/traffic.sh $OUT/${TAG}_traffic_cfg2_b32.json > /tmp/traffic.txt || { tail -5 /tmp/traffic.txt; exit 1; }; head -12 /tmp/traffic.txt
 echo "== attention variants A/B"; timeout -k 10 300 python3 tools/attn_bench.py --B 32 --parts 125 --reps 10 --rounds 2 2>&1 | grep -v amdgpu.ids | tee $OUT/${TAG}_attn_variants.txt
 for v in 81000 160000; do echo "MGX_FWD_LDS=$v"; MGX_FWD_LDS=$v timeout -k 10 300 python3 tools/attn_bench.py --B 32 --parts 1 --reps 10 --rounds 2 2>&1 | grep fwd32; done | tee -a $OUT/${TAG}_attn_variants.txt
 if [ -f musicgeneration_amd/libmgx_stamp.so ]; then
