@@ -24,6 +24,7 @@ SIGNATURES = {
     "mgx_pad_bitmap": [_vp, _vp, _i, _i, _i, _vp],
     "mgx_rel_attn_fwd_workspace": [_i],                  # returns size_t
     "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
+    "mgx_rel_attn_fwd_nomask": [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_bwd_workspace": [_i, _i, _i],          # returns size_t
     "mgx_rel_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],

@@ -50,11 +50,15 @@ constexpr float L_SAFE = 1.0e24f;       // a lane's partial sum of one tile abov
 // WRITE_W = false: the training/inference forward (ctx + lse).
 // WRITE_W = true : debug/eval output of the reference (layers.py:102,109): the same sweep recomputes S and
 //                  writes weights[b,h,i,j] = exp(S - lse_i) (fp32, caller pre-zeroes the future triangle).
-template <bool WRITE_W>
+// CAUSAL = false: the reference's generate() call, Decoder(x, mask=None) (network.py:60-62): every query attends to EVERY key
+//                  j < Lk (no look-ahead, no padding mask) while the relative term stays what _qe_masking + _skewing leave
+//                  of it -- q_i.E[M-1-(i-j)] for j <= i, zero for j > i (layers.py:111-133).  Inference only; all tiles run
+//                  the general body.
+template <bool WRITE_W, bool CAUSAL = true>
 __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ Ef /* fragment-ordered Er, see er_frag_kernel */,
     const uint32_t* __restrict__ padbits, uint16_t* __restrict__ ctx, float* __restrict__ lse_out,
-    const float* __restrict__ lse_in, float* __restrict__ weights, int L, int d, int bgroup) {
+    const float* __restrict__ lse_in, float* __restrict__ weights, int L, int d, int bgroup, int Lk = 0) {
     extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band stores XOR bit 7 of absolute LDS addresses
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     // a wave beyond the end of the sequence (L % 128 != 0) shadows the last valid 32-row block and stores nothing
     const int q0 = wave_on ? Q0 + w : nchunk - 1;        // the wave's diagonal tile / first "hi" chunk
     const int i0 = q0 * 32;
-    const int ntw = min(Q0 + 4, nchunk);                 // key tiles this workgroup visits
+    const int ntw = CAUSAL ? min(Q0 + 4, nchunk) : (Lk + 31) >> 5;      // key tiles this workgroup visits
     const size_t ld = (size_t)3 * d;                     // qkv row stride (elements)
     const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
 
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const int am = a - 4 * hh;                           // key crow(r,hh) is in the future of query a  <=>  crow(r,0) > am
 
     // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: ONE branch-free body -------------
-    const int nmain = (WRITE_W || anypad) ? 0 : Q0;       // Q0 <= ntw - 1: a next tile always exists inside this loop
+    const int nmain = (WRITE_W || anypad || !CAUSAL) ? 0 : Q0;       // Q0 <= ntw - 1: a next tile always exists inside this loop
     size_t koff = (ntw > 1) ? tile_stride : 0;            // element offset of the tile to prefetch
     int s = 0;
     for (; s < nmain; ++s) {
@@ -252,9 +256,9 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
         const u32x4 kreg = *(const u32x4*)(kg + koff);
         const u32x4 vreg = *(const u32x4*)(vg + koff);
         koff += (s + 2 < ntw) ? tile_stride : 0;
-        const int dq = q0 - s;                            // wave active iff dq >= 0
-        if (dq >= 0) {
-            const uint32_t pw = padword(s);
+        const int dq = q0 - s;                            // causal: wave active iff dq >= 0
+        if (!CAUSAL || dq >= 0) {
+            const uint32_t pw = CAUSAL ? padword(s) : 0u;
             if (dq >= 1) {
                 f32x16 qe = zero16();
 #pragma unroll
@@ -262,16 +266,24 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
                 band_put(qe, dq - 1);
             }
             wave_lds_fence();
-            f32x16 c = band_get(dq);
+            f32x16 c = (CAUSAL || dq >= 0) ? band_get(dq) : zero16();        // tiles beyond the diagonal have no relative term
             wave_lds_fence();
+            if (!CAUSAL && dq == 0) {                     // ... and on the diagonal tile only the keys b <= a have one
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (crow(r, 0) > am) ? 0.f : c[r];
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) e[ks] = ef(dq - 2, ks);
             const char* kt = smem + OFF_K + cur * TILE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
-            if (dq == 0) {                                // diagonal tile: key b > query a is the future
+            if (CAUSAL && dq == 0) {                      // diagonal tile: key b > query a is the future
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c[r] = (crow(r, 0) > am) ? -INFINITY : c[r];
+            }
+            if (!CAUSAL && 32 * s + 32 > Lk) {            // last tile of a window that is not a multiple of 32: keys >= Lk do not exist
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = (32 * s + crow(r, hh) >= Lk) ? -INFINITY : c[r];
             }
             if (pw) {                                     // padded key: the reference's additive -1e9 (future keys stay -inf)
                 const uint32_t pwl = pw >> (4 * hh);
@@ -318,6 +330,7 @@ static void set_fwd_attrs() {
     static const bool once = [] {
         hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return true;
     }();
     (void)once;
@@ -381,5 +394,22 @@ extern "C" int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, cons
     hipLaunchKernelGGL(rel_attn_fwd_kernel<true>, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
                        (const u32x4*)workspace, padbits, (uint16_t*)nullptr, (float*)nullptr, lse, weights, L, d, B);
     MGX_CHECK_LAUNCH("mgx_rel_attn_weights");
+    return MGX_OK;
+}
+
+// The reference's sampling call Decoder(x, mask=None) (network.py:60-62): bidirectional over the Lk <= L real positions of
+// the window (rows / keys Lk..L-1 are padding up to the kernels' multiple of 32: never attended to, their own outputs are
+// don't-cares), relative term for j <= i only.  Inference only (no lse / backward contract beyond the forward's).
+extern "C" int mgx_rel_attn_fwd_nomask(const uint16_t* qkv, const uint16_t* E, uint16_t* ctx, float* lse, void* workspace,
+                                       size_t ws_bytes, int B, int L, int Lk, int d, int M, void* stream) {
+    MGX_REQUIRE(qkv && E && ctx && lse, MGX_ERR_NULL, "mgx_rel_attn_fwd_nomask: NULL pointer");
+    if (int rc = fwd_common_checks("mgx_rel_attn_fwd_nomask", workspace, ws_bytes, B, L, d, M)) return rc;
+    MGX_REQUIRE(Lk > 0 && Lk <= L, MGX_ERR_SHAPE, "mgx_rel_attn_fwd_nomask: need 0 < Lk <= L (got Lk=%d L=%d)", Lk, L);
+    set_fwd_attrs();
+    launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
+    dim3 grid(B * (d / 64), (L + 127) / 128);
+    hipLaunchKernelGGL((rel_attn_fwd_kernel<false, false>), grid, dim3(256), LDS_BYTES, (hipStream_t)stream, qkv,
+                       (const u32x4*)workspace, (const uint32_t*)nullptr, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d, B, Lk);
+    MGX_CHECK_LAUNCH("mgx_rel_attn_fwd_nomask");
     return MGX_OK;
 }

@@ -33,6 +33,9 @@ def get_options(argv=None):
     parser.add_option('--repr', dest='repr', type='string', default='midi_like')
     parser.add_option('--grammar', dest='grammar', action='store_true', default=False,
                       help='constrain sampling to the REMI / MuMIDI event grammar (KV-cache decode, mask inside the sampler)')
+    parser.add_option('--reference-mask', dest='reference_mask', action='store_true', default=False,
+                      help="sample exactly as the reference's generate() does: Decoder(window, mask=None), i.e. no look-ahead "
+                           'mask at sampling time (network.py:60); default: the training-time causal semantics')
     parser.add_option('-M', '--max_seq', dest='max_seq', type='int', default=config.max_seq)
     parser.add_option('-c', '--condition-file', dest='condition_file', type='string', default=getattr(config, 'condition_file', None),
                       help='MIDI file to continue (the reference reads config.condition_file, generate.py:101-105): its '
@@ -83,7 +86,8 @@ def main(argv=None):
         res = mt.generate_cached(prior, o.max_len, temperature=o.temperature, top_k=o.top_k, top_p=o.top_p,
                                  grammar=Codec.next_token_table()).cpu().numpy()
     else:
-        res = mt.generate(prior, o.max_len, temperature=o.temperature, top_k=o.top_k, top_p=o.top_p).cpu().numpy()
+        res = mt.generate(prior, o.max_len, temperature=o.temperature, top_k=o.top_k, top_p=o.top_p,
+                          reference_mask=o.reference_mask).cpu().numpy()
     os.makedirs(o.output_dir, exist_ok=True)
     for i, seq in enumerate(res):
         name = os.path.join(o.output_dir, f'gen-{i:03d}')

@@ -81,11 +81,12 @@ def _pad_bitmap_from_flags(padded: torch.Tensor) -> torch.Tensor:
 
 
 def _need_mask(mask):
-    if mask is None:
+    """mask=None is the reference's sampling call (network.py:60-62): bidirectional attention, relative term for j <= i only.
+    The kernels run it (mgx_rel_attn_fwd_nomask) for inference; there is no backward for it."""
+    if mask is None and torch.is_grad_enabled():
         raise NotImplementedError(
-            "mask=None asks for bidirectional attention (what the reference's generate() does, network.py:60); the MI355X "
-            "kernels are causal -- pass the look-ahead mask.  Sampling with training-time causal semantics is "
-            "MusicTransformer.generate / generate_cached (DESIGN.md section 5).")
+            "mask=None (the bidirectional attention of the reference's generate(), network.py:60) is an inference path on the "
+            "MI355X kernels: call it under torch.no_grad(), or pass the look-ahead mask for training")
 
 
 class RelativeGlobalAttention(torch.nn.Module):
@@ -121,7 +122,7 @@ class RelativeGlobalAttention(torch.nn.Module):
         if L % 32 != 0 or L > self.max_seq:
             raise ValueError(f"sequence length {L} must be a multiple of 32 and <= max_seq={self.max_seq}")
         self.len_q = self.len_k = L
-        padbits = _pad_bitmap_from_flags(key_padding_from_mask(mask, L))
+        padbits = None if mask is None else _pad_bitmap_from_flags(key_padding_from_mask(mask, L))
         bf = torch.bfloat16
         if q is k and k is v:
             x16 = q.to(bf).contiguous()
@@ -130,6 +131,9 @@ class RelativeGlobalAttention(torch.nn.Module):
         else:
             qkv = torch.cat([ops.linear_std(t.to(bf).contiguous(), lin.weight, lin.bias)
                              for t, lin in ((q, self.Wq), (k, self.Wk), (v, self.Wv))], -1)
+        if mask is None:                                          # the reference's sampling call: no look-ahead, no padding mask
+            att = ops.rel_attn_fwd_nomask(qkv, self.E.detach().to(bf).contiguous())
+            return ops.linear_std(att, self.fc.weight, self.fc.bias).to(q.dtype), None
         att, lse = ops.rel_attn_std(qkv, self.E, padbits)          # E is cut to its last L rows inside (M >= L)
         out = ops.linear_std(att, self.fc.weight, self.fc.bias)
         weights = None

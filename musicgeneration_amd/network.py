@@ -162,11 +162,39 @@ class MusicTransformer(torch.nn.Module):
     # sampling                                                                   network.py:44-80
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def next_token_probs(self, window: torch.Tensor) -> torch.Tensor:
-        """softmax of the logits that follow the last token of ``window`` [B,W] (causal semantics:
-        the training-time mask, see DESIGN.md 'decode semantics').  The window is right-padded to a
-        multiple of 32 with pad tokens, which lie in the masked future of every real position."""
+    def _logits_nomask(self, window: torch.Tensor) -> torch.Tensor:
+        """logits [B,W,V] of ``Decoder(window, mask=None)`` + fc -- the reference's sampling call (network.py:60-63): every
+        position attends to every position of the window, the relative term only reaches back (j <= i).  The window is
+        right-padded to the kernels' multiple of 32; the padding rows are excluded as keys (Lk = W) and dropped as queries."""
+        st = self.store()
+        st.sync_shadow()
         B, W = window.shape
+        Lp = (W + 31) // 32 * 32
+        if Lp > self.max_seq:
+            raise ValueError(f"window {W} pads to {Lp} > max_seq={self.max_seq}")
+        dev, d, Pm = st.param.device, self.embedding_dim, st.params
+        seq = torch.zeros(B, Lp, dtype=torch.int32, device=dev)
+        seq[:, :W] = window.to(torch.int32)
+        hh = ops.embed_pe_fwd(seq, Pm["Decoder.embedding.weight"].data, self.Decoder.pos_encoding.table())
+        for lp in self._layer_params():
+            qkv = ops.linear_fwd(hh, lp.wqkv, lp.bqkv, 0)
+            att = ops.rel_attn_fwd_nomask(qkv, lp.E, W)
+            o1 = ops.add_ln_fwd(ops.linear_fwd(att, lp.wfc, lp.bfc, 0), hh, lp.g1, lp.b1, 1e-6)[0]
+            f = ops.linear_fwd(ops.linear_fwd(o1, lp.wpre, lp.bpre, 1), lp.wsuf, lp.bsuf, 0)
+            hh = ops.add_ln_fwd(f, o1, lp.g2, lp.b2, 1e-6)[0]
+        Vp = self.vocab_padded
+        logits = ops.linear_fwd(hh, st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param"), 0)
+        return logits[:, :W, : self.vocab_size]
+
+    @torch.no_grad()
+    def next_token_probs(self, window: torch.Tensor, reference_mask: bool = False) -> torch.Tensor:
+        """softmax of the logits that follow the last token of ``window`` [B,W].  Default: causal semantics (the
+        training-time mask, see DESIGN.md 'decode semantics'); the window is right-padded to a multiple of 32 with pad
+        tokens, which lie in the masked future of every real position.  ``reference_mask=True``: the reference's own
+        sampling call, ``Decoder(window, mask=None)`` (network.py:60-62)."""
+        B, W = window.shape
+        if reference_mask:
+            return torch.softmax(self._logits_nomask(window)[:, W - 1].float(), -1)
         Lp = (W + 31) // 32 * 32
         if Lp != W:
             padcol = torch.full((B, Lp - W), self.pad_token, dtype=window.dtype, device=window.device)
@@ -179,16 +207,18 @@ class MusicTransformer(torch.nn.Module):
 
     @torch.no_grad()
     def generate(self, prior: torch.Tensor, length=2048, tf_board_writer=None, temperature: float = 1.0,
-                 top_k: int = 0, top_p: float = 1.0):
+                 top_k: int = 0, top_p: float = 1.0, reference_mask: bool = False):
         """Autoregressive sampling with the reference's sliding window (config.threshold_len) and
         full-softmax categorical sampling by default (top_k=0, top_p=1.0 == the reference's
-        OneHotCategorical, network.py:73-74); top-k / top-p / temperature are opt-in extras."""
+        OneHotCategorical, network.py:73-74); top-k / top-p / temperature are opt-in extras.
+        ``reference_mask=True`` reproduces the reference's step exactly -- ``Decoder(decode_array, None)``, i.e. NO look-ahead
+        mask at sampling time (network.py:60) -- instead of the training-time causal semantics."""
         decode_array = prior
         result_array = prior
         for _ in range(length):
             if decode_array.size(1) >= config.threshold_len:
                 decode_array = decode_array[:, 1:]
-            probs = self.next_token_probs(decode_array)
+            probs = self.next_token_probs(decode_array, reference_mask)
             probs = filter_probs(probs, temperature, top_k, top_p)
             nxt = torch.multinomial(probs, 1).to(decode_array.dtype)
             decode_array = torch.cat((decode_array, nxt), dim=-1)

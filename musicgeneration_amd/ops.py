@@ -72,6 +72,21 @@ def rel_attn_fwd(qkv, E, padbits, M=None) -> Tuple[torch.Tensor, torch.Tensor]:
     return ctx, lse
 
 
+def rel_attn_fwd_nomask(qkv, E, Lk=None) -> torch.Tensor:
+    """the reference's sampling call (mask=None): bidirectional attention over keys 0..Lk-1, relative term for j <= i only
+    (mgx.h).  qkv bf16 [B,L,3d] -> ctx bf16 [B,L,d]; rows >= Lk are don't-cares.  Inference only."""
+    _need_cuda(qkv, E)
+    B, L, d3 = qkv.shape
+    d = d3 // 3
+    ctx = torch.empty(B, L, d, dtype=BF16, device=qkv.device)
+    lse = torch.empty(B, d // 64, L, dtype=torch.float32, device=qkv.device)
+    lib = _lib.load()
+    ws = torch.empty(lib.mgx_rel_attn_fwd_workspace(L), dtype=torch.uint8, device=qkv.device)
+    check(lib.mgx_rel_attn_fwd_nomask(ptr(qkv), ptr(E), ptr(ctx), ptr(lse), ptr(ws), ws.numel(), B, L, L if Lk is None else int(Lk), d,
+                                      E.shape[0], stream_ptr()), "mgx_rel_attn_fwd_nomask")
+    return ctx
+
+
 def rel_attn_weights(qkv, E, padbits, lse) -> torch.Tensor:
     """materialised attention weights f32 [B,h,L,L] (eval/debug output of the reference)"""
     _need_cuda(qkv, E, padbits, lse)

@@ -70,6 +70,30 @@ def test_rel_attn_fwd_matches_oracle(B, L, d, M, padcase):
     assert (lse - ref_lse).abs().max().item() < 2e-3 * max(1.0, ref_lse.abs().max().item())
 
 
+@pytest.mark.parametrize("B,L,Lk,d,M", [(2, 32, 32, 64, 32), (1, 160, 160, 128, 192), (2, 64, 37, 64, 64), (1, 288, 261, 64, 288),
+                                        (3, 128, 97, 192, 128)])
+def test_rel_attn_fwd_nomask_matches_oracle(B, L, Lk, d, M):
+    """mgx_rel_attn_fwd_nomask = the reference's attention with mask=None (its sampling call): bidirectional over the Lk real
+    positions, relative term q_i.E[M-1-(i-j)] for j <= i and 0 for j > i; rows >= Lk are padding (ignored)."""
+    from musicgeneration_amd import ops
+    from oracle import ref_cpu as R
+    dev = _dev()
+    g = torch.Generator().manual_seed(77 + L + Lk)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.8).to(torch.bfloat16)
+    E = (torch.randn(M, 64, generator=g) * 0.5).to(torch.bfloat16)
+    # the oracle on the window of Lk positions (E is indexed from its END, so a shorter window only drops distances)
+    ref, _, _ = R.attn_core(qkv[:, :Lk].float(), E.float(), None, d // 64)
+    ctx = ops.rel_attn_fwd_nomask(qkv.to(dev), E.to(dev), Lk)
+    torch.cuda.synchronize()
+    got = ctx[:, :Lk].float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-2
+    # not the causal result
+    causal, _ = ops.rel_attn_fwd(qkv.to(dev), E.to(dev), None)
+    assert (causal[:, :Lk].float().cpu() - ref).abs().max().item() > 5e-2 * ref.abs().max().item() or Lk == 1
+
+
 def test_rel_attn_fwd_softmax_rescale_branch():
     """Force the online-softmax rescale: one late key dominates a row so the running max jumps at a
     later key tile (cdna guide rule 26: a rare data-dependent branch needs its own test)."""
