@@ -534,6 +534,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 // tiles i0 = J0, J0+32, ...  orientation: queries on registers, keys on lanes (S, P, dP, dS);
 // accumulators dK^T[c][b], dV^T[c][b].
 // ================================================================================================
+#ifndef MGX_DKV_PEEL
+#define MGX_DKV_PEEL 0      // timing experiments only (tools/peel_dkv.sh): 1 no E loads in the sweep | 2 no dS stores | 4 no band round trip
+#endif                      // | 8 no exponentials | 16 no q / dO tile prefetch+publish (the first tile is reused); results are then wrong
 namespace k2 {
 constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
@@ -686,16 +689,23 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) qe[r] = (bl <= crow(r, hh)) ? qe[r] : ql[r];
         }
+        if (!(MGX_DKV_PEEL & 4)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lds_store_f32(wr0 + crow(r, 0) * 128, qe[r]);
+            for (int r = 0; r < 16; ++r) lds_store_f32(wr0 + crow(r, 0) * 128, qe[r]);
+        }
         // the lo slot is free now: fetch the next step's hi chunk into it
+        if (!(MGX_DKV_PEEL & 1)) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
+            for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
+        }
         if (!MASKED) __builtin_amdgcn_sched_barrier(0x78F);    // VMEM may not sink below: needed at the top of the next step
         wave_lds_fence();
         f32x16 c;
+        if (MGX_DKV_PEEL & 4) c = qe;
+        else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = *(lds_f32_ptr)(uintptr_t)rd[r];
+            for (int r = 0; r < 16; ++r) c[r] = *(lds_f32_ptr)(uintptr_t)rd[r];
+        }
         wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c = mfma(qa[ks], kf[ks], c);
@@ -725,7 +735,8 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], 0.125f * LOG2E, -l4[k]));    // c = 8 S
+                const float p = (MGX_DKV_PEEL & 8) ? __builtin_fmaf(c[4 * g4 + k], 1e-9f, -l4[k])
+                                                   : __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], 0.125f * LOG2E, -l4[k]));    // c = 8 S
                 c[4 * g4 + k] = p;
                 ds[4 * g4 + k] = p * dp[4 * g4 + k];
             }
@@ -743,9 +754,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             dk1 = mfma(frag_T(qt, lane, ss, 1), df, dk1);
             dfx[ss] = __builtin_bit_cast(u32x4, df);
         }
-        // streamed (read back from HBM by two later kernels): costs this kernel ~55 us of its 600 at cfg2, 35 of them HBM
-        // write traffic (stores to an L2-resident dummy: 20) -- profiles/README.md round 3
-        if (EXPORT_DS) {
+        // streamed (read back from HBM by two later kernels): costs this kernel 55-100 us of its 600 at cfg2 (tools/peel_dkv.sh);
+        // issuing them before the dV / dK products instead of after changes nothing
+        if (EXPORT_DS && !(MGX_DKV_PEEL & 2)) {
             __builtin_nontemporal_store(dfx[0], (u32x4*)dsp);
             __builtin_nontemporal_store(dfx[1], (u32x4*)(dsp + 1024));
         }
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     u32x4 qreg, oreg;
     float streg = 0.f;
     auto prefetch = [&](int t) {      // tile t + 1, clamped
-        const int tn = min(t + 1, nT - 1);
+        const int tn = (MGX_DKV_PEEL & 16) ? 0 : min(t + 1, nT - 1);
         qreg = q_tile(tn);
         oreg = o_tile(tn);
         streg = stat_src(tn);
