@@ -58,8 +58,10 @@ def test_rccl_world_of_one_matches_no_dp(tmp_path):
     print("RCCL version", rccl["describe"]["rccl_version"])
     assert rccl["buckets"] >= 3 and rccl["bytes_reduced"] > 0 and one["bytes_reduced"] == 0
     noise = max(abs(a - b) / abs(a) for a, b in zip(one["losses"], again["losses"]))
-    tol = max(10 * noise, 2e-6)
+    # one pair of plain runs can agree by chance far better than the typical noise of the fp32 atomics (dE, dW splits): the floor
+    # is the typical level (1e-5 .. 5e-5 relative over these steps); a mis-ordered bucket moves the loss by > 1e-2
+    tol = max(10 * noise, 2e-4)
     for a, b in zip(one["losses"], rccl["losses"]):
         assert abs(a - b) <= tol * abs(a), (one["losses"], rccl["losses"], noise)
     pnoise = abs(one["param_sum"] - again["param_sum"]) / one["param_abs"]
-    assert abs(one["param_sum"] - rccl["param_sum"]) <= max(10 * pnoise, 1e-7) * one["param_abs"]
+    assert abs(one["param_sum"] - rccl["param_sum"]) <= max(10 * pnoise, 1e-5) * one["param_abs"]
