@@ -86,16 +86,22 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     // ---- staging roles: thread -> (row, 16-byte chunk) of a 32x64 tile -------------------------
     const int srow = tid >> 3, sch = tid & 7;
     const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
-    const uint16_t* kg = qkv_b + (size_t)srow * ld + d + hd * 64 + sch * 8;       // + 32*tile*ld
-    const uint16_t* vg = kg + d;
-    const size_t tile_stride = (size_t)32 * ld;
-    // every load of the sweep is unconditional with a clamped index: a load inside a branch makes the compiler drain
-    // the whole VMEM queue where the branch rejoins.  Data of clamped tiles / chunks is never used.
-    auto ef = [&](int q, int ks) { return __builtin_bit_cast(bf16x8, Ef[(size_t)(max(q, 0) * 4 + ks) * 64 + lane]); };
+    // Every global address of the sweep is (wave-uniform base in SGPRs) + (32-bit per-lane offset) + immediate, so a load costs
+    // no vector address arithmetic.  Every load is unconditional with a clamped index: a load inside a branch makes the
+    // compiler drain the whole VMEM queue where the branch rejoins.  Data of clamped tiles / chunks is never used.
+    const char* kv_base = (const char*)(qkv_b + d + hd * 64);                 // K columns of this head; V is d elements further
+    const uint32_t kv_voff = (uint32_t)((srow * ld + sch * 8) * 2);            // bytes
+    const uint32_t tile_bytes = (uint32_t)(32 * ld * 2);                       // one 32-row step of qkv
+    auto k_tile = [&](int t) { return *(const u32x4*)(kv_base + (size_t)t * tile_bytes + kv_voff); };
+    auto v_tile = [&](int t) { return *(const u32x4*)(kv_base + (size_t)t * tile_bytes + (size_t)d * 2 + kv_voff); };
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    auto ef = [&](int q, int ks) {
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)Ef + (size_t)max(q, 0) * 4096 + ks * 1024 + lane16));
+    };
 
     // ---- prologue: K/V tile 0, key-padding words ---------------------------------------------------
-    *(u32x4*)(smem + OFF_K + st_offR) = *(const u32x4*)kg;
-    *(u32x4*)(smem + OFF_V + st_offT) = *(const u32x4*)vg;
+    *(u32x4*)(smem + OFF_K + st_offR) = k_tile(0);
+    *(u32x4*)(smem + OFF_V + st_offT) = v_tile(0);
     // (no __syncthreads_or: it allocates static LDS, which moves the dynamic base off 0 and costs one v_add per band store)
     int anypad = 0;
     if (padbits) {
@@ -222,13 +228,12 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
 
     // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: ONE branch-free body -------------
     const int nmain = (WRITE_W || anypad || !CAUSAL) ? 0 : Q0;       // Q0 <= ntw - 1: a next tile always exists inside this loop
-    size_t koff = (ntw > 1) ? tile_stride : 0;            // element offset of the tile to prefetch
     int s = 0;
     for (; s < nmain; ++s) {
         const int cur = s & 1;
-        const u32x4 kreg = *(const u32x4*)(kg + koff);
-        const u32x4 vreg = *(const u32x4*)(vg + koff);
-        koff += (s + 2 < ntw) ? tile_stride : 0;
+        const int tn = min(s + 1, ntw - 1);
+        const u32x4 kreg = k_tile(tn);
+        const u32x4 vreg = v_tile(tn);
         const int dq = q0 - s;                            // >= 1
         f32x16 c = zero16();
 #pragma unroll
@@ -253,9 +258,9 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     //      weights output ------------------------------------------------------------------------------------------
     for (; s < ntw; ++s) {
         const int cur = s & 1;
-        const u32x4 kreg = *(const u32x4*)(kg + koff);
-        const u32x4 vreg = *(const u32x4*)(vg + koff);
-        koff += (s + 2 < ntw) ? tile_stride : 0;
+        const int tn = min(s + 1, ntw - 1);
+        const u32x4 kreg = k_tile(tn);
+        const u32x4 vreg = v_tile(tn);
         const int dq = q0 - s;                            // causal: wave active iff dq >= 0
         if (!CAUSAL || dq >= 0) {
             const uint32_t pw = CAUSAL ? padword(s) : 0u;
