@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 // accumulators dK^T[c][b], dV^T[c][b].
 // ================================================================================================
 #ifndef MGX_DKV_PEEL
-#define MGX_DKV_PEEL 0      // timing experiments only (tools/peel_dkv.sh): 1 no E loads in the sweep | 2 no dS stores | 4 no band round trip
+#define MGX_DKV_PEEL 0      // timing experiments only (tools/peel_dkv.sh): 1 no E loads in the sweep | 2 no dS stores | 4 no skew (bpermute)
 #endif                      // | 8 no exponentials | 16 no q / dO tile prefetch+publish (the first tile is reused); results are then wrong
 namespace k2 {
 constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
@@ -544,9 +544,10 @@ constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K  dO image R
 constexpr int OFF_OT = OFF_OR + 2 * TILE_BYTES;            // 2 x 4K  dO image T
 constexpr int ST_BYTES = 1024;                             // per buffer: lse2[32], delta[32] (+ 192 unread duplicates, see publish)
 constexpr int OFF_ST = OFF_OT + 2 * TILE_BYTES;            // 2 x 1 KB
-constexpr int OFF_BAND = OFF_ST + 2 * ST_BYTES;            // 4 x 8K fp32 [32][64]
-constexpr int OFF_FLAG = OFF_BAND + WAVES * 8192;          // "a key of this workgroup is padded" flag
-constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 66,064 B -> 2 workgroups per CU
+constexpr int PATCH_BYTES = 4608;                          // per wave: 32 rows x 144 B, the epilogue's row-major store patch
+constexpr int OFF_BAND = OFF_ST + 2 * ST_BYTES;
+constexpr int OFF_FLAG = OFF_BAND + WAVES * PATCH_BYTES;   // "a key of this workgroup is padded" flag
+constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 51,728 B (the 256 VGPRs limit the kernel to 2 workgroups per CU)
 // The Er chunks (B operand of Q.Er^T: column t = lane&31, 16 contiguous bytes of row L-1-32q-t) are
 // loaded straight from global/L2 into registers, one new chunk per step (the previous "hi" chunk is
 // the next "lo" chunk), so E needs no LDS here.
@@ -639,15 +640,11 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         }
     }
     __syncthreads();
-    const int band_base = OFF_BAND + w * 8192;
-    char* band = smem + band_base;
-    // band (plain [32 query rows][32 merged distances] fp32, 4 KB per wave; the 8 KB slot also serves as the epilogue's store
-    // patch): merged[ar][t] is written at column t (lane-linear, conflict-free); the tile reads column (ar - bl) & 31 of row
-    // ar = crow(r,hh) (a permutation of the 32 banks).  rd[r] = ABSOLUTE LDS address of that element.
+    char* band = smem + OFF_BAND + w * PATCH_BYTES;          // the epilogue's store patch
+    // rd[r] = byte address (source lane * 4) of the ds_bpermute that skews register r (see `tile`)
     uint32_t rd[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rd[r] = lds_addr_of(smem) + band_base + crow(r, hh) * 128 + (((crow(r, hh) - bl) & 31) << 2);
-    const uint32_t wr0 = lds_addr_of(smem) + band_base + hh * 512 + bl * 4;       // + crow(r,0)*128 as the immediate
+    for (int r = 0; r < 16; ++r) rd[r] = (uint32_t)((hh * 32 + ((crow(r, hh) - bl) & 31)) << 2);
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
     // Every dS tile goes to the workspace as the operand registers this wave multiplies with q (bf16, the dK
     // product's own rounding): tile (b,h, I = query tile, J = key tile <= I) is 2 KB at ((bh*T + I(I+1)/2 + J)*1024 elements,
@@ -689,24 +686,21 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) qe[r] = (bl <= crow(r, hh)) ? qe[r] : ql[r];
         }
-        if (!(MGX_DKV_PEEL & 4)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lds_store_f32(wr0 + crow(r, 0) * 128, qe[r]);
-        }
         // the lo slot is free now: fetch the next step's hi chunk into it
         if (!(MGX_DKV_PEEL & 1)) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
         }
         if (!MASKED) __builtin_amdgcn_sched_barrier(0x78F);    // VMEM may not sink below: needed at the top of the next step
-        wave_lds_fence();
+        // The skew is a LANE permutation inside each half-wave: the tile's element (row a = crow(r,hh), key bl) is the merged value
+        // merged[a][t = (a - bl) & 31], which lane t of the same half holds in the SAME register r -- one ds_bpermute_b32 per
+        // register and no LDS memory (until round 3 the merged tile went through a 4 KB band: 16 stores + 16 loads per tile).
         f32x16 c;
-        if (MGX_DKV_PEEL & 4) c = qe;
-        else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c[r] = *(lds_f32_ptr)(uintptr_t)rd[r];
+        for (int r = 0; r < 16; ++r) {
+            const float v = qe[r];            // (a __builtin_bit_cast of the vector ELEMENT expression itself reads element 0)
+            c[r] = (MGX_DKV_PEEL & 4) ? v : __int_as_float(__builtin_amdgcn_ds_bpermute((int)rd[r], __float_as_int(v)));
         }
-        wave_lds_fence();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c = mfma(qa[ks], kf[ks], c);
         if (MASKED) {

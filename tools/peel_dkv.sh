@@ -2,7 +2,7 @@
 # What a dK/dV step is made of: builds of the kernel with one part compiled out (timing only, the results are wrong).
 #   here (no GPU):  bash tools/peel_dkv.sh build      -> musicgeneration_amd/libmgx_dkvpeel<mask>.so for every mask below
 #   GPU box:        bash tools/peel_dkv.sh run [B]     -> one line per build: dkv ms (tools/attn_bench.py --parts 8)
-# masks (MGX_DKV_PEEL, rel_attn_bwd.hip): 1 no E-fragment loads in the sweep | 2 no dS stores | 4 no band round trip (LDS) |
+# masks (MGX_DKV_PEEL, rel_attn_bwd.hip): 1 no E-fragment loads in the sweep | 2 no dS stores | 4 no skew (ds_bpermute; until the bpermute version: the LDS band round trip) |
 #   8 no exponentials | 16 the q / dO tile prefetch always re-reads tile 0 (L2-resident)
 MASKS="0 1 2 4 8 16 31"
 if [ "$1" = build ]; then
