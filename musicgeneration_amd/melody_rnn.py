@@ -230,12 +230,12 @@ class Event_Melody_RNN(nn.Module):
 
     def _train_workspace(self, pk, T, B):
         """sequence buffers of Train for one (T, B) -- they cross the boundary of the captured time loops, so they must keep
-        their addresses between calls -- and the hipGraphs of those loops.  At most four shapes are kept."""
+        their addresses between calls -- and the hipGraphs of those loops.  At most eight shapes are kept."""
         import os
         cache = self._train_ws
         ws = cache.get((T, B))
         if ws is None:
-            if len(cache) >= 4:
+            if len(cache) >= 8:
                 cache.pop(next(iter(cache)))
             dev, H = pk["dev"], self.hidden_dim
             mk = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
@@ -307,7 +307,14 @@ class Event_Melody_RNN(nn.Module):
             lens = torch.as_tensor(lengths, dtype=torch.int64)
             if int(lens.max()) > ev.shape[1] or int(lens.min()) < 1:
                 raise ValueError("lengths must lie in [1, Tmax]")
-            full = self.Train(init, ev.t().contiguous())                     # [Tmax+1, B, V], padded steps included
+            # Tmax is rounded up to a multiple of 16 steps (zero events, computed and dropped): the time loops are replayed from
+            # hipGraphs keyed by (T, B), and a data set of ragged batches would otherwise capture a new graph per distinct Tmax
+            Tmax = ev.shape[1]
+            Tb = (Tmax + 15) // 16 * 16
+            evt = ev.t().contiguous()
+            if Tb != Tmax:
+                evt = torch.cat([evt, torch.zeros(Tb - Tmax, evt.shape[1], dtype=evt.dtype, device=evt.device)], 0)
+            full = self.Train(init, evt)[: Tmax + 1]                         # [Tmax+1, B, V], padded steps included
             steps = torch.arange(full.shape[0], device=full.device)[:, None]
             valid = steps <= lens.to(full.device)[None, :]                   # step 0 = primary event, steps 1..len = events
             fill = self.output_fc.bias.to(full.dtype)                        # output_fc applied to a zero (padded) GRU output
