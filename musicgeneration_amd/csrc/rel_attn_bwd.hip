@@ -1013,6 +1013,9 @@ __global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
 // 32(m+1) + i - j of a [64 rows][160 distances] image -- every write lands inside the row (no predication, no wrap);
 // positions no tile writes are zeroed once and stay zero.  Wave w (of 5) multiplies columns 32w .. 32w+31 = chunk c0-1+w.
 // ================================================================================================
+#ifndef MGX_DET_PEEL
+#define MGX_DET_PEEL 0      // timing experiments only (tools/peel_de_tiles.sh): 1 three quarters of the scatter stores | 2 no products |
+#endif                      // 4 q tile re-read from row block 0 (L2-resident); results are then wrong
 namespace k3t {
 constexpr int DIAGS = 4, RS = 64, STEPS = 32, NW = 5;
 constexpr int AROW = 352;                                  // bytes per image row: 160 bf16 + pad (4 consecutive rows -> 4 bank groups)
@@ -1076,7 +1079,7 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
             areg[k][0] = __builtin_nontemporal_load((const u32x4*)p);
             areg[k][1] = __builtin_nontemporal_load((const u32x4*)(p + 1024));
         }
-        const uint16_t* qp = qkv + ((size_t)bb * L + i0) * ld + hd * 64 + (qch & 7) * 8;
+        const uint16_t* qp = qkv + ((size_t)bb * L + ((MGX_DET_PEEL & 4) ? 0 : i0)) * ld + hd * 64 + (qch & 7) * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = (qrow & 31) + 32 * i;
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
                 for (int ss = 0; ss < 2; ++ss) {
                     const u32x4 v = a_ok[k] ? areg[k][ss] : zero;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < ((MGX_DET_PEEL & 1) ? 1 : 4); ++j) {
                         const int r0 = 8 * ss + 2 * j;
                         *(uint16_t*)(base + crow(r0, 0) * (AROW + 2)) = (uint16_t)v[j];
                         *(uint16_t*)(base + crow(r0 + 1, 0) * (AROW + 2)) = (uint16_t)(v[j] >> 16);
@@ -1114,6 +1117,7 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
     const int fa_i = lane & 15, fa_g = lane >> 4;
     const int fa_off = (fa_i >> 2) * AROW + (32 * w) * 2 + (2 * (fa_g & 1) + ((fa_i & 3) >> 1)) * 16 + 8 * (fa_i & 1) + 8 * hh * AROW;
     auto multiply = [&]() {
+        if (MGX_DET_PEEL & 2) return;
         const char* at = smem + OFF_A + fa_off;
         const char* qt = smem + OFF_Q;
 #pragma unroll
