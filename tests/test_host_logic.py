@@ -224,3 +224,22 @@ def test_check_pads_trail_accepts_tail_padding_and_refuses_leading_or_interior()
     for bad in ([[9, 1, 2, 3, 4]], [[1, 9, 2, 9, 9]]):
         with pytest.raises(ValueError, match="pads must only trail"):
             utils.check_pads_trail(np.array(bad, dtype=np.int16), pad)
+
+
+def test_pack_frag_layout_matches_the_header():
+    """ops.pack_frag (pure torch, runs without a GPU): unit ((nt*K/16 + ks)*64 + lane) of the packed buffer holds
+    W[32 nt + lane % 32][16 ks + 8 (lane // 32) .. +7] -- the layout include/mgx.h documents for the *_frag / GRU entry points."""
+    import torch
+    from musicgeneration_amd import ops
+    N, K = 96, 64
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251          # exactly representable in bf16
+    packed = ops.pack_frag(w).reshape(-1, 8).float()
+    for nt in range(N // 32):
+        for ks in range(K // 16):
+            for lane in (0, 5, 31, 32, 47, 63):
+                unit = (nt * (K // 16) + ks) * 64 + lane
+                want = w[32 * nt + lane % 32, 16 * ks + 8 * (lane // 32): 16 * ks + 8 * (lane // 32) + 8]
+                assert torch.equal(packed[unit], want)
+    import pytest
+    with pytest.raises(ValueError):
+        ops.pack_frag(torch.zeros(40, 64))
