@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask */
-#define MGX_ABI_VERSION 14
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows */
+#define MGX_ABI_VERSION 15
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -227,6 +227,12 @@ int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, uint16_t* vca
 int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
                          uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
                          float* probs_out, int B, int advance, const uint32_t* allow_table, void* stream);
+/* The same for rows [row0, row0+B) of a larger batch (every pointer addresses the sub-batch's first row): the draw is a
+ * function of (seed, t, row0 + row), so a batch sampled in several independent sub-batches (KV-cache decode runs them on
+ * separate streams, each with its own pos_dev) gets the tokens the whole batch would get.                              */
+int mgx_sample_topk_topp_rows(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
+                              uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
+                              float* probs_out, int B, int row0, int advance, const uint32_t* allow_table, void* stream);
 
 /* ---- K13: Event_Melody_RNN step (Event_MelodyRNN/network.py:51-61): the GRU projections run on
  * mgx_linear_fwd; these two kernels are the rest of a step.

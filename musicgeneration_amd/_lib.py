@@ -13,7 +13,7 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 # the ABI the SIGNATURES table below was written for (MGX_ABI_VERSION of include/mgx.h).  A left-over
 # libmgx.so of another ABI still exports the same names: calling it with this table would shift arguments.
-EXPECTED_ABI = 14
+EXPECTED_ABI = 15
 
 # name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
 SIGNATURES = {
@@ -41,6 +41,7 @@ SIGNATURES = {
     "mgx_rel_attn_decode_workspace": [_i, _i, _i],       # returns size_t
     "mgx_rel_attn_decode": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_sample_topk_topp": [_vp, _i, _i, _f, _i, _f, _u64, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp],
+    "mgx_sample_topk_topp_rows": [_vp, _i, _i, _f, _i, _f, _u64, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp],
     "mgx_gather_rows": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_gru_gates": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "mgx_linear_dx": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

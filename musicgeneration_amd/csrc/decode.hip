@@ -171,7 +171,7 @@ MGX_DEV float u01(uint64_t seed, uint32_t step, uint32_t row) {
 __global__ __launch_bounds__(64) void sample_kernel(const uint16_t* __restrict__ logits, int V, int ld, float inv_temp,
                                                     int top_k, float top_p, uint64_t seed, int32_t* __restrict__ pos_dev,
                                                     int32_t* __restrict__ next_tok, int32_t* __restrict__ out_tokens,
-                                                    int out_ld, float* __restrict__ probs_out, int B,
+                                                    int out_ld, float* __restrict__ probs_out, int row0,
                                                     const uint32_t* __restrict__ allow_table) {
     const int row = blockIdx.x, lane = threadIdx.x;
     const uint16_t* lp = logits + (size_t)row * ld;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const uint16_t* __restrict__
     for (int i = 0; i < SMP_PER_LANE; ++i) { if (!(p[i] >= tau)) p[i] = 0.f; kept += p[i]; }
     const float total = wave_sum(kept);
     const int step = pos_dev[0];
-    const float target = u01(seed, (uint32_t)step, (uint32_t)row) * total;
+    const float target = u01(seed, (uint32_t)step, (uint32_t)(row0 + row)) * total;
     int choice = -1;
     float base = 0.f;
     // index order: v = lane + 64*i  ->  iterate i outer (blocks of 64 consecutive ids), prefix over lanes inner
@@ -340,17 +340,25 @@ extern "C" int mgx_rel_attn_decode(const uint16_t* qkv_new, uint16_t* kcache, ui
     return MGX_OK;
 }
 
-extern "C" int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
-                                    uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
-                                    float* probs_out, int B, int advance, const uint32_t* allow_table, void* stream) {
+extern "C" int mgx_sample_topk_topp_rows(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
+                                         uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
+                                         float* probs_out, int B, int row0, int advance, const uint32_t* allow_table,
+                                         void* stream) {
     MGX_REQUIRE(logits && pos_dev && next_tok, MGX_ERR_NULL, "mgx_sample_topk_topp: NULL pointer");
-    MGX_REQUIRE(B > 0 && V > 0 && V <= 64 * SMP_PER_LANE && ld >= V && temperature > 0.f && top_p > 0.f, MGX_ERR_SHAPE,
-                "mgx_sample_topk_topp: need 0<V<=%d, ld>=V, temperature>0, top_p>0 (V=%d ld=%d)", 64 * SMP_PER_LANE, V, ld);
+    MGX_REQUIRE(B > 0 && V > 0 && V <= 64 * SMP_PER_LANE && ld >= V && temperature > 0.f && top_p > 0.f && row0 >= 0, MGX_ERR_SHAPE,
+                "mgx_sample_topk_topp: need 0<V<=%d, ld>=V, temperature>0, top_p>0, row0>=0 (V=%d ld=%d)", 64 * SMP_PER_LANE, V, ld);
     hipLaunchKernelGGL(sample_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, V, ld, 1.f / temperature, top_k,
-                       top_p, seed, pos_dev, next_tok, out_tokens, out_ld, probs_out, B, allow_table);
+                       top_p, seed, pos_dev, next_tok, out_tokens, out_ld, probs_out, row0, allow_table);
     if (advance) hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, pos_dev);
     MGX_CHECK_LAUNCH("mgx_sample_topk_topp");
     return MGX_OK;
+}
+
+extern "C" int mgx_sample_topk_topp(const uint16_t* logits, int V, int ld, float temperature, int top_k, float top_p,
+                                    uint64_t seed, int32_t* pos_dev, int32_t* next_tok, int32_t* out_tokens, int out_ld,
+                                    float* probs_out, int B, int advance, const uint32_t* allow_table, void* stream) {
+    return mgx_sample_topk_topp_rows(logits, V, ld, temperature, top_k, top_p, seed, pos_dev, next_tok, out_tokens, out_ld,
+                                     probs_out, B, 0, advance, allow_table, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -231,7 +231,7 @@ class MusicTransformer(torch.nn.Module):
     @torch.no_grad()
     def generate_cached(self, prior: torch.Tensor, length: int, temperature: float = 1.0, top_k: int = 0,
                         top_p: float = 1.0, seed: int = 0, use_graph: bool = True, return_probs: bool = False,
-                        grammar=None, prefill: str = "auto", return_cache: bool = False):
+                        grammar=None, prefill: str = "auto", return_cache: bool = False, groups: Optional[int] = None):
         """Sample ``length`` events after ``prior`` [B,P] with per-layer K/V caches and absolute positions
         0..P+length-1 (requires P+length <= max_seq; no sliding window).  Every step runs
         embed -> N x (QKV GEMM, cached relative attention, fc, LN, FFN, LN) -> vocabulary GEMM -> fused
@@ -260,7 +260,17 @@ class MusicTransformer(torch.nn.Module):
         # caches are head-major [B, h, total, 64]: the decode kernel's workgroup (b, h) streams one contiguous run
         kc = [torch.zeros(B, d // 64, total, 64, dtype=bf, device=dev) for _ in range(nl)]
         vc = [torch.zeros(B, d // 64, total, 64, dtype=bf, device=dev) for _ in range(nl)]
-        pos = torch.zeros(1, dtype=torch.int32, device=dev)
+        # ``groups`` (default 1, or MGX_DECODE_GROUPS): the batch rows as that many independent sub-batches, each with its own
+        # captured step graph replayed on its own stream.  Rows never interact and the sampler draws by (seed, step, GLOBAL
+        # row), so the tokens do not depend on the grouping (tests/test_gpu_decode.py).  The point would be to let one
+        # sub-batch's bandwidth-bound attention stream its caches while another's chain of ~40 small projections waits out
+        # its launch latencies; measured at cfg5 (profiles/README.md, round 3) two hardware queues dispatch those chains
+        # SLOWER than one does (0.75 ms/token at 2 groups, 0.48 at 3-4, 0.72 at 6, against 0.50-0.51 at 1), so it stays off.
+        if groups is None:
+            groups = int(os.environ.get("MGX_DECODE_GROUPS", "0")) or 1
+        G = max(1, min(int(groups), B))
+        cuts = [B * g // G for g in range(G + 1)]
+        pos_all = torch.zeros(G, dtype=torch.int32, device=dev)
         tok = prior[:, 0].to(torch.int32).contiguous().to(dev)
         prior_i = prior.to(torch.int32).to(dev)
         out_tokens = torch.zeros(B, total, dtype=torch.int32, device=dev)
@@ -269,7 +279,20 @@ class MusicTransformer(torch.nn.Module):
         probs_step = torch.zeros(B, V, dtype=torch.float32, device=dev) if return_probs else None
         hbuf = torch.empty(B, d, dtype=bf, device=dev)
         ctxbuf = torch.empty(B, d, dtype=bf, device=dev)
-        attn_ws = ops.rel_attn_decode_workspace(B, total, d, dev)       # split-K partials (long caches only)
+
+        class _Rows:                                        # one sub-batch: views of rows [b0, b1) of every per-row buffer
+            pass
+        subs = []
+        for g in range(G):
+            r = _Rows()
+            r.b0, b1 = cuts[g], cuts[g + 1]
+            r.pos = pos_all[g:g + 1]
+            r.tok, r.out, r.h, r.ctx = tok[r.b0:b1], out_tokens[r.b0:b1], hbuf[r.b0:b1], ctxbuf[r.b0:b1]
+            r.probs = probs_step[r.b0:b1] if return_probs else None
+            r.kc, r.vc = [k[r.b0:b1] for k in kc], [v[r.b0:b1] for v in vc]
+            r.ws = ops.rel_attn_decode_workspace(b1 - r.b0, total, d, dev)       # split-K partials (long caches only)
+            r.stream = torch.cuda.Stream()
+            subs.append(r)
         pe = self.Decoder.pos_encoding.table()
         Pm = st.params
         layers = []
@@ -303,18 +326,18 @@ class MusicTransformer(torch.nn.Module):
                     ly[k + "_f"] = ops.FragWeight(ly[k])
             wv_f = ops.FragWeight(wv)
 
-        def step(sample_into_out: bool):
+        def step_rows(r, sample_into_out: bool):
             if fuse_ln:
-                qkv, h = ops.decode_embed_linear(tok, Pm["Decoder.embedding.weight"].data, pe, pos, layers[0]["wqkv_f"],
-                                                 layers[0]["bqkv"], hbuf)
+                qkv, h = ops.decode_embed_linear(r.tok, Pm["Decoder.embedding.weight"].data, pe, r.pos, layers[0]["wqkv_f"],
+                                                 layers[0]["bqkv"], r.h)
             else:
-                h = ops.decode_embed(tok, Pm["Decoder.embedding.weight"].data, pe, pos, hbuf)
+                h = ops.decode_embed(r.tok, Pm["Decoder.embedding.weight"].data, pe, r.pos, r.h)
                 qkv = ops.linear_fwd(h, layers[0]["wqkv"], layers[0]["bqkv"], 0)
             for i, ly in enumerate(layers):
-                ops.rel_attn_decode(qkv, kc[i], vc[i], ly["E"], pos, ctxbuf, attn_ws)
+                ops.rel_attn_decode(qkv, r.kc[i], r.vc[i], ly["E"], r.pos, r.ctx, r.ws)
                 nxt = layers[i + 1] if i + 1 < nl else None
                 if fuse_ln:
-                    a = ops.linear_fwd(ctxbuf, ly["wfc_f"], ly["bfc"], 0)
+                    a = ops.linear_fwd(r.ctx, ly["wfc_f"], ly["bfc"], 0)
                     f, o1 = ops.linear_ln_fwd(a, h, ly["g1"], ly["b1"], ly["w1_f"], ly["bb1"], 1)
                     f = ops.linear_fwd(f, ly["w2_f"], ly["bb2"], 0)
                     if nxt is not None:
@@ -322,7 +345,7 @@ class MusicTransformer(torch.nn.Module):
                     else:
                         logits, h = ops.linear_ln_fwd(f, o1, ly["g2"], ly["b2"], wv_f, bv, 0)
                 else:
-                    a = ops.linear_fwd(ctxbuf, ly["wfc"], ly["bfc"], 0)
+                    a = ops.linear_fwd(r.ctx, ly["wfc"], ly["bfc"], 0)
                     o1 = ops.add_ln_fwd(a, h, ly["g1"], ly["b1"], 1e-6)[0]
                     f = ops.linear_fwd(o1, ly["w1"], ly["bb1"], 1)
                     f = ops.linear_fwd(f, ly["w2"], ly["bb2"], 0)
@@ -331,8 +354,12 @@ class MusicTransformer(torch.nn.Module):
                         qkv = ops.linear_fwd(h, nxt["wqkv"], nxt["bqkv"], 0)
                     else:
                         logits = ops.linear_fwd(h, wv, bv, 0)
-            ops.sample_topk_topp(logits, V, pos, tok, out_tokens if sample_into_out else None, probs_step, temperature,
-                                 top_k, top_p, seed, advance=True, allow_table=allow)
+            ops.sample_topk_topp(logits, V, r.pos, r.tok, r.out if sample_into_out else None, r.probs, temperature,
+                                 top_k, top_p, seed, advance=True, allow_table=allow, row0=r.b0)
+
+        def step(sample_into_out: bool):                  # eager: the sub-batches one after the other on the current stream
+            for r in subs:
+                step_rows(r, sample_into_out)
 
         if prefill not in ("auto", "token", "batched"):
             raise ValueError("prefill must be 'auto', 'token' or 'batched'")
@@ -364,7 +391,7 @@ class MusicTransformer(torch.nn.Module):
                     o1_p = ops.add_ln_fwd(a_p, hh, ly["g1"], ly["b1"], 1e-6)[0]
                     f_p = ops.linear_fwd(ops.linear_fwd(o1_p, ly["w1"], ly["bb1"], 1), ly["w2"], ly["bb2"], 0)
                     hh = ops.add_ln_fwd(f_p, o1_p, ly["g2"], ly["b2"], 1e-6)[0]
-                pos.fill_(n)
+                pos_all.fill_(n)
                 tok.copy_(prior_i[:, n])
                 first = n
         # the (rest of the) prior is teacher-forced token by token (it also warms every kernel up before capture)
@@ -376,22 +403,25 @@ class MusicTransformer(torch.nn.Module):
                 tok.copy_(prior_i[:, p + 1])
         remaining = length - 1 if length > 0 else 0
         if remaining > 0:
-            graph = None
             if use_graph and not return_probs and remaining > 2:
+                # one graph per sub-batch, each replayed on its own stream: the sub-batches never meet until the end, so their
+                # chains of launches overlap freely (parallel branches INSIDE one graph were measured to run one after the other)
+                cur = torch.cuda.current_stream()
                 torch.cuda.synchronize()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, stream=side):
-                        step(True)
-                torch.cuda.current_stream().wait_stream(side)
-                remaining -= 1                      # the capture itself does not execute; replay below
-                remaining += 1
-            for p in range(remaining):
-                if graph is not None:
-                    graph.replay()
-                else:
+                for r in subs:
+                    r.stream.wait_stream(cur)
+                    with torch.cuda.stream(r.stream):
+                        r.graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(r.graph, stream=r.stream):
+                            step_rows(r, True)              # the capture itself does not execute
+                for p in range(remaining):
+                    for r in subs:
+                        with torch.cuda.stream(r.stream):
+                            r.graph.replay()
+                for r in subs:
+                    cur.wait_stream(r.stream)
+            else:
+                for p in range(remaining):
                     step(True)
                     if return_probs:
                         probs_all[:, P + p] = probs_step

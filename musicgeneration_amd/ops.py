@@ -435,8 +435,9 @@ def rel_attn_decode(qkv_new, kcache, vcache, E, pos_dev, ctx, workspace=None):
 
 
 def sample_topk_topp(logits, V, pos_dev, next_tok, out_tokens=None, probs_out=None, temperature=1.0, top_k=0, top_p=1.0,
-                     seed=0, advance=True, allow_table=None):
-    """allow_table: optional int32/uint32 [V, ceil(V/32)] grammar mask on the device (bit v of row t: v may follow t)"""
+                     seed=0, advance=True, allow_table=None, row0=0):
+    """allow_table: optional int32/uint32 [V, ceil(V/32)] grammar mask on the device (bit v of row t: v may follow t);
+    row0: index of the first row in the whole batch when the tensors are a sub-batch's rows (the draw is by global row)"""
     _need_cuda(logits, pos_dev, next_tok, out_tokens, probs_out, allow_table)
     ld = logits.shape[-1]
     B = logits.numel() // ld
@@ -444,10 +445,10 @@ def sample_topk_topp(logits, V, pos_dev, next_tok, out_tokens=None, probs_out=No
                                     or allow_table.shape[1] != (V + 31) // 32 or allow_table.element_size() != 4
                                     or not allow_table.is_contiguous()):
         raise ValueError("allow_table must be a contiguous 32-bit integer tensor of shape [V, ceil(V/32)]")
-    check(_lib.load().mgx_sample_topk_topp(ptr(logits), int(V), ld, float(temperature), int(top_k), float(top_p), int(seed),
-                                           ptr(pos_dev), ptr(next_tok), ptr(out_tokens),
-                                           0 if out_tokens is None else out_tokens.shape[-1], ptr(probs_out), B,
-                                           1 if advance else 0, ptr(allow_table), stream_ptr()), "mgx_sample_topk_topp")
+    check(_lib.load().mgx_sample_topk_topp_rows(ptr(logits), int(V), ld, float(temperature), int(top_k), float(top_p), int(seed),
+                                                ptr(pos_dev), ptr(next_tok), ptr(out_tokens),
+                                                0 if out_tokens is None else out_tokens.shape[-1], ptr(probs_out), B, int(row0),
+                                                1 if advance else 0, ptr(allow_table), stream_ptr()), "mgx_sample_topk_topp")
     return next_tok
 
 

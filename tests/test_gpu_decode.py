@@ -559,3 +559,21 @@ def test_gru_fused_sampling_step_matches_the_three_kernel_path(B, H, Kx):
     assert (y.float() - hb_ref.float()).abs().max().item() <= 3e-2
     with pytest.raises(ops._lib.MgxError):
         ops.gru_step_x_fwd(x, ops.pack_frag(wih), bih, hb, h, ops.pack_frag(whh), bhh, h, y)      # in place is refused
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_decode_row_groups_on_streams_give_the_same_tokens(use_graph):
+    """generate_cached(groups=G): the batch as G independent sub-batches on forked streams (joined per step, one graph).  Rows
+    never interact and the sampler draws by (seed, step, GLOBAL row), so every grouping returns the same tokens -- bitwise
+    below the split-key length (the number of key splits depends on the sub-batch size, the per-row arithmetic otherwise
+    not).  A ragged grouping (B=7 in 3 groups) is part of the sweep."""
+    mt, _ = _model(d=128, nl=2, L=160, V=337, seed=31)
+    g = torch.Generator().manual_seed(5)
+    for B, groups in ((8, (2, 4)), (7, (3,))):
+        prior = torch.randint(0, 336, (B, 3), generator=g).cuda()
+        ref = mt.generate_cached(prior, 150, top_p=0.95, seed=77, use_graph=use_graph, groups=1)
+        for G in groups:
+            got = mt.generate_cached(prior, 150, top_p=0.95, seed=77, use_graph=use_graph, groups=G)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (B, G)
+    assert len(set(ref[:, -1].tolist())) > 1                       # rows are not copies of each other
