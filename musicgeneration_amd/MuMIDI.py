@@ -6,9 +6,10 @@ tempo_value 364-423, chord 424-484.  Reference quirk kept: ``from_array`` names 
 its track ('melody' ... 'drum'), which ``to_array`` cannot encode (KeyError) -- MuMIDI.py:396-397."""
 from __future__ import annotations
 
-import collections
 
 import numpy as np
+
+from . import _vocab
 
 DEFAULT_FRACTION = 32
 DEFAULT_DURATION_STEP = 60
@@ -62,48 +63,37 @@ class MuMIDI_EventSeq:
         pass
 
     @staticmethod
-    def dim():
-        return sum(MuMIDI_EventSeq.feat_dims().values())
+    def _layout():
+        """(feature, slots) in id order -- MuMIDI.py:352-386 (drum hits share note_on, after the pitches)"""
+        c = MuMIDI_EventSeq
+        return (('empty', 1), ('note_on', len(c.pitch_range) + len(DEFAULT_DRUM_TYPE)), ('note_duration', len(c.duration_bins)),
+                ('note_velocity', len(DEFAULT_VELOCITY_BINS)), ('bar', 1), ('position', DEFAULT_FRACTION + 1),
+                ('track', len(DEFAULT_TRACKS)), ('tempo_class', len(DEFAULT_TEMPO_INTERVALS)),
+                ('tempo_value', len(DEFAULT_TEMPO_INTERVALS[0])), ('chord', len(chord_map)))
 
     @staticmethod
     def feat_dims():
-        """MuMIDI.py:352-386"""
-        feat_dims = collections.OrderedDict()
-        feat_dims['empty'] = 1
-        feat_dims['note_on'] = len(MuMIDI_EventSeq.pitch_range) + len(DEFAULT_DRUM_TYPE)
-        feat_dims['note_duration'] = len(MuMIDI_EventSeq.duration_bins)
-        feat_dims['note_velocity'] = len(DEFAULT_VELOCITY_BINS)
-        feat_dims['bar'] = 1
-        feat_dims['position'] = DEFAULT_FRACTION + 1
-        feat_dims['track'] = len(DEFAULT_TRACKS)
-        feat_dims['tempo_class'] = len(DEFAULT_TEMPO_INTERVALS)
-        feat_dims['tempo_value'] = len(DEFAULT_TEMPO_INTERVALS[0])
-        feat_dims['chord'] = len(chord_map)
-        return feat_dims
+        return _vocab.slots(MuMIDI_EventSeq._layout())
+
+    @staticmethod
+    def dim():
+        return sum(n for _, n in MuMIDI_EventSeq._layout())
 
     @staticmethod
     def feat_ranges():
-        if MuMIDI_EventSeq.feats_ranges is not None:
-            return MuMIDI_EventSeq.feats_ranges
-        offset = 0
-        feat_ranges = collections.OrderedDict()
-        for feat_name, feat_dim in MuMIDI_EventSeq.feat_dims().items():
-            feat_ranges[feat_name] = range(offset, offset + feat_dim)
-            offset += feat_dim
-        MuMIDI_EventSeq.feats_ranges = feat_ranges
-        return feat_ranges
+        """computed once and kept in ``feats_ranges``, as the reference does (MuMIDI.py:376-386)"""
+        c = MuMIDI_EventSeq
+        if c.feats_ranges is None:
+            c.feats_ranges = _vocab.id_ranges(c._layout())
+        return c.feats_ranges
 
     @staticmethod
     def dims_feat():
-        """index -> (name, value); track ids map to the TRACK's name (MuMIDI.py:388-405)"""
-        if MuMIDI_EventSeq.idxs_feats is not None:
-            return MuMIDI_EventSeq.idxs_feats
-        idxs_feat = collections.OrderedDict()
-        for feat_name, r in MuMIDI_EventSeq.feat_ranges().items():
-            for i, idx in enumerate(r):
-                idxs_feat[idx] = (DEFAULT_TRACKS[i], i) if feat_name == 'track' else (feat_name, i)
-        MuMIDI_EventSeq.idxs_feats = idxs_feat
-        return idxs_feat
+        """id -> (name, value), kept in ``idxs_feats``; a track id reports the TRACK's name, not 'track' (MuMIDI.py:388-405)"""
+        c = MuMIDI_EventSeq
+        if c.idxs_feats is None:
+            c.idxs_feats = _vocab.id_table(c.feat_ranges(), lambda feat, v: DEFAULT_TRACKS[v] if feat == 'track' else feat)
+        return c.idxs_feats
 
     @staticmethod
     def get_track_id(track_name):
@@ -115,32 +105,23 @@ class MuMIDI_EventSeq:
 
     @staticmethod
     def to_array(events):
-        """MuMIDI.py:543-556 ('track_<name>' events use the first five characters as the feature)"""
-        feat_idxs = MuMIDI_EventSeq.feat_ranges()
-        idxs = []
-        for event in events:
-            if event.name == 'chord':
-                idxs.append(feat_idxs[event.name][chord_map[event.value]])
-            elif event.name.startswith('track'):
-                idxs.append(feat_idxs[event.name[:5]][event.value])
-            else:
-                idxs.append(feat_idxs[event.name][event.value])
-        dtype = np.uint8 if MuMIDI_EventSeq.dim() <= 256 else np.uint16
-        return np.array(idxs, dtype=dtype)
+        """events -> ids (MuMIDI.py:543-556): 'track_<name>' events are filed under 'track' (their first five characters),
+        a chord's value is its name"""
+        ids = MuMIDI_EventSeq.feat_ranges()
+
+        def slot(e):
+            if e.name == 'chord':
+                return ids['chord'], chord_map[e.value]
+            return ids[e.name[:5] if e.name.startswith('track') else e.name], e.value
+        return _vocab.encode([slot(e) for e in events], MuMIDI_EventSeq.dim())
 
     @staticmethod
     def to_event(words):
-        """MuMIDI.py:558-569"""
-        idxs_feat = MuMIDI_EventSeq.dims_feat()
-        events = []
-        for word in words:
-            event_name, event_value = idxs_feat[int(word)]
-            if event_name == 'chord':
-                event_value = inv_chord_map[event_value]
-            if event_name == 'track':   # never true: dims_feat already substituted the track's name
-                event_name = event_name + '_' + DEFAULT_TRACKS[event_value]
-            events.append(Event(event_name, None, event_value, None))
-        return events
+        """ids -> events without times (MuMIDI.py:558-569).  The reference would rename a 'track' event to 'track_<name>'
+        here, but its id table never reports 'track' (see dims_feat), so track events come back named after the track."""
+        table = MuMIDI_EventSeq.dims_feat()
+        named = (table[int(w)] for w in words)
+        return [Event(name, None, inv_chord_map[v] if name == 'chord' else v, None) for name, v in named]
 
     @staticmethod
     def from_array(words):

@@ -6,9 +6,10 @@ strings 'C:maj' ... 'N:N').  Reference quirk kept: note_velocity has only 4 slot
 ``to_array`` raises IndexError for a velocity value >= 4 (REMI.py:452 vs :206-209)."""
 from __future__ import annotations
 
-import collections
 
 import numpy as np
+
+from . import _vocab
 
 DEFAULT_FRACTION = 16
 DEFAULT_DURATION_RANGE = range(60, 3841)
@@ -54,40 +55,31 @@ class REMI_EventSeq:
         pass
 
     @staticmethod
-    def dim():
-        return sum(REMI_EventSeq.feat_dims().values())
+    def _layout():
+        """(feature, slots) in id order -- REMI.py:434-460.  Read from the class attributes on every call, so a caller that
+        narrows ``pitch_range`` / ``duration_bins`` gets the vocabulary the reference would give."""
+        c = REMI_EventSeq
+        return (('note_on', len(c.pitch_range)), ('note_duration', len(c.duration_bins)),
+                ('note_velocity', c.velocity_steps), ('bar', 1), ('position', DEFAULT_FRACTION),
+                ('tempo_class', len(DEFAULT_tempo_INTERVALS)), ('tempo_value', len(DEFAULT_tempo_INTERVALS[0])),
+                ('chord', len(chord_map)))
 
     @staticmethod
     def feat_dims():
-        """REMI.py:434-460"""
-        feat_dims = collections.OrderedDict()
-        feat_dims['note_on'] = len(REMI_EventSeq.pitch_range)
-        feat_dims['note_duration'] = len(REMI_EventSeq.duration_bins)
-        feat_dims['note_velocity'] = REMI_EventSeq.velocity_steps
-        feat_dims['bar'] = 1
-        feat_dims['position'] = DEFAULT_FRACTION
-        feat_dims['tempo_class'] = len(DEFAULT_tempo_INTERVALS)
-        feat_dims['tempo_value'] = len(DEFAULT_tempo_INTERVALS[0])
-        feat_dims['chord'] = len(chord_map)
-        return feat_dims
+        return _vocab.slots(REMI_EventSeq._layout())
+
+    @staticmethod
+    def dim():
+        return sum(n for _, n in REMI_EventSeq._layout())
 
     @staticmethod
     def feat_ranges():
-        offset = 0
-        feat_ranges = collections.OrderedDict()
-        for feat_name, feat_dim in REMI_EventSeq.feat_dims().items():
-            feat_ranges[feat_name] = range(offset, offset + feat_dim)
-            offset += feat_dim
-        return feat_ranges
+        return _vocab.id_ranges(REMI_EventSeq._layout())
 
     @staticmethod
     def dims_feat():
-        """index -> (feature name, value)          REMI.py:462-474"""
-        idxs_feat = collections.OrderedDict()
-        for feat_name, r in REMI_EventSeq.feat_ranges().items():
-            for i, idx in enumerate(r):
-                idxs_feat[idx] = (feat_name, i)
-        return idxs_feat
+        """id -> (feature name, value)          REMI.py:462-474"""
+        return _vocab.id_table(REMI_EventSeq.feat_ranges())
 
     @staticmethod
     def write_midi(events, output_path, prompt_path=None):
@@ -167,28 +159,17 @@ class REMI_EventSeq:
 
     @staticmethod
     def to_array(events):
-        """REMI.py:510-520"""
-        feat_idxs = REMI_EventSeq.feat_ranges()
-        idxs = []
-        for event in events:
-            if event.name == 'chord':
-                idxs.append(feat_idxs[event.name][chord_map[event.value]])
-            else:
-                idxs.append(feat_idxs[event.name][event.value])   # IndexError beyond the feature's slots
-        dtype = np.uint8 if REMI_EventSeq.dim() <= 256 else np.uint16
-        return np.array(idxs, dtype=dtype)
+        """events -> ids (REMI.py:510-520); a chord's value is its name, every other value indexes the feature's slots"""
+        ids = REMI_EventSeq.feat_ranges()
+        return _vocab.encode([(ids[e.name], chord_map[e.value] if e.name == 'chord' else e.value) for e in events],
+                             REMI_EventSeq.dim())
 
     @staticmethod
     def to_event(words):
-        """REMI.py:522-531"""
-        idxs_feat = REMI_EventSeq.dims_feat()
-        events = []
-        for word in words:
-            event_name, event_value = idxs_feat[int(word)]
-            if event_name == 'chord':
-                event_value = inv_chord_map[event_value]
-            events.append(Event(event_name, None, event_value, None))
-        return events
+        """ids -> events without times (REMI.py:522-531)"""
+        table = REMI_EventSeq.dims_feat()
+        named = (table[int(w)] for w in words)
+        return [Event(name, None, inv_chord_map[v] if name == 'chord' else v, None) for name, v in named]
 
     @staticmethod
     def from_array(words):

@@ -8,10 +8,11 @@ time_shift 208-307 (0.01 s .. 1.00 s).  Index work is integer and bit-exact with
 is installed (optional; absent in this image)."""
 from __future__ import annotations
 
-import collections
 import copy
 
 import numpy as np
+
+from . import _vocab
 
 DEFAULT_SAVING_PROGRAM = 1
 DEFAULT_LOADING_PROGRAMS = range(128)
@@ -102,29 +103,25 @@ class EventSeq:
 
     # ---- vocabulary ------------------------------------------------------------------------------
     @staticmethod
+    def _layout():
+        """(feature, slots) in id order -- sequence.py:204-212; the velocity feature exists only with USE_VELOCITY"""
+        c = EventSeq
+        keys = len(c.pitch_range)
+        return (('note_on', keys), ('note_off', keys)) + ((('velocity', c.velocity_steps),) if USE_VELOCITY else ()) \
+            + (('time_shift', len(c.time_shift_bins)),)
+
+    @staticmethod
     def feat_dims():
-        """sequence.py:204-212"""
-        feat_dims = collections.OrderedDict()
-        feat_dims['note_on'] = len(EventSeq.pitch_range)
-        feat_dims['note_off'] = len(EventSeq.pitch_range)
-        if USE_VELOCITY:
-            feat_dims['velocity'] = EventSeq.velocity_steps
-        feat_dims['time_shift'] = len(EventSeq.time_shift_bins)
-        return feat_dims
+        return _vocab.slots(EventSeq._layout())
 
     @staticmethod
     def feat_ranges():
         """sequence.py:214-221"""
-        offset = 0
-        feat_ranges = collections.OrderedDict()
-        for feat_name, feat_dim in EventSeq.feat_dims().items():
-            feat_ranges[feat_name] = range(offset, offset + feat_dim)
-            offset += feat_dim
-        return feat_ranges
+        return _vocab.id_ranges(EventSeq._layout())
 
     @staticmethod
     def dim():
-        return sum(EventSeq.feat_dims().values())
+        return sum(n for _, n in EventSeq._layout())
 
     @staticmethod
     def get_velocity_bins():
