@@ -45,7 +45,8 @@ int mgx_device_count(void);
  * (seed, element index) so the backward regenerates it.  p == 0 disables it.                  */
 int mgx_embed_pe_fwd(const int32_t* tok, const float* table, const float* pe, uint16_t* out,
                      int B, int L, int d, int V, float p_drop, uint64_t seed, void* stream);
-/* dtable f32 [V,d] += scatter-add of dout bf16 [rows,d] (deterministic: one block per vocab row) */
+/* dtable f32 [V,d] += scatter-add of dout bf16 [rows,d] (per vocabulary row and token range one block-wide sum, added with
+ * one fp32 atomic per element: the order of those few adds, hence the last bits, may differ between runs) */
 int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dtable,
                   int B, int L, int d, int V, float p_drop, uint64_t seed, void* stream);
 

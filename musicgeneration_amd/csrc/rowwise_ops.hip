@@ -30,10 +30,12 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(
     }
 }
 
-// dtable[v, :] += sqrt(d) * sum_{r: tok[r]==v} dropmask * dout[r, :]     one block per vocab row
-// (deterministic: no atomics; the tokens are re-scanned from L2 by every block).  The token stream is scanned in
-// chunks of 4096 into an LDS hit list, then the block's waves gather the hit rows in parallel (wave = one hit row at a
-// time, lane = 8 columns; d <= 512 per pass) and the four partial sums are folded through LDS at the end.
+// dtable[v, :] += sqrt(d) * sum_{r: tok[r]==v} dropmask * dout[r, :]     block (v, s) = vocab row v, token range s of
+// gridDim.y (the tokens are re-scanned from L2 by every block of the range).  The range is scanned in chunks of 4096 into
+// an LDS hit list, then the block's waves gather the hit rows in parallel (wave = one hit row at a time, lane = 8 columns;
+// d <= 512 per pass), the four partial sums are folded through LDS and the block adds its sum with one fp32 atomic per
+// element -- gridDim.y adds per element, not one per token.  (One block per vocabulary row, as until round 3, is a chain of
+// dependent scan / gather phases over the whole batch: 235 us at cfg2 / batch 64 for a 67 MB read.)
 constexpr int EB_CHUNK = 4096;
 __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int32_t* __restrict__ tok, const uint16_t* __restrict__ dout, float* __restrict__ dtable,
@@ -41,16 +43,18 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int v = blockIdx.x;
     const int gpr = d >> 3;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int per = ((rows + (int)gridDim.y - 1) / (int)gridDim.y + EB_CHUNK - 1) / EB_CHUNK * EB_CHUNK;
+    const int r_lo = blockIdx.y * per, r_hi = min(rows, r_lo + per);
     __shared__ int hits[EB_CHUNK];
     __shared__ int nhit;
     __shared__ float part[3][64][8];
     for (int g0 = 0; g0 < gpr; g0 += 64) {                  // column pass (one for d <= 512)
         const int gi = g0 + lane;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int base = 0; base < rows; base += EB_CHUNK) {
+        for (int base = r_lo; base < r_hi; base += EB_CHUNK) {
             if (tid == 0) nhit = 0;
             __syncthreads();
-            for (int r = base + tid; r < min(rows, base + EB_CHUNK); r += 256)
+            for (int r = base + tid; r < min(r_hi, base + EB_CHUNK); r += 256)
                 if (tok[r] == v) hits[atomicAdd(&nhit, 1)] = r;
             __syncthreads();
             const int n = nhit;
@@ -79,13 +83,17 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
         if (w == 0 && gi < gpr) {
             float* dp = dtable + (size_t)v * d + gi * 8;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) dp[q] += (acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]) * scale;
+            for (int q = 0; q < 8; ++q) {
+                const float sum = (acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]) * scale;
+                if (gridDim.y == 1) dp[q] += sum;
+                else if (sum != 0.f) atomicAdd(dp + q, sum);
+            }
         }
         __syncthreads();
     }
 }
-// NOTE on determinism: hits[] order depends on LDS atomic arrival order, so the fp32 sum order can
-// vary between launches by rounding only; values are identical to ~1 ulp of the fp32 sum.
+// NOTE on determinism: hits[] order depends on LDS atomic arrival order and the ranges' sums arrive in any order, so the
+// fp32 sum order can vary between launches by rounding only; values are identical to ~1 ulp of the fp32 sum.
 
 extern "C" int mgx_embed_pe_fwd(const int32_t* tok, const float* table, const float* pe, uint16_t* out,
                                 int B, int L, int d, int V, float p_drop, uint64_t seed, void* stream) {
@@ -106,7 +114,11 @@ extern "C" int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dt
     MGX_REQUIRE(tok && dout && dtable, MGX_ERR_NULL, "mgx_embed_bwd: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && V > 0 && d > 0 && d % 8 == 0, MGX_ERR_SHAPE,
                 "mgx_embed_bwd: need B,L,V>0 and d%%8==0 (got B=%d L=%d d=%d V=%d)", B, L, d, V);
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, tok, dout, dtable, B * L, d,
+    // token ranges: enough blocks to fill the chip several times over, at least two chunks of tokens each
+    const long rows = (long)B * L;
+    int split = (int)std::min<long>(16, std::max<long>(1, rows / (2 * EB_CHUNK)));
+    while (split > 1 && (long)V * split > 8192) --split;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V, split), dim3(256), 0, (hipStream_t)stream, tok, dout, dtable, B * L, d,
                        sqrtf((float)d), make_drop(p_drop, seed));
     MGX_CHECK_LAUNCH("mgx_embed_bwd");
     return MGX_OK;
