@@ -58,9 +58,11 @@ def test_rccl_world_of_one_matches_no_dp(tmp_path):
     print("RCCL version", rccl["describe"]["rccl_version"])
     assert rccl["buckets"] >= 3 and rccl["bytes_reduced"] > 0 and one["bytes_reduced"] == 0
     noise = max(abs(a - b) / abs(a) for a, b in zip(one["losses"], again["losses"]))
-    # one pair of plain runs can agree by chance far better than the typical noise of the fp32 atomics (dE, dW splits): the floor
-    # is the typical level (1e-5 .. 5e-5 relative over these steps); a mis-ordered bucket moves the loss by > 1e-2
-    tol = max(10 * noise, 2e-4)
+    # one pair of plain runs can agree by chance far better than the typical noise: the fp32 atomics (dE, dW splits, the embedding
+    # gradient) differ in the last bits, and once such a bit flips the bf16 rounding of a shadow weight the loss of the NEXT step
+    # moves by 1e-4 .. 5e-4 relative (seen: five steps equal to 4e-6, the sixth 2.9e-4 apart).  The floor sits above that and
+    # 10x below what a mis-ordered bucket does (> 1e-2).
+    tol = max(10 * noise, 1e-3)
     for a, b in zip(one["losses"], rccl["losses"]):
         assert abs(a - b) <= tol * abs(a), (one["losses"], rccl["losses"], noise)
     pnoise = abs(one["param_sum"] - again["param_sum"]) / one["param_abs"]
