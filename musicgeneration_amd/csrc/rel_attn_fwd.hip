@@ -35,6 +35,10 @@
 
 using namespace relattn;
 
+#ifndef MGX_FWD_AHEAD
+#define MGX_FWD_AHEAD 0   // 1: main loop with the Q.Er^T product one step ahead of its tile (experiment: 0.567-0.569 ms against 0.562-0.563
+                          // at cfg2 batch 64 -- with three waves per SIMD the shorter per-wave chain buys nothing; 168 VGPRs, 2 spilled)
+#endif
 #ifndef MGX_FWD_PEEL
 #define MGX_FWD_PEEL 0      // timing experiments only (tools/peel_fwd.sh): 1 no E-fragment loads in the main loop | 2 no band round trip |
 #endif                      // 4 no exponentials | 8 K / V prefetch re-reads tile 0; results are then wrong
@@ -233,6 +237,48 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: ONE branch-free body -------------
     const int nmain = (WRITE_W || anypad || !CAUSAL) ? 0 : Q0;       // Q0 <= ntw - 1: a next tile always exists inside this loop
     int s = 0;
+#if MGX_FWD_AHEAD
+    // The Q.Er^T product runs ONE STEP AHEAD of the tile that needs it: on entry of step s the band already holds both chunks of
+    // the tile (dq and dq-1), so the step starts with the band read and its chain is band read -> K.Q^T -> softmax -> P.V; the
+    // product of chunk dq-2 (for the next step) is independent of that chain -- its MFMAs run under the softmax's VALU work and its
+    // 16 band stores go out behind the P.V MFMAs (they overwrite the slot of chunk dq, which was read at the top).
+    if (nmain > 0) {
+        f32x16 qe = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
+        band_put(qe, q0 - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(q0 - 2, ks);
+    }
+    for (; s < nmain; ++s) {
+        const int cur = s & 1;
+        const int tn = (MGX_FWD_PEEL & 8) ? 0 : min(s + 1, ntw - 1);
+        const u32x4 kreg = k_tile(tn);
+        const u32x4 vreg = v_tile(tn);
+        const int dq = q0 - s;                            // >= 1
+        wave_lds_fence();
+        f32x16 c = band_get(dq);
+        wave_lds_fence();
+        const char* kt = smem + OFF_K + cur * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
+        f32x16 qe = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(dq - 3, ks);              // chunk of the next step's product
+        __builtin_amdgcn_sched_barrier(0x78F);             // VMEM may not sink below: the fragments are needed in the next step
+        softmax_pv(c, cur);
+        band_put(qe, dq - 2);
+        *(u32x4*)(smem + OFF_K + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
+        *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
+        __syncthreads();
+    }
+    if (nmain > 0) {                                      // hand-over to the general body: it forms chunk dq-1 itself (again)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(q0 - s - 1, ks);
+    }
+#else
     for (; s < nmain; ++s) {
         const int cur = s & 1;
         const int tn = (MGX_FWD_PEEL & 8) ? 0 : min(s + 1, ntw - 1);
@@ -261,6 +307,8 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
         *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
         __syncthreads();
     }
+
+#endif
 
     // ---- general body: the diagonal 128 x 128 block (a wave is full / on its diagonal / done), padded keys,
     //      weights output ------------------------------------------------------------------------------------------
