@@ -536,7 +536,8 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 // ================================================================================================
 #ifndef MGX_DKV_PEEL
 #define MGX_DKV_PEEL 0      // timing experiments only (tools/peel_dkv.sh): 1 no E loads in the sweep | 2 no dS stores | 4 no skew (bpermute)
-#endif                      // | 8 no exponentials | 16 no q / dO tile prefetch+publish (the first tile is reused); results are then wrong
+#endif                      // | 8 no exponentials | 16 no q / dO tile prefetch+publish (the first tile is reused) | 32 no lse / delta reads
+                            // (constants); results are then wrong
 namespace k2 {
 constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         f32x16 dp;                                        // initial accumulator: -delta of the accumulator's query rows
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
+            const f32x4 d4 = (MGX_DKV_PEEL & 32) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
             dp[4 * g4] = d4.x; dp[4 * g4 + 1] = d4.y; dp[4 * g4 + 2] = d4.z; dp[4 * g4 + 3] = d4.w;
         }
         const char* orr = smem + OFF_OR + cur * TILE_BYTES;
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         f32x16 ds;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
+            const f32x4 l4 = (MGX_DKV_PEEL & 32) ? f32x4{9.f, 9.f, 9.f, 9.f} : *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float p = (MGX_DKV_PEEL & 8) ? __builtin_fmaf(c[4 * g4 + k], 1e-9f, -l4[k])
@@ -943,8 +944,8 @@ __global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
             f32x16 ds;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 l4 = *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
-                const f32x4 d4 = *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
+                const f32x4 l4 = (MGX_DKV_PEEL & 32) ? f32x4{9.f, 9.f, 9.f, 9.f} : *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
+                const f32x4 d4 = (MGX_DKV_PEEL & 32) ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(st + 128 + (8 * g4 + 4 * hh) * 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * g4 + k;

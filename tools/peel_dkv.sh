@@ -3,8 +3,8 @@
 #   here (no GPU):  bash tools/peel_dkv.sh build      -> musicgeneration_amd/libmgx_dkvpeel<mask>.so for every mask below
 #   GPU box:        bash tools/peel_dkv.sh run [B]     -> one line per build: dkv ms (tools/attn_bench.py --parts 8)
 # masks (MGX_DKV_PEEL, rel_attn_bwd.hip): 1 no E-fragment loads in the sweep | 2 no dS stores | 4 no skew (ds_bpermute; until the bpermute version: the LDS band round trip) |
-#   8 no exponentials | 16 the q / dO tile prefetch always re-reads tile 0 (L2-resident)
-MASKS="0 1 2 4 8 16 31"
+#   8 no exponentials | 16 the q / dO tile prefetch always re-reads tile 0 (L2-resident) | 32 lse / delta are constants (no LDS reads of the statistics)
+MASKS=${MASKS:-"0 1 2 4 8 16 32 63"}
 if [ "$1" = build ]; then
   for m in $MASKS; do python3 -m musicgeneration_amd._build --variant dkvpeel$m -DMGX_DKV_PEEL=$m | tail -1; done
 else
