@@ -6,17 +6,22 @@ B=${1:-65536}
 export GEMM_M=$B
 ROOT=$(pwd)
 OUT=${2:-gpurun_out/pmc_gemm.json}
+TAG=pmcgemm_$$
+mkdir -p gpurun_out
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_MISC" \
            "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; do
   n=$(echo $set | cut -c1-14 | tr " " "_")
-  rm -rf /tmp/pmc_$n
-  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$n -- python3 $ROOT/tools/gemm_bench.py > /dev/null 2>&1)
+  rm -rf /tmp/${TAG}_$n
+  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/${TAG}_$n -- python3 $ROOT/tools/gemm_bench.py > $ROOT/gpurun_out/pmc_gemm_pass_$n.log 2>&1) \
+    || { echo "pmc pass $n failed (rc $?):"; tail -5 gpurun_out/pmc_gemm_pass_$n.log; exit 1; }
 done
-python3 - "$OUT" "$B" <<'PY'
+python3 - "$OUT" "$B" "$TAG" <<'PY'
 import csv, glob, json, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("/tmp/pmc_*/**/*counter_collection.csv", recursive=True):
+files = glob.glob(f"/tmp/{sys.argv[3]}_*/**/*counter_collection.csv", recursive=True)
+assert len(files) == 3, f"expected 3 counter files of this run, found {files}"
+for f in files:
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
         if "linear_" in k:
