@@ -41,7 +41,8 @@ using namespace relattn;
 #endif
 #ifndef MGX_FWD_PEEL
 #define MGX_FWD_PEEL 0      // timing experiments only (tools/peel_fwd.sh): 1 no E-fragment loads in the main loop | 2 no band round trip |
-#endif                      // 4 no exponentials | 8 K / V prefetch re-reads tile 0; results are then wrong
+#endif                      // 4 no exponentials | 8 K / V prefetch re-reads tile 0 | 16 no parity XOR of the band-store addresses | 32 no row-sum
+                            // adds | 64 no redo branch anywhere (main loop AND general body); results are then wrong
 namespace {
 constexpr int WAVES = 4;
 constexpr int OFF_K = 0;                                        // 2 x 4 KiB   image R
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     auto band_put = [&](const f32x16& v, int q) {        // chunk q of Q.Er^T -> band
         const uint32_t tog = (q & 1) << 7;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lds_store_f32((wcl[r] ^ tog) + r * BAND_STRIDE, v[r]);
+        for (int r = 0; r < 16; ++r) lds_store_f32(((MGX_FWD_PEEL & 16) ? wcl[r] : (wcl[r] ^ tog)) + r * BAND_STRIDE, v[r]);
     };
     auto band_get = [&](int dq) {                        // Srel^T of the tile with D/32 = dq
         const char* rb = smem + rbase + ((dq & 1) << 7);
@@ -199,8 +200,10 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
                 const float a0 = __builtin_fmaf(c[8 * ss + 2 * jj], LOG2E, mneg), a1 = __builtin_fmaf(c[8 * ss + 2 * jj + 1], LOG2E, mneg);
                 const float p0 = (MGX_FWD_PEEL & 4) ? a0 * 1e-9f : __builtin_amdgcn_exp2f(a0);
                 const float p1 = (MGX_FWD_PEEL & 4) ? a1 * 1e-9f : __builtin_amdgcn_exp2f(a1);
-                lsum += p0;
-                lsum += p1;
+                if (!(MGX_FWD_PEEL & 32)) {
+                    lsum += p0;
+                    lsum += p1;
+                }
                 wv[jj] = pack_bf16x2(p0, p1);
             }
             pf[ss] = __builtin_bit_cast(bf16x8, wv);
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     auto softmax_pv = [&](const f32x16& c, int cur) {
         bf16x8 pf[2];
         float lsum = exp_tile(c, -m_ref * LOG2E, pf);
-        if (__builtin_expect(__any(!(lsum <= L_SAFE)), 0)) {
+        if (!(MGX_FWD_PEEL & 64) && __builtin_expect(__any(!(lsum <= L_SAFE)), 0)) {
             // redo against the true maximum (both lane halves of a query row must agree on m)
             float tmax = c[0];
 #pragma unroll

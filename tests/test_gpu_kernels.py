@@ -437,3 +437,34 @@ def test_linear_ln_fwd(M, N, K, act):
     with pytest.raises(ops._lib.MgxError):
         ops.linear_ln_fwd(torch.zeros(33, K, dtype=torch.bfloat16, device=dev), torch.zeros(33, K, dtype=torch.bfloat16, device=dev),
                           gamma, beta, w, bias, act)
+
+
+def test_rel_attn_fwd_redoes_a_main_loop_tile_that_leaves_the_safe_range():
+    """The lazy softmax of the forward keeps one reference per query row and redoes a tile against the true maximum when a
+    lane's tile sum leaves the safe range (then rescales O and l once).  Every sweep does that on its first tile; here it must
+    ALSO happen deep inside the branch-free-looking main loop: key 70 (key tile 2, below the diagonal block of every query block
+    from the second on) beats the reference of query row 400 by 128 nats and of row 300 by 64.  Both rows, and every other row
+    of those workgroups, must match the oracle."""
+    from musicgeneration_amd import ops
+    from oracle import ref_cpu as R
+    dev = torch.device("cuda")
+    B, L, d = 2, 512, 128
+    g = torch.Generator().manual_seed(17)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.3).to(torch.bfloat16)
+    E = (torch.randn(L, 64, generator=g) * 0.3).to(torch.bfloat16)
+    qkv[0, 400, :64] = 4.0          # head 0: query row 400 (query block 3) ...
+    qkv[0, 70, d:d + 64] = 4.0      # ... and key 70: logit 64 * 16 / 8 = 128
+    qkv[0, 300, :64] = 2.0          # query block 2: 64 nats above its reference
+    qkv[1, 200, 64:128] = -4.0      # head 1 of batch row 1: the same key pattern strongly NEGATIVE (no restart there)
+    qkv[1, 70, d + 64:d + 128] = 4.0
+    tok = torch.zeros(B, L, dtype=torch.int32)
+    ref_ctx, _, _ = R.attn_core(qkv.float(), E.float(), R.look_ahead_mask(tok, 9), d // 64)
+    ctx, lse = ops.rel_attn_fwd(qkv.to(dev), E.to(dev), None)
+    torch.cuda.synchronize()
+    ctx = ctx.float().cpu()
+    assert torch.isfinite(ctx).all() and torch.isfinite(lse).all()
+    assert (ctx - ref_ctx).abs().max().item() <= 2e-2 * ref_ctx.abs().max().item()
+    # the dominated rows attend to key 70 alone
+    v70 = qkv[0, 70, 2 * d:2 * d + 64].float()
+    assert (ctx[0, 400, :64] - v70).abs().max().item() < 2e-2
+    assert abs(lse.view(B, d // 64, L)[0, 0, 400].item() - 128.0) < 4.0          # 128 + the relative term of that pair
