@@ -42,7 +42,7 @@ using namespace relattn;
 #ifndef MGX_FWD_PEEL
 #define MGX_FWD_PEEL 0      // timing experiments only (tools/peel_fwd.sh): 1 no E-fragment loads in the main loop | 2 no band round trip |
 #endif                      // 4 no exponentials | 8 K / V prefetch re-reads tile 0 | 16 no parity XOR of the band-store addresses | 32 no row-sum
-                            // adds | 64 no redo branch anywhere (main loop AND general body); results are then wrong
+                            // adds | 64 no redo branch anywhere (main loop AND general body) | 128 no general steps after a main loop; results are then wrong
 namespace {
 constexpr int WAVES = 4;
 constexpr int OFF_K = 0;                                        // 2 x 4 KiB   image R
@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
 
     // ---- general body: the diagonal 128 x 128 block (a wave is full / on its diagonal / done), padded keys,
     //      weights output ------------------------------------------------------------------------------------------
+    if ((MGX_FWD_PEEL & 128) && nmain > 0) s = ntw;       // peel: no general steps after a main loop (what the diagonal block costs)
     for (; s < ntw; ++s) {
         const int cur = s & 1;
         const int tn = min(s + 1, ntw - 1);
