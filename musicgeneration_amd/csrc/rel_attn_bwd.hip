@@ -1167,6 +1167,8 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
 static int bwd_batch_group(int B, int L, int d) {
     const double per_row = (double)L * d * 2 * 5;
     int g = B;
+    static const int forced = [] { const char* e = getenv("MGX_ATTN_BGROUP"); return e ? atoi(e) : 0; }();   // experiment knob
+    if (forced > 0 && B % forced == 0) return forced;
     while (g > 1 && (g * per_row > 110e6 || B % g != 0)) --g;
     return g;
 }

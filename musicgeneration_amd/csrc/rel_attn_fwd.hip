@@ -407,6 +407,8 @@ extern "C" size_t mgx_rel_attn_fwd_workspace(int L) { return L > 0 ? er_frag_byt
 static int batch_group(int B, int L, int d) {
     const double per_row = (double)L * d * 2 * 4;
     int g = B;
+    static const int forced = [] { const char* e = getenv("MGX_ATTN_BGROUP"); return e ? atoi(e) : 0; }();   // experiment knob
+    if (forced > 0 && B % forced == 0) return forced;
     while (g > 1 && (g * per_row > 110e6 || B % g != 0)) --g;
     return g;
 }
