@@ -1223,8 +1223,15 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     const int bg = bwd_batch_group(B, L, d);
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
     const dim3 gq(bg * heads, ((L + 127) / 128) * (B / bg));
-    if (parts & 4)
-        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), k2::LDS_BYTES, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
+    if (parts & 4) {
+        static const int dkv_lds = [] {     // experiment: MGX_DKV_LDS pads the dynamic LDS to lower the residency (timing only)
+            const char* e = getenv("MGX_DKV_LDS");
+            const int v = e ? atoi(e) : 0;
+            if (v > k2::LDS_BYTES) hipFuncSetAttribute((const void*)rel_attn_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
+            return v > k2::LDS_BYTES ? v : k2::LDS_BYTES;
+        }();
+        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), dkv_lds, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
+    }
     if (parts & 2)
         hipLaunchKernelGGL(rel_attn_dq_lite_kernel, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, L, d, bg);
     if (parts & 32)
