@@ -34,7 +34,10 @@ import torch  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
-CFG2 = dict(vocab=337, layers=6, d_model=512, seq_len=2048)
+CFG2 = dict(vocab=337, layers=6, d_model=512, seq_len=2048, batch=64)
+# BASELINE configs[3]: MuMIDI_EventSeq multi-track (V = 485 + pad), 12 layers, d_model 768 (12 heads), seq_len 4096, DP=8; its
+# single-GPU share is per-GPU batch 4
+CFG4 = dict(vocab=486, layers=12, d_model=768, seq_len=4096, batch=4)
 
 
 def train_flops_per_event(nl, d, L, V):
@@ -54,12 +57,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling); rounds 1-3 were quoted at 32, which "
+    ap.add_argument("--workload", choices=("cfg2", "cfg4"), default="cfg2", help="cfg2 (default): BASELINE configs[1], the metric's "
+                    "workload.  cfg4: BASELINE configs[3] at its single-GPU share (MuMIDI V=486, 12 layers, d=768, L=4096, batch 4) as "
+                    "the main line -- for profiling; the default run already reports it in its `cfg4` block")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4 block (N=1 only)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); rounds 1-3 were quoted at 32, which "
                     "reads about 2 %% lower on the same box (profiles/README.md)")
-    ap.add_argument("--seq-len", type=int, default=CFG2["seq_len"])
-    ap.add_argument("--d-model", type=int, default=CFG2["d_model"])
-    ap.add_argument("--layers", type=int, default=CFG2["layers"])
-    ap.add_argument("--vocab", type=int, default=CFG2["vocab"])
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--d-model", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--vocab", type=int, default=None)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -71,7 +78,13 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "rehearsing the data-parallel path with several ranks on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="all ranks use cuda:0 (rehearsal with --backend gloo)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    base = CFG4 if a.workload == "cfg4" else CFG2
+    for k, dflt in (("batch", base["batch"]), ("seq_len", base["seq_len"]), ("d_model", base["d_model"]),
+                    ("layers", base["layers"]), ("vocab", base["vocab"])):
+        if getattr(a, k) is None:
+            setattr(a, k, dflt)
+    return a
 
 
 def time_kernels(B, L, d, M, reps=10):
@@ -225,6 +238,55 @@ def decode_bench(args):
                                  "tokens_per_s": Bd * steps / dtg, "ms_per_step": 1e3 * dtg / steps,
                                  "weight_bytes_per_step": gru_w_bytes, "achieved_gbs": gru_w_bytes * steps / dtg / 1e9,
                                  "bound": "launch latency (weights are 9.4 MB: 1.2 us at the HBM peak)"}}
+
+
+def cfg4_block(args, steps=6, warmup=3):
+    """BASELINE configs[3] at its single-GPU share (MuMIDI V=486, 12 layers, d_model=768 = 12 heads, L=4096, per-GPU
+    batch 4): the same training step as the main line, a short run beside it.  Events/s, the model-level fraction of the bf16
+    MFMA peak in algorithmic FLOPs, and the attention kernels' launch times at this shape."""
+    from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
+    from musicgeneration_amd.metrics import CategoricalAccuracy, LogitsBucketting, MetricsSet
+    from musicgeneration_amd.network import MusicTransformer
+    from musicgeneration_amd.optim import FusedAdam
+    V, nl, d, L, B = CFG4["vocab"], CFG4["layers"], CFG4["d_model"], CFG4["seq_len"], CFG4["batch"]
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=args.dropout).to(dev).train()
+    opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9)
+    sch = CustomSchedule(d, optimizer=opt)
+    ms = MetricsSet({"accuracy": CategoricalAccuracy(), "loss": SmoothCrossEntropyLoss(0.1, V, V - 1), "bucket": LogitsBucketting(V)})
+    gen = torch.Generator().manual_seed(4321)
+    ring = []
+    for _ in range(2):
+        xf = torch.randint(0, V - 1, (B, L + 1), generator=gen)
+        ring.append((xf[:, :-1].to(torch.int32).contiguous().to(dev), xf[:, 1:].to(torch.int32).contiguous().to(dev)))
+    last = None
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        x, y = ring[i % 2]
+        last = ms(mt(x), y)
+        last["loss"].backward()
+        sch.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mt.check_pads_trail()
+    value = B * L * steps / dt
+    out = {"workload": f"cfg4 at its single-GPU share: MuMIDI_EventSeq MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} bf16, "
+                       f"per-GPU batch {B}, fwd+smoothed-CE+bwd+Adam/Noam, dropout {args.dropout}",
+           "value": value, "unit": "events/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+           "final_loss": float(last["loss"].item()), "train_mflop_per_event": train_flops_per_event(nl, d, L, V) / 1e6,
+           "model_mfma_frac": value * train_flops_per_event(nl, d, L, V) / (PEAK_BF16_TFLOPS * 1e12)}
+    del mt, opt, sch, ring, last
+    torch.cuda.empty_cache()
+    if not args.no_kernel_timing:
+        kt = time_kernels(B, L, d, L)
+        out["kernel_ms"] = kt
+        out["attention_all_kernels"] = {"ms_per_layer": sum(kt.values()),
+                                        "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12}
+    return out
 
 
 def pmc_traffic(kernel, B, L, d):
@@ -392,16 +454,18 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    mt.check_pads_trail()      # device-side pads-only-trail record of every forward above (read after the timed region)
     events = float(world) * B * L * args.steps
     value = events / dt
     loss_val = float(last["loss"].item())
 
     out = {
-        "metric": "training events/sec (whole node), REMI seq_len=2048",
+        "metric": "training events/sec (whole node), REMI seq_len=2048" if args.workload == "cfg2"
+                  else "training events/sec (whole node), MuMIDI seq_len=4096 (BASELINE configs[3]; NOT the headline metric)",
         "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"cfg2 REMI_EventSeq MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} "
+        "config": {"workload": f"{'cfg2 REMI_EventSeq' if args.workload == 'cfg2' else 'cfg4 MuMIDI_EventSeq'} MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} "
                                f"bf16, fwd+smoothed-CE+bwd+Adam/Noam, dropout {args.dropout}",
                    "global_batch": world * B, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
                    "final_loss": loss_val},
@@ -456,6 +520,10 @@ def main():
             "ms_per_layer": sum(kt.values()),
             "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12,
             "executed_tflops": attn_flops_per_launch(B, L, d, 12.25) / (sum(kt.values()) * 1e-3) / 1e12}
+    if rank == 0 and world == 1 and not args.no_cfg4 and args.workload == "cfg2":
+        del mt, opt, sch, ring, last
+        torch.cuda.empty_cache()
+        out["cfg4"] = cfg4_block(args)
     if rank == 0 and world == 1 and not args.no_decode:
         out["decode"] = decode_bench(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -35,7 +35,7 @@ typedef enum {
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
 int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows */
-#define MGX_ABI_VERSION 15
+#define MGX_ABI_VERSION 16
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -51,8 +51,12 @@ int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dtable,
                   int B, int L, int d, int V, float p_drop, uint64_t seed, void* stream);
 
 /* ---- A3: key-padding bitmap from tokens                          utils.py:58-83 --------------
- * bits uint32 [B, L/32]: bit (j&31) of word j>>5 set iff tok[b,j] == pad.  L % 32 == 0.         */
-int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, int B, int L, int pad, void* stream);
+ * bits uint32 [B, L/32]: bit (j&31) of word j>>5 set iff tok[b,j] == pad.  L % 32 == 0.
+ * flag (ABI 16; device uint32[1] or NULL): bit 0 is OR-ed in, and never cleared, when some pad token is followed by a real
+ *   token in its row.  Padding may only TRAIL a sequence: a query whose visible keys are all padding has no defined result
+ *   in the reference (softmax of -1e9 + x in fp32, layers.py:99-102) and is outside the parity contract, so the host side
+ *   reads this flag at its next synchronisation point and refuses such input (no host sync on the hot path).            */
+int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, uint32_t* flag, int B, int L, int pad, void* stream);
 
 /* ---- K3+K4: fused relative global attention (Shaw/Huang skewing)  layers.py:86-106,111-133 ---
  * qkv bf16 [B,L,3d]: columns [0,d)=Q, [d,2d)=K, [2d,3d)=V, head hd at columns hd*64..hd*64+63
@@ -128,11 +132,13 @@ int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res,
  * row_lse f32 [rows] is saved for the backward.                                               */
 int mgx_smooth_ce_fwd(const uint16_t* logits, const int32_t* target, float* stats, int32_t* argmax,
                       float* row_lse, int rows, int V, int ld, float eps_ls, int pad, void* stream);
-/* dlogits bf16 [rows,ld] (columns >= V written as 0) = gscale/stats[1] * (softmax - q') for target!=pad rows, else 0.
- * stats is read on the device (no host sync); gscale is the upstream gradient (1/accum).       */
+/* dlogits bf16 [rows,ld] (columns >= V written as 0) = g/stats[1] * (softmax - q') for target!=pad rows, else 0, where
+ * g = gscale * (gscale_dev ? *gscale_dev : 1): the upstream gradient of the scalar loss -- a host constant (1/accum) times,
+ * optionally, a device-side f32 scalar (autograd's grad_output, the data-parallel loss weight): both are read on the device,
+ * as stats is (no host sync, no extra elementwise pass over dlogits) (ABI 16).                    */
 int mgx_smooth_ce_bwd(const uint16_t* logits, const int32_t* target, const float* stats,
                       const float* row_lse, uint16_t* dlogits, int rows, int V, int ld,
-                      float eps_ls, int pad, float gscale, void* stream);
+                      float eps_ls, int pad, float gscale, const float* gscale_dev, void* stream);
 
 /* ---- K11: Adam over one flat fp32 parameter buffer                train.py:143, criterion.py:81-87
  * p,g,m,v f32 [n]; shadow bf16 [n] (the bf16 copy the GEMMs/attention read) written in the same
@@ -164,7 +170,8 @@ int mgx_decode_embed_linear(const int32_t* tok, const float* table, const float*
 /* The three decode-size projections with the weight in MFMA FRAGMENT ORDER (see the fused GRU step below for the layout; rows
  * zero-padded to a multiple of 32): a wave load of weights is 1 KB contiguous instead of 32 bytes of 32 different rows.   */
 int mgx_skinny_fwd_frag(const uint16_t* A, const uint16_t* Wf, const float* bias, uint16_t* C, int M, int N, int K, int act,
-                        void* stream);                                    /* M <= 32; = mgx_linear_fwd otherwise */
+                        void* stream);                                    /* M <= 32 only: MGX_ERR_SHAPE otherwise (a fragment-ordered
+                                                                           * weight must never reach mgx_linear_fwd) */
 int mgx_linear_ln_fwd_frag(const uint16_t* X, const uint16_t* RES, const float* gamma, const float* beta, float eps,
                            const uint16_t* Wf, const float* bias, uint16_t* C, uint16_t* Z, int M, int N, int K, int act,
                            void* stream);

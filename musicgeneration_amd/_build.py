@@ -6,7 +6,10 @@ with the source tree (it is git-ignored, not gpurun-ignored).
 `python -m musicgeneration_amd._build [--force]` builds the product library.
 `python -m musicgeneration_amd._build --variant NAME -DMACRO[=v] ...` builds `libmgx_NAME.so` beside it with extra
 macros: the timing-only "peel" / in-kernel "stamp" builds the profile notes quote are made this way, from the
-tracked sources, and loaded with `MGX_LIB_PATH=musicgeneration_amd/libmgx_NAME.so` (tools/variants.sh)."""
+tracked sources, and loaded with `MGX_LIB_PATH=musicgeneration_amd/libmgx_NAME.so` (tools/peel_*.sh, tools/ab.sh).
+`--experiments` additionally compiles the alternative kernels kept under tools/experiments/ (two forward-attention
+structures that measured slower) and defines MGX_EXPERIMENTS=1, which is also what enables the environment knobs
+(MGX_ATTN_FWD64, MGX_FWD_LDS, MGX_DKV_LDS, MGX_ATTN_BGROUP): the product library reads none of them."""
 from __future__ import annotations
 
 import fcntl
@@ -19,8 +22,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgx.so")
-SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_fwd2.hip", "rel_attn_fwd3.hip", "rel_attn_bwd.hip", "linear.hip", "decode.hip",
-           "gru_train.hip"]
+SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_bwd.hip", "linear.hip", "decode.hip", "gru_train.hip"]
+EXPERIMENT_DIR = os.path.join(ROOT, "tools", "experiments")
+EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip"]      # --experiments builds only
 # per-file flags.  The 64-rows-per-wave attention kernels run one wave per SIMD with the whole 512-entry register file:
 # MFMA results that VALU code reads (scores) must stay in arch VGPRs (with more than 256 registers available hipcc otherwise
 # gives every MFMA an AGPR destination and copies each result out), and the SLP vectoriser must not pair the two blocks'
@@ -52,15 +56,19 @@ def _stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile_and_link(lib: str, objdir: str, defines, verbose: bool) -> None:
+def _compile_and_link(lib: str, objdir: str, defines, verbose: bool, experiments: bool = False) -> None:
     hipcc = _hipcc()
     os.makedirs(objdir, exist_ok=True)
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
               "-I" + CSRC, "-Wno-unused-value", "-Wno-unused-result"] + list(defines)
     objs, procs = [], []
     pid = os.getpid()
-    for src in SOURCES:
-        sp = os.path.join(CSRC, src)
+    if experiments:
+        common.append("-DMGX_EXPERIMENTS=1")
+    todo = [(s_, os.path.join(CSRC, s_)) for s_ in SOURCES]
+    if experiments:
+        todo += [(s_, os.path.join(EXPERIMENT_DIR, s_)) for s_ in EXPERIMENT_SOURCES]
+    for src, sp in todo:
         if not os.path.exists(sp):
             continue
         # pid-unique object names: two processes that get past the lock in turn never share a half-written object
@@ -89,10 +97,12 @@ def _compile_and_link(lib: str, objdir: str, defines, verbose: bool) -> None:
                 os.remove(o)
 
 
-def build(force: bool = False, verbose: bool = False, variant: str | None = None, defines=()) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str | None = None, defines=(), experiments: bool = False) -> str:
     """Compile every source in csrc/ for gfx950 and link libmgx.so (or libmgx_<variant>.so with extra -D macros).
     Returns the library path.  Safe to call from several processes at once (torchrun ranks, bench.py's self-launch):
     the stale check and the build run under an exclusive file lock, and a rank that waited finds the library fresh."""
+    if experiments and not variant:
+        raise ValueError("--experiments needs --variant NAME: the product library is built without the experiment kernels")
     lib = LIB if not variant else os.path.join(PKG, f"libmgx_{variant}.so")
     if not force and not variant and not _stale(lib):
         return lib
@@ -102,7 +112,7 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
             if force or variant or _stale(lib):          # re-check: another process may have built it while we waited
-                _compile_and_link(lib, objdir, defines, verbose)
+                _compile_and_link(lib, objdir, defines, verbose, experiments)
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
     return lib
@@ -111,4 +121,5 @@ def build(force: bool = False, verbose: bool = False, variant: str | None = None
 if __name__ == "__main__":
     argv = sys.argv[1:]
     var = argv[argv.index("--variant") + 1] if "--variant" in argv else None
-    print(build(force="--force" in argv, verbose="-v" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")]))
+    print(build(force="--force" in argv, verbose="-v" in argv, variant=var, defines=[a for a in argv if a.startswith("-D")],
+                experiments="--experiments" in argv))

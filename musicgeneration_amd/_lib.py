@@ -13,7 +13,7 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 # the ABI the SIGNATURES table below was written for (MGX_ABI_VERSION of include/mgx.h).  A left-over
 # libmgx.so of another ABI still exports the same names: calling it with this table would shift arguments.
-EXPECTED_ABI = 15
+EXPECTED_ABI = 16
 
 # name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
 SIGNATURES = {
@@ -21,7 +21,7 @@ SIGNATURES = {
     "mgx_device_count": [],
     "mgx_embed_pe_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
-    "mgx_pad_bitmap": [_vp, _vp, _i, _i, _i, _vp],
+    "mgx_pad_bitmap": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_rel_attn_fwd_workspace": [_i],                  # returns size_t
     "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_fwd_nomask": [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
@@ -33,7 +33,7 @@ SIGNATURES = {
     "mgx_add_ln_bwd_workspace": [_i, _i],                 # returns size_t
     "mgx_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _f, _u64, _vp],
     "mgx_smooth_ce_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
-    "mgx_smooth_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp],
+    "mgx_smooth_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _vp, _vp],
     "mgx_adam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp],
     "mgx_cast_bf16": [_vp, _vp, _sz, _vp],
     "mgx_linear_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -25,9 +25,11 @@
 
 using namespace relattn;
 
+#ifndef MGX_EXPERIMENTS
+#define MGX_EXPERIMENTS 0   // see rel_attn_fwd.hip
+#endif
 namespace {
 constexpr int WAVES = 4;
-constexpr int E_SLOTS = 6;
 }  // namespace
 
 // ================================================================================================
@@ -1167,8 +1169,10 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
 static int bwd_batch_group(int B, int L, int d) {
     const double per_row = (double)L * d * 2 * 5;
     int g = B;
+#if MGX_EXPERIMENTS
     static const int forced = [] { const char* e = getenv("MGX_ATTN_BGROUP"); return e ? atoi(e) : 0; }();   // experiment knob
     if (forced > 0 && B % forced == 0) return forced;
+#endif
     while (g > 1 && (g * per_row > 110e6 || B % g != 0)) --g;
     return g;
 }
@@ -1224,12 +1228,16 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
     const dim3 gq(bg * heads, ((L + 127) / 128) * (B / bg));
     if (parts & 4) {
+#if MGX_EXPERIMENTS
         static const int dkv_lds = [] {     // experiment: MGX_DKV_LDS pads the dynamic LDS to lower the residency (timing only)
             const char* e = getenv("MGX_DKV_LDS");
             const int v = e ? atoi(e) : 0;
             if (v > k2::LDS_BYTES) hipFuncSetAttribute((const void*)rel_attn_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
             return v > k2::LDS_BYTES ? v : k2::LDS_BYTES;
         }();
+#else
+        constexpr int dkv_lds = k2::LDS_BYTES;
+#endif
         hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), dkv_lds, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
     }
     if (parts & 2)

@@ -215,9 +215,10 @@ static inline void launch_er_frag(const uint16_t* Er, u32x4* EfA, u32x4* EfT, in
     hipLaunchKernelGGL(er_frag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Er, EfA, EfT, L);
 }
 
+// experiment builds only (tools/experiments/rel_attn_fwd2.hip, rel_attn_fwd3.hip; MGX_EXPERIMENTS)
 int fwd64_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, uint16_t* ctx, float* lse, int B, int L, int d,
-                 void* stream);   // rel_attn_fwd2.hip
+                 void* stream);
 int fwdpp_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, uint16_t* ctx, float* lse, int B, int L, int d,
-                 void* stream);   // rel_attn_fwd3.hip
+                 void* stream);
 
 }  // namespace relattn

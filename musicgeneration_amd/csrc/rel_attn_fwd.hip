@@ -35,6 +35,9 @@
 
 using namespace relattn;
 
+#ifndef MGX_EXPERIMENTS
+#define MGX_EXPERIMENTS 0   // 1 (experiment builds only): environment knobs that change which kernel runs / its residency, and the two
+#endif                      // alternative forward kernels of tools/experiments/.  The product library reads no environment variable here.
 #ifndef MGX_FWD_AHEAD
 #define MGX_FWD_AHEAD 0   // 1: main loop with the Q.Er^T product one step ahead of its tile (experiment: 0.567-0.569 ms against 0.562-0.563
                           // at cfg2 batch 64 -- with three waves per SIMD the shorter per-wave chain buys nothing; 168 VGPRs, 2 spilled)
@@ -407,8 +410,10 @@ extern "C" size_t mgx_rel_attn_fwd_workspace(int L) { return L > 0 ? er_frag_byt
 static int batch_group(int B, int L, int d) {
     const double per_row = (double)L * d * 2 * 4;
     int g = B;
+#if MGX_EXPERIMENTS
     static const int forced = [] { const char* e = getenv("MGX_ATTN_BGROUP"); return e ? atoi(e) : 0; }();   // experiment knob
     if (forced > 0 && B % forced == 0) return forced;
+#endif
     while (g > 1 && (g * per_row > 110e6 || B % g != 0)) --g;
     return g;
 }
@@ -429,21 +434,27 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
     if (int rc = fwd_common_checks("mgx_rel_attn_fwd", workspace, ws_bytes, B, L, d, M)) return rc;
     set_fwd_attrs();
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
-    // L % 256 == 0: MGX_ATTN_FWD64 = 2 the ping-pong kernel (rel_attn_fwd3.hip), 1 the 64-rows-per-wave kernel
-    // (rel_attn_fwd2.hip), 0 this file's 32-row kernel
+#if MGX_EXPERIMENTS
+    // experiment builds only (`_build.py --variant NAME --experiments`, tools/experiments/): for L % 256 == 0, MGX_ATTN_FWD64 = 2
+    // selects the ping-pong kernel (rel_attn_fwd3.hip), 1 the 64-rows-per-wave kernel (rel_attn_fwd2.hip); both measured slower
     if (L % 256 == 0) {
         const int mode = env_digit("MGX_ATTN_FWD64", 0);
         if (mode == 2) return fwdpp_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
         if (mode == 1) return fwd64_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
     }
+#endif
     const int bg = batch_group(B, L, d);
     dim3 grid(bg * (d / 64), ((L + 127) / 128) * (B / bg));
+#if MGX_EXPERIMENTS
     static const int occ_lds = [] {        // experiment: MGX_FWD_LDS pads the dynamic LDS to lower the residency (timing only)
         const char* e = getenv("MGX_FWD_LDS");
         const int v = e ? atoi(e) : 0;
         if (v > LDS_BYTES) hipFuncSetAttribute((const void*)rel_attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, v);
         return v > LDS_BYTES ? v : LDS_BYTES;
     }();
+#else
+    constexpr int occ_lds = LDS_BYTES;
+#endif
     hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), occ_lds, (hipStream_t)stream, qkv,
                        (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d, bg);
     MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");

@@ -127,7 +127,8 @@ extern "C" int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dt
 // =================================================================================================
 // A3  key-padding bitmap                                                     utils.py:73-77
 // =================================================================================================
-__global__ void pad_bitmap_kernel(const int32_t* __restrict__ tok, uint32_t* __restrict__ bits, int total, int pad) {
+__global__ void pad_bitmap_kernel(const int32_t* __restrict__ tok, uint32_t* __restrict__ bits, uint32_t* __restrict__ flag,
+                                  int total, int L, int pad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one thread per token, 64 | blockDim
     const bool p = (i < total) && (tok[i] == pad);
     const unsigned long long m = __ballot(p);
@@ -136,13 +137,15 @@ __global__ void pad_bitmap_kernel(const int32_t* __restrict__ tok, uint32_t* __r
         if (lane == 0) bits[i >> 5] = (uint32_t)m;
         if (lane == 32) bits[i >> 5] = (uint32_t)(m >> 32);
     }
+    // padding may only TRAIL a row: a pad followed by a real token raises the sticky flag
+    if (flag && p && (i % L) != L - 1 && tok[i + 1] != pad) atomicOr(flag, 1u);
 }
-extern "C" int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, int B, int L, int pad, void* stream) {
+extern "C" int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, uint32_t* flag, int B, int L, int pad, void* stream) {
     MGX_REQUIRE(tok && bits, MGX_ERR_NULL, "mgx_pad_bitmap: NULL pointer");
     MGX_REQUIRE(B > 0 && L > 0 && L % 32 == 0, MGX_ERR_SHAPE, "mgx_pad_bitmap: need L%%32==0 (got L=%d)", L);
     const int total = B * L;
-    hipLaunchKernelGGL(pad_bitmap_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, bits,
-                       total, pad);
+    hipLaunchKernelGGL(pad_bitmap_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, bits, flag,
+                       total, L, pad);
     MGX_CHECK_LAUNCH("mgx_pad_bitmap");
     return MGX_OK;
 }
@@ -499,12 +502,12 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
 __global__ __launch_bounds__(256) void smooth_ce_bwd_kernel(
     const uint16_t* __restrict__ logits, const int32_t* __restrict__ target, const float* __restrict__ stats,
     const float* __restrict__ row_lse, uint16_t* __restrict__ dlogits, int rows, int V, int ld, float eps_ls,
-    int pad, float gscale) {
+    int pad, float gscale, const float* __restrict__ gscale_dev) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
     const float cnt = stats[1];
-    const float sc = gscale / cnt;
+    const float sc = (gscale_dev ? gscale * gscale_dev[0] : gscale) / cnt;
     const float u = eps_ls / (float)V;
     for (int r = wave; r < rows; r += nwave) {
         const uint16_t* lp = logits + (size_t)r * ld;
@@ -537,14 +540,14 @@ extern "C" int mgx_smooth_ce_fwd(const uint16_t* logits, const int32_t* target, 
 }
 extern "C" int mgx_smooth_ce_bwd(const uint16_t* logits, const int32_t* target, const float* stats,
                                  const float* row_lse, uint16_t* dlogits, int rows, int V, int ld, float eps_ls,
-                                 int pad, float gscale, void* stream) {
+                                 int pad, float gscale, const float* gscale_dev, void* stream) {
     MGX_REQUIRE(logits && target && stats && row_lse && dlogits, MGX_ERR_NULL, "mgx_smooth_ce_bwd: NULL pointer");
     MGX_REQUIRE(rows > 0 && V > 0 && ld >= V, MGX_ERR_SHAPE, "mgx_smooth_ce_bwd: need ld>=V (rows=%d V=%d ld=%d)",
                 rows, V, ld);
     int grid = (rows + 3) / 4;
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(smooth_ce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
-                       row_lse, dlogits, rows, V, ld, eps_ls, pad, gscale);
+                       row_lse, dlogits, rows, V, ld, eps_ls, pad, gscale, gscale_dev);
     MGX_CHECK_LAUNCH("mgx_smooth_ce_bwd");
     return MGX_OK;
 }

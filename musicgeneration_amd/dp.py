@@ -22,8 +22,9 @@ class DataParallel:
 
     def __init__(self, model, process_group=None, force_collectives: bool = False):
         """``force_collectives``: issue every collective even in a world of one rank (broadcast, per-bucket all-reduce,
-        loss-weight all-reduce).  A sum over one rank is the identity, so results must be bit-identical to a run without
-        data parallelism -- which lets a single-GPU box prove RCCL communicator setup, stream ordering against the backward
+        loss-weight all-reduce).  A sum over one rank is the identity, so results must equal a run without data
+        parallelism up to the summation-order noise of the kernels' own fp32 atomics (bit-identical under
+        MGX_DETERMINISTIC=1) -- which lets a single-GPU box prove RCCL communicator setup, stream ordering against the backward
         kernels and the flat-buffer views before the first multi-GPU run (tests/test_gpu_dp.py)."""
         self.model = model
         self.pg = process_group

@@ -49,6 +49,22 @@ def _captured(ws, key, body, use_graph):
     g.replay()
 
 
+class _WsLease:
+    """Marks one sequence-buffer set as holding the saved activations of a forward whose backward has not run.  Released by
+    that backward, or when autograd frees the graph (the ctx drops its reference), whichever comes first."""
+
+    def __init__(self, ws):
+        self.ws = ws
+        ws["busy"] = True
+
+    def release(self):
+        if self.ws is not None:
+            self.ws["busy"] = False
+            self.ws = None
+
+    __del__ = release
+
+
 class _GRUSeq(torch.autograd.Function):
     """Teacher-forced multi-layer GRU + output projection over a whole sequence (network.py:63-84 SeqForward with the
     primary step folded in as step 0), forward and backward-through-time on the libmgx kernels.
@@ -62,7 +78,7 @@ class _GRUSeq(torch.autograd.Function):
     (``mgx_gru_step_bwd``: d_rec = dgh_{t+1} W_hh, then the cell backward), weight gradients batched over the sequence."""
 
     @staticmethod
-    def forward(ctx, tokens, h0, pk, ws, p_drop, seed, *params):
+    def forward(ctx, tokens, h0, pk, ws, p_drop, seed, want_grad, *params):
         T, B = tokens.shape
         nl, H = h0.shape[0], h0.shape[2]
         dev = h0.device
@@ -70,7 +86,8 @@ class _GRUSeq(torch.autograd.Function):
         x = torch.empty(T * B, pk["Ep"], dtype=BF16, device=dev)
         check(_load().mgx_gather_rows(ptr(tok), ptr(pk["emb"]), ptr(x), T * B, pk["Ep"], pk["emb"].shape[0], stream_ptr()),
               "mgx_gather_rows")
-        ws["gen"] += 1
+        # a grad-enabled forward leases the buffer set until its backward (Train hands out a set that is not leased)
+        lease = _WsLease(ws) if want_grad else None       # (grad mode is always off INSIDE a Function.forward)
         xs = []
         for l, ly in enumerate(pk["layers"]):
             wl = ws["layers"][l]
@@ -88,7 +105,7 @@ class _GRUSeq(torch.autograd.Function):
             if l < nl - 1:
                 x = ops.dropout_bf16(x, p_drop, seed + l)
         logits = ops.linear_fwd(x, pk["wo"], pk["bo"], 0)
-        ctx.pk, ctx.ws, ctx.gen, ctx.xs = pk, ws, ws["gen"], xs
+        ctx.pk, ctx.ws, ctx.lease, ctx.xs = pk, ws, lease, xs
         ctx.cfg, ctx.x_last, ctx.tok = (T, B, H, nl, p_drop, seed), x, tok
         ctx.shapes = [p.shape for p in params]
         V = params[0].shape[0]
@@ -97,9 +114,9 @@ class _GRUSeq(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         pk, ws = ctx.pk, ctx.ws
-        if ws["gen"] != ctx.gen:
-            raise RuntimeError("Event_Melody_RNN.Train: the sequence buffers of this forward were overwritten by a later Train() "
-                               "call with the same shape; call backward() before the next forward")
+        if ctx.lease is None or ctx.lease.ws is not ws:
+            raise RuntimeError("Event_Melody_RNN.Train: backward through a forward that ran without gradients enabled, or twice "
+                               "through the same forward (its sequence buffers have been handed back)")
         T, B, H, nl, p_drop, seed = ctx.cfg
         dev = dlogits.device
         V, Vp = ctx.shapes[0][0], pk["wo"].shape[0]
@@ -144,7 +161,8 @@ class _GRUSeq(torch.autograd.Function):
             grads += [g_wih[:, : ctx.shapes[1 + 4 * l][1]], g_whh, g_bih, g_bhh]
         grads += [g_wo[:V], g_bo[:V]]
         ctx.xs = None
-        return (None, dh0, None, None, None, None) + tuple(grads)
+        ctx.lease.release()
+        return (None, dh0, None, None, None, None, None) + tuple(grads)
 
 
 class _GruState:
@@ -229,21 +247,31 @@ class Event_Melody_RNN(nn.Module):
         return pk
 
     def _train_workspace(self, pk, T, B):
-        """sequence buffers of Train for one (T, B) -- they cross the boundary of the captured time loops, so they must keep
-        their addresses between calls -- and the hipGraphs of those loops.  At most eight shapes are kept."""
+        """Sequence buffers of Train for one (T, B) -- they cross the boundary of the captured time loops, so they must keep
+        their addresses between calls -- and the hipGraphs of those loops.  A buffer set holds the saved activations of a
+        forward until its backward has run (``_WsLease``), so a second forward of the same shape before that backward --
+        ``(loss1 + loss2).backward()``, an evaluation between forward and backward -- gets ANOTHER set: up to three per shape
+        are kept (each with its own graphs); beyond that a throw-away set with eager launches is used.  Calls under
+        ``no_grad`` take any free set and lease nothing.  At most eight shapes are kept."""
         import os
         cache = self._train_ws
-        ws = cache.get((T, B))
-        if ws is None:
+        sets = cache.get((T, B))
+        if sets is None:
             if len(cache) >= 8:
                 cache.pop(next(iter(cache)))
-            dev, H = pk["dev"], self.hidden_dim
-            mk = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
-            ws = {"gen": 0, "graphs": {}, "use_graph": os.environ.get("MGX_GRU_GRAPH", "1") != "0", "layers": [
-                dict(gi=mk(T, B, 3 * H), gh=mk(T, B, 3 * H), h_all=mk(T + 1, B, H, dt=torch.float32), hp=mk(T + 1, B, H),
-                     dgi=mk(T, B, 3 * H), dgh=mk(T, B, 3 * H), dy=mk(T, B, H), dh=mk(2, B, H, dt=torch.float32),
-                     dh0=mk(B, H, dt=torch.float32)) for _ in range(self.rnn_layers)]}
-            cache[(T, B)] = ws
+            sets = cache[(T, B)] = []
+        for ws in sets:
+            if not ws["busy"]:
+                return ws
+        dev, H = pk["dev"], self.hidden_dim
+        mk = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)
+        keep = len(sets) < 3
+        ws = {"busy": False, "graphs": {}, "use_graph": keep and os.environ.get("MGX_GRU_GRAPH", "1") != "0", "layers": [
+            dict(gi=mk(T, B, 3 * H), gh=mk(T, B, 3 * H), h_all=mk(T + 1, B, H, dt=torch.float32), hp=mk(T + 1, B, H),
+                 dgi=mk(T, B, 3 * H), dgh=mk(T, B, 3 * H), dy=mk(T, B, H), dh=mk(2, B, H, dt=torch.float32),
+                 dh0=mk(B, H, dt=torch.float32)) for _ in range(self.rnn_layers)]}
+        if keep:
+            sets.append(ws)
         return ws
 
     # ---- reference API ------------------------------------------------------------------------------
@@ -331,7 +359,7 @@ class Event_Melody_RNN(nn.Module):
         params += [self.output_fc.weight, self.output_fc.bias]
         seed = (torch.initial_seed() + 7919 * self._train_calls) & 0x7FFFFFFFFFFF
         ws = self._train_workspace(pk, tokens.shape[0], B)
-        return _GRUSeq.apply(tokens, hidden, pk, ws, p_drop, seed, *params)
+        return _GRUSeq.apply(tokens, hidden, pk, ws, p_drop, seed, torch.is_grad_enabled(), *params)
 
     @torch.no_grad()
     def generate(self, init, steps, events=None, greedy=1.0, temperature=1.0, teacher_forcing_ratio=1.0,

@@ -46,6 +46,7 @@ class MusicTransformer(torch.nn.Module):
         self._store: Optional[FlatStore] = None
         self._seed_ctr = 0
         self._dp = None                          # set by dp.DataParallel
+        self._pad_flag: Optional[torch.Tensor] = None   # device int32[1], sticky: a pad token was followed by a real one
 
     # ------------------------------------------------------------------------------------------
     # flat storage
@@ -79,8 +80,11 @@ class MusicTransformer(torch.nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _next_seed(self) -> int:
+        # under data parallelism every rank usually calls torch.manual_seed with the same value: the rank enters the seed, or
+        # all ranks would draw the same dropout masks for their (different) rows
         self._seed_ctr += 1
-        return (torch.initial_seed() * 1000003 + self._seed_ctr * 64) & 0x7FFFFFFFFFFFFFFF
+        rank = self._dp.rank if self._dp is not None else 0
+        return ((torch.initial_seed() + 0x9E3779B9 * rank) * 1000003 + self._seed_ctr * 64) & 0x7FFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------------------------------
     # the hot path: tokens -> logits                 network.py:37-39 + layers.py:223-233,152-161
@@ -102,7 +106,9 @@ class MusicTransformer(torch.nn.Module):
         done = ((lambda name: (lambda: dp.bucket_ready(name))) if (dp is not None and (dp.world > 1 or dp.force) and training)
                 else (lambda name: None))
 
-        padbits = ops.pad_bitmap(tok, self.pad_token)
+        if self._pad_flag is None or self._pad_flag.device != tok.device:
+            self._pad_flag = torch.zeros(1, dtype=torch.int32, device=tok.device)
+        padbits = ops.pad_bitmap(tok, self.pad_token, self._pad_flag)
         pe = self.Decoder.pos_encoding.table()
         P = st.params
         h = ops.embed_pe(tok, P["Decoder.embedding.weight"], pe, p, seed, st.g("Decoder.embedding.weight"),
@@ -146,6 +152,18 @@ class MusicTransformer(torch.nn.Module):
             out.append(lp)
         self._lp_store, self._lp = st, out
         return out
+
+    def check_pads_trail(self) -> None:
+        """The library-boundary twin of ``utils.check_pads_trail``: every ``forward`` lets the bitmap kernel record, on the
+        device, whether some pad token was followed by a real one (leading / interior padding: rows with fully masked queries,
+        outside the parity contract with the reference).  Reading the record is a device synchronisation,
+        so it is done here, on request -- train.py calls it where it prints metrics, bench.py after its timed region -- and
+        not inside ``forward``.  Raises ValueError and clears the record."""
+        if self._pad_flag is not None and int(self._pad_flag.item()) != 0:
+            self._pad_flag.zero_()
+            raise ValueError(f"a batch handed to MusicTransformer.forward had padding token {self.pad_token} followed by a "
+                             "real token: pads must only trail (leading / interior padding is outside the parity contract "
+                             "with the reference)")
 
     def forward(self, x, length=None, writer=None):
         if self.training or not self.infer:
@@ -260,15 +278,13 @@ class MusicTransformer(torch.nn.Module):
         # caches are head-major [B, h, total, 64]: the decode kernel's workgroup (b, h) streams one contiguous run
         kc = [torch.zeros(B, d // 64, total, 64, dtype=bf, device=dev) for _ in range(nl)]
         vc = [torch.zeros(B, d // 64, total, 64, dtype=bf, device=dev) for _ in range(nl)]
-        # ``groups`` (default 1, or MGX_DECODE_GROUPS): the batch rows as that many independent sub-batches, each with its own
+        # ``groups`` (default 1): the batch rows as that many independent sub-batches, each with its own
         # captured step graph replayed on its own stream.  Rows never interact and the sampler draws by (seed, step, GLOBAL
         # row), so the tokens do not depend on the grouping (tests/test_gpu_decode.py).  The point would be to let one
         # sub-batch's bandwidth-bound attention stream its caches while another's chain of ~40 small projections waits out
         # its launch latencies; measured at cfg5 (profiles/README.md, round 3) two hardware queues dispatch those chains
         # SLOWER than one does (0.75 ms/token at 2 groups, 0.48 at 3-4, 0.72 at 6, against 0.50-0.51 at 1), so it stays off.
-        if groups is None:
-            groups = int(os.environ.get("MGX_DECODE_GROUPS", "0")) or 1
-        G = max(1, min(int(groups), B))
+        G = max(1, min(int(groups or 1), B))
         cuts = [B * g // G for g in range(G + 1)]
         pos_all = torch.zeros(G, dtype=torch.int32, device=dev)
         tok = prior[:, 0].to(torch.int32).contiguous().to(dev)
@@ -420,6 +436,9 @@ class MusicTransformer(torch.nn.Module):
                             r.graph.replay()
                 for r in subs:
                     cur.wait_stream(r.stream)
+                # the graphs, their private pools and the side streams are locals: they must outlive the replays still in flight
+                for r in subs:
+                    r.stream.synchronize()
             else:
                 for p in range(remaining):
                     step(True)

@@ -30,12 +30,13 @@ def _need_cuda(*ts):
 # --------------------------------------------------------------------------------------------------
 # raw launchers (no autograd)
 # --------------------------------------------------------------------------------------------------
-def pad_bitmap(tok: torch.Tensor, pad: int) -> torch.Tensor:
-    """tok int32 [B,L] -> uint32 bitmap [B, L/32] (stored as int32)."""
-    _need_cuda(tok)
+def pad_bitmap(tok: torch.Tensor, pad: int, flag: torch.Tensor | None = None) -> torch.Tensor:
+    """tok int32 [B,L] -> uint32 bitmap [B, L/32] (stored as int32).  ``flag`` (int32[1] on the device, optional) gets bit 0
+    OR-ed in when a pad token is followed by a real token in its row (sticky; read it at a synchronisation point)."""
+    _need_cuda(tok, flag)
     B, L = tok.shape
     bits = torch.empty(B, L // 32, dtype=torch.int32, device=tok.device)
-    check(_lib.load().mgx_pad_bitmap(ptr(tok), ptr(bits), B, L, pad, stream_ptr()), "mgx_pad_bitmap")
+    check(_lib.load().mgx_pad_bitmap(ptr(tok), ptr(bits), ptr(flag), B, L, pad, stream_ptr()), "mgx_pad_bitmap")
     return bits
 
 
@@ -191,13 +192,18 @@ def smooth_ce_fwd(logits, target, V, eps_ls, pad):
     return stats, argmax, row_lse
 
 
-def smooth_ce_bwd(logits, target, stats, row_lse, V, eps_ls, pad, gscale=1.0):
+def smooth_ce_bwd(logits, target, stats, row_lse, V, eps_ls, pad, gscale=1.0, gscale_dev=None):
+    """gscale_dev: optional 0-d / 1-element f32 device tensor multiplied into the gradient inside the kernel"""
     _need_cuda(logits, target, stats, row_lse)
+    if gscale_dev is not None:
+        _need_cuda(gscale_dev)
+        if gscale_dev.dtype != torch.float32 or gscale_dev.numel() != 1:
+            raise ValueError("gscale_dev must be one float32 element")
     ld = logits.shape[-1]
     rows = logits.numel() // ld
     dlogits = torch.empty_like(logits)
     check(_lib.load().mgx_smooth_ce_bwd(ptr(logits), ptr(target), ptr(stats), ptr(row_lse), ptr(dlogits), rows, V, ld,
-                                        float(eps_ls), int(pad), float(gscale), stream_ptr()), "mgx_smooth_ce_bwd")
+                                        float(eps_ls), int(pad), float(gscale), ptr(gscale_dev), stream_ptr()), "mgx_smooth_ce_bwd")
     return dlogits
 
 
@@ -577,9 +583,8 @@ class _SmoothCE(torch.autograd.Function):
     def backward(ctx, gloss, _gs, _ga):
         logits, target, stats, row_lse = ctx.saved_tensors
         V, eps_ls, pad = ctx.cfg
-        # gloss is a 0-d device tensor: folding it in on the device avoids a host sync
-        dl = smooth_ce_bwd(logits, target, stats, row_lse, V, eps_ls, pad, 1.0)
-        dl = dl * gloss.to(dl.dtype)
+        # gloss is a 0-d device tensor: the kernel reads it on the device (no host sync, no second pass over dlogits)
+        dl = smooth_ce_bwd(logits, target, stats, row_lse, V, eps_ls, pad, 1.0, gloss.detach().to(torch.float32).contiguous())
         return dl, None, None, None, None
 
 

@@ -167,8 +167,6 @@ def main(argv=None):
             for b in range(nb):
                 try:
                     batch_x, batch_y = dataset.slide_seq2seq_batch(options.batch_size, options.max_seq)
-                    utils.check_pads_trail(batch_x, pad)                   # host-side, before the H2D copy
-                    batch_x, batch_y = to_dev(batch_x), to_dev(batch_y)
                 except (IndexError, ValueError):
                     # the reference swallows IndexError (train.py:261-262); a file of exactly max_seq+1 events raises
                     # ValueError from randrange instead.  Single process: skip like the reference.
@@ -176,6 +174,10 @@ def main(argv=None):
                         raise RuntimeError("a rank failed to draw a batch under data parallelism: the ranks would stop "
                                            "issuing the same collectives (dataset changed after the min_length filter?)")
                     continue
+                # host-side, before the H2D copy, and OUTSIDE the try above: its ValueError (which rows, why) must reach the user
+                # instead of being taken for a failed draw (skipped silently / reported as a rank mismatch under DP)
+                utils.check_pads_trail(batch_x, pad)
+                batch_x, batch_y = to_dev(batch_x), to_dev(batch_y)
                 mt.train()
                 last_micro = (b + 1) % options.accum_grad == 0
                 ctx = dp.no_sync() if (dp is not None and not last_micro) else _null()
@@ -194,6 +196,7 @@ def main(argv=None):
                 if options.max_batches and idx >= options.max_batches:
                     break
             eval_metrics = evaluate()
+            mt.check_pads_trail()        # the device-side record of the same guard (this is a synchronisation point anyway)
             if (e + 1) % options.saving_interval == 0:
                 save_model(e, eval_metrics['accuracy'])
             dt = time.time() - t_meter

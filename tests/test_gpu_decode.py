@@ -495,8 +495,9 @@ def test_gru_fused_step_kernels_match_the_two_kernel_path(B, H):
 
 def test_gru_train_graph_replay_equals_eager_and_survives_an_optimizer_step(monkeypatch):
     """Train's time loops replayed from hipGraphs give the same logits and gradients as the eager launches, and the graphs
-    stay valid after the parameters change (the bf16 operand copies are refreshed in place); a second forward before the
-    backward of the first is refused."""
+    stay valid after the parameters change (the bf16 operand copies are refreshed in place).  Forwards of the same shape before
+    the backward of an earlier one -- ``(loss1 + loss2).backward()``, an evaluation in between -- get their own sequence buffers
+    (the patterns the reference's nn.GRU allows): gradients equal the sum of two separate backward passes."""
     from musicgeneration_amd.melody_rnn import Event_Melody_RNN
     torch.manual_seed(3)
     V, H, B, T = 40, 64, 6, 9
@@ -528,10 +529,33 @@ def test_gru_train_graph_replay_equals_eager_and_survives_an_optimizer_step(monk
     net._train_ws = {}
     out_e2, _ = grads()
     assert torch.equal(out_e2, out_g2) and not torch.equal(out_e2, out_e)
+    monkeypatch.setenv("MGX_GRU_GRAPH", "1")
+    net._train_ws = {}
+    ev2 = torch.randint(0, V, (T, B), device="cuda")
+    sep = []
+    for e_ in (ev, ev2):
+        net.zero_grad()
+        (net.Train(init, e_).float() ** 2).mean().backward()
+        sep.append([p.grad.detach().clone() for p in net.parameters()])
+    net.zero_grad()
     o1 = net.Train(init, ev)
-    net.Train(init, ev)
-    with pytest.raises(RuntimeError, match="overwritten"):
-        o1.sum().backward()
+    with torch.no_grad():
+        ev_out = net.Train(init, ev2)                        # an evaluation between forward and backward: leases nothing
+    o2 = net.Train(init, ev2)                                # a second grad-enabled forward of the same shape: another buffer set
+    o3 = net.Train(init, ev)                                 # ... a third ...
+    o4 = net.Train(init, ev2)                                # ... and a fourth (beyond the kept sets: throw-away buffers, eager)
+    assert torch.equal(ev_out, o2.detach()) and torch.equal(o1.detach(), o3.detach()) and torch.equal(o2.detach(), o4.detach())
+    ((o1.float() ** 2).mean() + (o2.float() ** 2).mean()).backward()
+    for gsum, a, b in zip([p.grad for p in net.parameters()], sep[0], sep[1]):
+        assert torch.allclose(gsum, a + b, rtol=1e-4, atol=1e-6)
+    assert len(net._train_ws[(T + 1, B)]) == 3
+    del o3, o4                                               # never back-propagated: freeing the graph hands the buffers back
+    assert sum(w["busy"] for w in net._train_ws[(T + 1, B)]) == 0
+    with pytest.raises(RuntimeError, match="twice"):
+        out = net.Train(init, ev)
+        loss = out.sum()
+        loss.backward(retain_graph=True)
+        loss.backward()
 
 
 @pytest.mark.parametrize("B,H,Kx", [(32, 512, 320), (5, 64, 64), (40, 128, 192)])

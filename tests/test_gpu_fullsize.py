@@ -46,7 +46,8 @@ def test_cfg2_shape_forward_backward_vs_oracle():
     assert _cos(dE.cpu(), Er.grad) > 0.999 and _rel(dE.cpu(), Er.grad) < 2e-2
 
 
-@pytest.mark.parametrize("B,L,d", [(8, 2048, 512), (2, 4096, 768)])
+# (64, 2048, 512) is bench.py's default per-GPU shape: the first one whose dS workspace (2.18 GB) has byte offsets beyond 2^31
+@pytest.mark.parametrize("B,L,d", [(8, 2048, 512), (64, 2048, 512), (2, 4096, 768)])
 def test_full_batch_properties(B, L, d):
     from musicgeneration_amd import ops
     dev = torch.device("cuda")
@@ -112,13 +113,15 @@ def test_cfg2_model_step_is_finite_and_learns():
     assert losses[-1] < losses[0] - 0.2, losses
 
 
-def test_full_size_dE_two_ways_and_grouped_dW():
-    """At the bench's per-GPU shape (B=16 here, L=2048, d=512): the streamed dE (from the dS tiles the dK/dV kernel stores) equals
-    the full-recompute dE kernel, dQ from those tiles equals the recompute dQ kernel to bf16 rounding, and the grouped dW launch equals four separate launches -- independent implementations /
-    schedules of the same sums, agreeing to fp32 accumulation order."""
+@pytest.mark.parametrize("B", [16, 64])
+def test_full_size_dE_and_dQ_two_ways(B):
+    """At the bench's per-GPU shape (L=2048, d=512; B=64 is bench.py's default, its dS workspace passes 2^31 bytes): the dE from
+    the dS tiles the dK/dV kernel stores equals the full-recompute dE kernel, dQ from those tiles equals the recompute dQ kernel to
+    bf16 rounding -- independent implementations of the same sums -- and the LAST batch row's dq/dk/dv equal, bit for bit, a
+    batch-of-one call on that row alone (every per-row address, in particular the dS tile offsets, lands where it should)."""
     from musicgeneration_amd import ops
     dev = torch.device("cuda")
-    B, L, d = 16, 2048, 512
+    L, d = 2048, 512
     g = torch.Generator().manual_seed(99)
     qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.6).to(torch.bfloat16).to(dev)
     E = (torch.randn(L, 64, generator=g) * 0.3).to(torch.bfloat16).to(dev)
@@ -133,6 +136,21 @@ def test_full_size_dE_two_ways_and_grouped_dW():
     assert torch.equal(dq1[..., d:], dq2[..., d:])                                  # the same dK/dV kernel on the same inputs
     # two derivations of dS (the dK/dV kernel's and the recompute dQ kernel's own): equal up to the bf16 rounding of dS
     assert _rel(dq1[..., :d].float(), dq2[..., :d].float()) < 4e-3
+    # the last row alone
+    c1, l1 = ops.rel_attn_fwd(qkv[B - 1:].contiguous(), E, None)
+    assert torch.equal(c1[0], ctx[B - 1]) and torch.equal(l1[0], lse[B - 1])
+    dEl = torch.zeros(L, 64, device=dev)
+    dql = ops.rel_attn_bwd(qkv[B - 1:].contiguous(), E, None, c1, dctx[B - 1:].contiguous(), l1, dEl)
+    torch.cuda.synchronize()
+    assert torch.equal(dql[0], dq1[B - 1])
+
+
+def test_full_size_grouped_dW():
+    """the grouped dW launch equals four separate launches at the B=16 row count (fp32 accumulation order aside)"""
+    from musicgeneration_amd import ops
+    dev = torch.device("cuda")
+    B, L, d = 16, 2048, 512
+    g = torch.Generator().manual_seed(99)
     M = B * L
     shapes = [(3 * d, d), (d, d), (d // 2, d), (d, d // 2)]
     probs, sep = [], []

@@ -241,6 +241,14 @@ def test_smooth_ce_golden_and_random(golden_dir):
         dl = ops.smooth_ce_bwd(lb.to(dev), tg.to(torch.int32).to(dev), s2, rl, V, eps, pad, 1.0)
         assert _relerr(dl.cpu(), ref_in.grad) < 1e-2
         assert (dl.float().cpu() - ref_in.grad).abs().max().item() <= 1e-2 * ref_in.grad.abs().max().item()
+        # the upstream gradient as host constant x device scalar (ABI 16): read inside the kernel, no pass over dlogits
+        dl3 = ops.smooth_ce_bwd(lb.to(dev), tg.to(torch.int32).to(dev), s2, rl, V, eps, pad, 0.5, torch.tensor(3.0, device=dev))
+        assert _relerr(dl3.cpu(), 1.5 * ref_in.grad) < 1e-2
+        # ... which is how autograd's grad_output reaches it
+        lg_dev = lb.to(dev).requires_grad_(True)
+        loss2, _, _ = ops.smooth_ce(lg_dev, tg.to(torch.int32).to(dev), V, eps, pad)
+        (loss2 * 0.25).backward()
+        assert _relerr(lg_dev.grad.cpu(), 0.25 * ref_in.grad) < 1e-2
 
 
 def test_adam_matches_torch():

@@ -9,6 +9,7 @@ ap.add_argument("--B", type=int, default=8); ap.add_argument("--L", type=int, de
 ap.add_argument("--d", type=int, default=512); ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--parts", type=int, default=63, help="bit0 fwd, bit1 pre-pass, bit2 dq (from tiles / recompute), bit3 dkv, bit4 de (from tiles), bit5 de (recompute), bit6 whole backward")
 ap.add_argument("--rounds", type=int, default=1)
+ap.add_argument("--fwd-variants", action="store_true", help="also time the two experimental forwards (needs MGX_LIB_PATH=...libmgx_exp.so)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 g = torch.Generator().manual_seed(7)
@@ -39,6 +40,7 @@ def timed(fn, units, name):
 if a.parts & 1:
     for _ in range(a.rounds):          # interleaved rounds in one process (A/B)
         timed(with_env("MGX_ATTN_FWD64", "0", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd32")
+        if not a.fwd_variants: continue
         timed(with_env("MGX_ATTN_FWD64", "1", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd64")
         timed(with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwdpp")
         timed(with_env("MGX_ATTN_PP_RIGID", "1", with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None))), 3, "fwdpp_r")

@@ -1,4 +1,9 @@
-"""GPU parity tests of the opt-in forward attention kernels (64 rows per wave / ping-pong), taken for L % 256 == 0.
+"""GPU parity tests of the two alternative forward attention kernels kept under tools/experiments/ (64 rows per wave /
+ping-pong; both measured slower than the product kernel, profiles/README.md round 3).  They are NOT part of libmgx.so: build
+the experiment variant and point the package at it,
+
+    python -m musicgeneration_amd._build --variant exp --experiments
+    MGX_LIB_PATH=musicgeneration_amd/libmgx_exp.so python -m pytest tools/experiments/test_gpu_attn64.py -m gpu -q
 
 Each case is checked twice: against the fp32 oracle on the same bf16-rounded inputs (tolerances of
 tests/test_gpu_kernels.py) and against the 32-rows-per-wave kernel of the same library (MGX_ATTN_FWD64=0),
@@ -8,7 +13,9 @@ import os
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.environ.get("MGX_LIB_PATH", "").endswith("libmgx_exp.so"),
+                                 reason="needs the experiment build (see the module docstring)")]
 
 
 def _dev():

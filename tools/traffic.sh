@@ -6,18 +6,19 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/traffic.json}
 export BATCH=${BATCH:-64}
 ROOT=$(pwd)
+export TMPD=/tmp/mgx_traffic_$$; mkdir -p $TMPD
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -- \
-      python3 $ROOT/bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-decode > /tmp/pmc_$c.log 2>&1 || { tail -5 /tmp/pmc_$c.log; exit 1; }
+  rm -rf $TMPD/pmc_$c
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $TMPD/pmc_$c -- \
+      python3 $ROOT/bench.py --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-decode --no-cfg4 > $TMPD/pmc_$c.log 2>&1 || { tail -5 $TMPD/pmc_$c.log; exit 1; }
 done
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys, collections
 acc = {c: collections.defaultdict(list) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 for c in acc:
-    for f in glob.glob(f"/tmp/pmc_{c}/**/*counter_collection.csv", recursive=True):
+    for f in glob.glob(os.environ["TMPD"] + f"/pmc_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c:
                 acc[c][r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
