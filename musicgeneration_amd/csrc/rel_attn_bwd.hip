@@ -540,6 +540,15 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 #define MGX_DKV_PEEL 0      // timing experiments only (tools/peel_dkv.sh): 1 no E loads in the sweep | 2 no dS stores | 4 no skew (bpermute)
 #endif                      // | 8 no exponentials | 16 no q / dO tile prefetch+publish (the first tile is reused) | 32 no lse / delta reads
                             // (constants); results are then wrong
+// MGX_DKV_STAMP (diagnostic build only, `_build.py --variant dkvstamp -DMGX_DKV_STAMP`; tools/dkv_stamp.py): s_memtime stamps at five
+// points of a main-loop step; lane 0 of every wave leaves its sums in its first dk row (the results are then garbage).  Reading
+// a stamp waits for lgkmcnt(0), i.e. for the wave's outstanding LDS operations: the stamped kernel is a little slower.
+#ifdef MGX_DKV_STAMP
+#define DKV_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                          __builtin_amdgcn_sched_barrier(0); if (!MASKED) st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define DKV_STAMP(i)
+#endif
 namespace k2 {
 constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
@@ -667,9 +676,15 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     };
 
     // ---- one query tile.  cur = t & 1 (LDS buffers), PAR = E slot of the hi chunk; MASKED: diagonal / padded-key masks ----
+#ifdef MGX_DKV_STAMP
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = 0;
+    unsigned st_steps = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();   // realtime: constant 100 MHz
+#endif
     auto tile = [&](int dq, int cur, auto par_tag, auto masked_tag, char* dsp) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool MASKED = decltype(masked_tag)::value;
+        DKV_STAMP(5);                                     // [5] from the previous stamp (after the barrier) to here: prefetch issue
         const char* qr = smem + OFF_QR + cur * TILE_BYTES;
         bf16x8 qa[4];
 #pragma unroll
@@ -695,6 +710,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
         }
         if (!MASKED) __builtin_amdgcn_sched_barrier(0x78F);    // VMEM may not sink below: needed at the top of the next step
+        DKV_STAMP(0);                                     // [0] q fragments, 8 Q.Er^T MFMAs, merge
         // The skew is a LANE permutation inside each half-wave: the tile's element (row a = crow(r,hh), key bl) is the merged value
         // merged[a][t = (a - bl) & 31], which lane t of the same half holds in the SAME register r -- one ds_bpermute_b32 per
         // register and no LDS memory (until round 3 the merged tile went through a 4 KB band: 16 stores + 16 loads per tile).
@@ -704,6 +720,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             const float v = qe[r];            // (a __builtin_bit_cast of the vector ELEMENT expression itself reads element 0)
             c[r] = (MGX_DKV_PEEL & 4) ? v : __int_as_float(__builtin_amdgcn_ds_bpermute((int)rd[r], __float_as_int(v)));
         }
+        DKV_STAMP(1);                                     // [1] 16 ds_bpermute and their results
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c = mfma(qa[ks], kf[ks], c);
         if (MASKED) {
@@ -738,6 +755,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
                 ds[4 * g4 + k] = p * dp[4 * g4 + k];
             }
         }
+        DKV_STAMP(2);                                     // [2] S, dP MFMAs, statistics, exponentials, dS
         const char* ot = smem + OFF_OT + cur * TILE_BYTES;
         const char* qt = smem + OFF_QT + cur * TILE_BYTES;
         u32x4 dfx[2];
@@ -757,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             __builtin_nontemporal_store(dfx[0], (u32x4*)dsp);
             __builtin_nontemporal_store(dfx[1], (u32x4*)(dsp + 1024));
         }
+        DKV_STAMP(3);                                     // [3] packs, transposed fragments, 8 dV / dK MFMAs (issue), dS stores
     };
     // prefetch of the next query tile (registers) and its publication into the other LDS buffers
     u32x4 qreg, oreg;
@@ -792,7 +811,13 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     };
     int t = 0;
     const int nhead = wgpad ? nT : min(4, nT);
+#ifdef MGX_DKV_STAMP
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();      // end of the prologue
+#endif
     for (; t < nhead; ++t) general_step(t);
+#ifdef MGX_DKV_STAMP
+    const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();      // end of the diagonal block's general steps
+#endif
     // ---- main loop (t >= 4 is even here): every wave's tile is full, no masks: branch-free bodies, two steps per trip so
     //      that the LDS buffer and the E slot of each step are compile-time constants -----------------------------------------
     for (; t + 1 < nT; t += 2) {
@@ -800,17 +825,35 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         tile(t - wk, 0, std::integral_constant<int, 0>{}, std::false_type{}, ds_tile(t));
         publish(1);
         __syncthreads();
+#ifdef MGX_DKV_STAMP
+        { constexpr bool MASKED = false; DKV_STAMP(4); st_steps += 2; }     // [4] publish + barrier
+#endif
         prefetch(t + 1);
         tile(t + 1 - wk, 1, std::integral_constant<int, 1>{}, std::false_type{}, ds_tile(t + 1));
         publish(0);
         __syncthreads();
+#ifdef MGX_DKV_STAMP
+        { constexpr bool MASKED = false; DKV_STAMP(4); }
+#endif
     }
+#ifdef MGX_DKV_STAMP
+    const unsigned long long st_t3 = __builtin_amdgcn_s_memtime();      // end of the main loop
+#endif
     for (; t < nT; ++t) general_step(t);
 
     if (wave_on) {
         uint16_t* row0 = dqkv + ((size_t)b * L + j0) * ld + hd * 64;
         store_rows_lds(row0 + d, ld, dk0, dk1, lane, 0.125f, band);      // dk = dS^T (q/8)
         store_rows_lds(row0 + 2 * d, ld, dv0, dv1, lane, 1.f, band);
+#ifdef MGX_DKV_STAMP
+        if (lane == 0) {
+            float* rec = (float*)(row0 + d);
+            for (int i = 0; i < 6; ++i) rec[i] = (float)st_acc[i];
+            rec[6] = (float)st_steps; rec[7] = (float)(J0 >> 7); rec[8] = (float)w;
+            rec[9] = (float)(__builtin_amdgcn_s_memtime() - st_t0); rec[10] = (float)(__builtin_amdgcn_s_memrealtime() - st_r0);
+            rec[11] = (float)(st_t1 - st_t0); rec[12] = (float)(st_t2 - st_t1); rec[13] = (float)(st_t3 - st_t2);
+        }
+#endif
     }
 }
 

@@ -520,7 +520,7 @@ def test_library_boundary_records_pads_that_do_not_trail():
     from musicgeneration_amd.network import MusicTransformer
     torch.manual_seed(0)
     V, L = 50, 64
-    mt = MusicTransformer(embedding_dim=64, vocab_size=V, num_layer=1, max_seq=L, dropout=0.0).cuda().train()
+    mt = MusicTransformer(embedding_dim=128, vocab_size=V, num_layer=1, max_seq=L, dropout=0.0).cuda().train()
     x = torch.randint(0, V - 1, (3, L), dtype=torch.int32)
     x[1, L - 7:] = V - 1                         # trailing pads: fine
     x[2, L - 1] = V - 1                          # a pad in the last column of the last row: no "next token" to look at
