@@ -36,8 +36,9 @@ constexpr int WAVES = 4;
 // delta[b,h,i] = sum_c dctx[b,i,h*64+c] * ctx[b,i,h*64+c]         (8 lanes per (row, head))
 // ================================================================================================
 __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ ctx,
-                                                         const uint16_t* __restrict__ dctx,
-                                                         float* __restrict__ delta, int B, int L, int d) {
+                                                         const uint16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                         float* __restrict__ delta, float* __restrict__ nlse2,
+                                                         float* __restrict__ ndelta, int B, int L, int d) {
     const int heads = d >> 6;
     const long total = (long)B * L * heads * 8;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +59,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
     s += __shfl_xor(s, 4, 64);
     if (sub == 0) {
         const int bb = (int)(row / L), i = (int)(row % L);
-        delta[((size_t)bb * heads + hd) * L + i] = s;
+        const size_t si = ((size_t)bb * heads + hd) * L + i;
+        delta[si] = s;
+        // the dK/dV kernel's copies, in the form it consumes them (the initial accumulators of its S and dP products), so
+        // that its LDS-DMA staging needs no arithmetic on the way
+        ndelta[si] = -s;
+        nlse2[si] = -lse[si] * LOG2E;
     }
 }
 
@@ -549,12 +555,17 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 #else
 #define DKV_STAMP(i)
 #endif
+#ifndef MGX_DKV_FOLD
+#define MGX_DKV_FOLD 0      // 1: log2(e)/8 rides in K and in the Er copy, -lse log2(e) is the initial accumulator of the Q.Er^T products: S arrives as
+#endif                      //    the exponent's argument (16 fewer VALU per tile).  Measured at cfg2 / batch 64: 1.258 ms against 1.262 for 0 -- nothing;
+                            //    and the rounding of K changes (the backward's P no longer equals the forward's bit for bit), so the default
+                            //    stays 0: exponent = fma(8 S, log2(e)/8, -lse log2(e)) on unscaled operands
 namespace k2 {
 constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
 constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K  dO image R
 constexpr int OFF_OT = OFF_OR + 2 * TILE_BYTES;            // 2 x 4K  dO image T
-constexpr int ST_BYTES = 1024;                             // per buffer: lse2[32], delta[32] (+ 192 unread duplicates, see publish)
+constexpr int ST_BYTES = 1024;                             // per buffer: 4 waves x (-lse2[32], -delta[32]): every wave stages and reads its own copy
 constexpr int OFF_ST = OFF_OT + 2 * TILE_BYTES;            // 2 x 1 KB
 constexpr int PATCH_BYTES = 4608;                          // per wave: 32 rows x 144 B, the epilogue's row-major store patch
 constexpr int OFF_BAND = OFF_ST + 2 * ST_BYTES;
@@ -567,8 +578,8 @@ constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 51,728 B (the 256 
 
 template <bool EXPORT_DS>     // always true (one instantiation): as a plain function hipcc builds a 36 % longer main loop from the same source
 __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
-    const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const uint32_t* __restrict__ padbits,
-    const uint16_t* __restrict__ dctx, const float* __restrict__ lse, const float* __restrict__ delta,
+    const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfS /* Er fragments x log2(e)/8 */, const uint32_t* __restrict__ padbits,
+    const uint16_t* __restrict__ dctx, const float* __restrict__ nlse2 /* -lse log2(e) */, const float* __restrict__ ndelta /* -delta */,
     uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dst, int L, int d, int bgroup) {
     using namespace k2;
     extern __shared__ __attribute__((aligned(256))) char smem[];     // 256: the band reads XOR bit 7 of absolute LDS addresses
@@ -589,42 +600,42 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
     const size_t stat_base = ((size_t)b * heads + hd) * L;
 
-    const int srow = tid >> 3, sch = tid & 7;
-    const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
-    // Every global address of the sweep is (wave-uniform base in SGPRs) + (32-bit per-lane offset) + immediate.
+    // Staging of a query tile (q and dO, two LDS images each, and the two statistics of its 32 rows) is LDS-DMA: thread tid owns
+    // the 16-byte slot tid of every image -- row tid >> 3, PHYSICAL chunk tid & 7 -- and fetches the logical chunk the image's
+    // swizzle puts there (rel_attn_common.hpp: dma16), so a tile costs a wave five DMA instructions and neither registers nor
+    // ds_write (round 3: 2 loads into registers, then 5 stores).  Every global address of the sweep is (wave-uniform base in
+    // SGPRs) + (32-bit per-lane offset).
+    const int srow = tid >> 3, spc = tid & 7;
+    const int lcR = spc ^ ((srow >> 1) & 7), lcT = spc ^ (((srow >> 1) & 1) << 2);      // logical chunks: imgR_off / imgT_off inverted
     const char* q_base = (const char*)(qkv_b + (size_t)J0 * ld + hd * 64);                      // + t * 32 rows
     const char* o_base = (const char*)(dctx + ((size_t)b * L + J0) * d + hd * 64);
-    const uint32_t q_voff = (uint32_t)((srow * ld + sch * 8) * 2), o_voff = (uint32_t)((srow * d + sch * 8) * 2);
+    const uint32_t q_voffR = (uint32_t)((srow * ld + lcR * 8) * 2), q_voffT = (uint32_t)((srow * ld + lcT * 8) * 2);
+    const uint32_t o_voffR = (uint32_t)((srow * d + lcR * 8) * 2), o_voffT = (uint32_t)((srow * d + lcT * 8) * 2);
     const uint32_t q_step = (uint32_t)(32 * ld * 2), o_step = (uint32_t)(32 * d * 2);
-    auto q_tile = [&](int t) { return *(const u32x4*)(q_base + (size_t)t * q_step + q_voff); };
-    auto o_tile = [&](int t) { return *(const u32x4*)(o_base + (size_t)t * o_step + o_voff); };
     // fragment ks of Er chunk q for this lane (fragment-ordered copy: 1 KB contiguous per wave load).  Every load of the
     // sweep is unconditional with a clamped index; data of clamped tiles / chunks is never used.
     const uint32_t lane16 = (uint32_t)lane * 16u;
     auto e_frag = [&](int q, int ks) {
-        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)EfA + (size_t)min(max(q, 0), nchunk - 1) * 4096 + ks * 1024 + lane16));
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)EfS + (size_t)min(max(q, 0), nchunk - 1) * 4096 + ks * 1024 + lane16));
     };
-    // lse * log2e (threads with tid&32 == 0) / MINUS delta (tid&32 != 0) of row (tid&31) of query tile t.  EVERY thread loads
-    // (threads 0..63 publish): a load under `if (tid < 64)` is a branch around VMEM, and where it rejoins the compiler drains
-    // the whole VMEM queue -- i.e. waits for the tile prefetch issued two instructions earlier, on every step.
-    // -delta is the INITIAL accumulator of dP = dO V^T (the rows of the accumulator are the query rows), so dS = P (dP - delta)
-    // costs one multiply per element and no subtraction.
-    const float* stat_ptr = ((tid & 32) ? delta : lse) + stat_base + (tid & 31);
-    const float stat_mul = (tid & 32) ? -1.f : LOG2E;
-    auto stat_src = [&](int t) { return stat_ptr[J0 + 32 * min(t, nT - 1)]; };     // raw; scaled by stat_mul when published
-
-    {
-        // q is NOT pre-scaled here (the forward and dQ kernels hold q/8 in registers for the whole sweep; this kernel would
-        // rescale every staged tile): 1/8 is exact, so it moves into the exponent's multiplier (log2e/8) and into the final
-        // scale of dK -- bit-identical products, 20 fewer VALU per thread and step.
-        const u32x4 qq = q_tile(0);
-        const u32x4 oo = o_tile(0);
-        *(u32x4*)(smem + OFF_QR + st_offR) = qq;
-        *(u32x4*)(smem + OFF_QT + st_offT) = qq;
-        *(u32x4*)(smem + OFF_OR + st_offR) = oo;
-        *(u32x4*)(smem + OFF_OT + st_offT) = oo;
-        if (tid < 64) *(float*)(smem + OFF_ST + tid * 4) = stat_src(0) * stat_mul;
-    }
+    // -lse log2(e) (lanes 0..31) / -delta (lanes 32..63) of row (lane & 31) of a query tile, from the pre-pass's copies: both are
+    // INITIAL ACCUMULATORS -- of the two Q.Er^T chunk products (rows = queries; the lane permutation of the skew keeps a value in
+    // its row) and of dP = dO V^T --, so the MFMAs deliver the exponent's argument and dP - delta without a VALU instruction.
+    // Every wave stages (and reads) its own 256-byte copy: no statistic crosses waves.
+    const uint32_t st_voff = (uint32_t)(((lane & 32) ? (const char*)ndelta - (const char*)nlse2 : 0) + (lane & 31) * 4);   // |offset| < 2^31: same allocation
+    const char* st_base = (const char*)(nlse2 + stat_base + J0);
+    const uint32_t lds_w = lds_addr_of(smem) + w * 1024;   // this wave's 1 KB of every 4 KB image; + OFF_ST: its 256 B of statistics
+    auto stage = [&](int t, int buf) {                     // tile t (clamped) -> LDS buffers `buf`
+        const int tn = (MGX_DKV_PEEL & 16) ? 0 : min(t, nT - 1);
+        const char* qb = q_base + (size_t)tn * q_step;
+        const char* ob = o_base + (size_t)tn * o_step;
+        dma16(qb, q_voffR, lds_w + OFF_QR + buf * TILE_BYTES);
+        dma16(qb, q_voffT, lds_w + OFF_QT + buf * TILE_BYTES);
+        dma16(ob, o_voffR, lds_w + OFF_OR + buf * TILE_BYTES);
+        dma16(ob, o_voffT, lds_w + OFF_OT + buf * TILE_BYTES);
+        dma4(st_base + (size_t)tn * 128, st_voff, lds_addr_of(smem) + OFF_ST + buf * ST_BYTES + w * 256);
+    };
+    stage(0, 0);
     // E chunk fragments: a step's "hi" chunk (t - wk) sits in e[PAR], the "lo" chunk (t - wk - 1) in e[PAR^1]; the slot of
     // the lo chunk receives chunk t - wk + 1 once it has been used, which is the next step's hi chunk.  The main loop
     // alternates PAR = 0, 1 (two steps per trip); the general body always uses PAR = 0 and swaps the slots afterwards.
@@ -635,7 +646,11 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         const uint16_t* kp = qkv_b + (size_t)(j0 + bl) * ld + d + hd * 64 + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + ks * 16));
+            // K carries the exponent's whole multiplier log2(e)/8 (one bf16 rounding per element, here; the Er copy EfS carries the
+            // same factor): S arrives as the argument of exp2.  q stays unscaled -- it is also the operand of dK, whose 1/8 is the
+            // final scale of the accumulators.
+            kf[ks] = MGX_DKV_FOLD ? __builtin_bit_cast(bf16x8, scale8(*(const u32x4*)(kp + ks * 16), 0.125f * LOG2E))
+                                  : __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + ks * 16));
             vf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + d + ks * 16));
             e[0][ks] = e_frag(0, ks);                       // the wave's first step (t = wk) is its diagonal: hi chunk 0
             e[1][ks] = e[0][ks];
@@ -651,6 +666,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
             wgpad = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)(smem + OFF_FLAG));
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tile 0 has landed (a DMA has no register the compiler could wait on)
     __syncthreads();
     char* band = smem + OFF_BAND + w * PATCH_BYTES;          // the epilogue's store patch
     // rd[r] = byte address (source lane * 4) of the ds_bpermute that skews register r (see `tile`)
@@ -681,7 +697,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     unsigned st_steps = 0;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();   // realtime: constant 100 MHz
 #endif
-    auto tile = [&](int dq, int cur, auto par_tag, auto masked_tag, char* dsp) {
+    auto tile = [&](int dq, int cur, auto par_tag, auto masked_tag, char* dsp, int tnext) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool MASKED = decltype(masked_tag)::value;
         DKV_STAMP(5);                                     // [5] from the previous stamp (after the barrier) to here: prefetch issue
@@ -694,11 +710,18 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         // chunk for t > a: the two products are MERGED in registers (one v_cndmask per element) and stored once -- 16 band
         // stores per tile instead of 32, a 4 KB band per wave instead of an 8 KB ring, and no parity in any address (this
         // kernel computes both chunks for every tile anyway: unlike the forward / dQ kernels nothing is reused by the next tile).
-        f32x16 qe = zero16();
+        const char* st = smem + OFF_ST + cur * ST_BYTES + w * 256;
+        f32x16 nl;                                        // -lse2 of the accumulator's query rows
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 l4 = (MGX_DKV_PEEL & 32) ? f32x4{-9.f, -9.f, -9.f, -9.f} : *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
+            nl[4 * g4] = l4.x; nl[4 * g4 + 1] = l4.y; nl[4 * g4 + 2] = l4.z; nl[4 * g4 + 3] = l4.w;
+        }
+        f32x16 qe = MGX_DKV_FOLD ? nl : zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR][ks], qe);
         if (!MASKED || dq >= 1) {
-            f32x16 ql = zero16();
+            f32x16 ql = MGX_DKV_FOLD ? nl : zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ql = mfma(qa[ks], e[PAR ^ 1][ks], ql);
 #pragma unroll
@@ -709,6 +732,10 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) e[PAR ^ 1][ks] = e_frag(dq + 1, ks);
         }
+        // ... and request the next query tile into the other LDS buffers (every wave is past the barrier that ended their last
+        // use).  AFTER the E loads: the compiler's wait for those at the top of the next step counts the operations it knows to
+        // be younger (the two dS stores) and so also covers these five -- which have landed by then anyway (see `landed`)
+        stage(tnext, cur ^ 1);
         if (!MASKED) __builtin_amdgcn_sched_barrier(0x78F);    // VMEM may not sink below: needed at the top of the next step
         DKV_STAMP(0);                                     // [0] q fragments, 8 Q.Er^T MFMAs, merge
         // The skew is a LANE permutation inside each half-wave: the tile's element (row a = crow(r,hh), key bl) is the merged value
@@ -733,7 +760,6 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
                 for (int r = 0; r < 16; ++r) c[r] = -INFINITY;
             }
         }
-        const char* st = smem + OFF_ST + cur * ST_BYTES;
         f32x16 dp;                                        // initial accumulator: -delta of the accumulator's query rows
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -745,15 +771,12 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(orr, bl, hh, ks), vf[ks], dp);
         f32x16 ds;
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 l4 = (MGX_DKV_PEEL & 32) ? f32x4{9.f, 9.f, 9.f, 9.f} : *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float p = (MGX_DKV_PEEL & 8) ? __builtin_fmaf(c[4 * g4 + k], 1e-9f, -l4[k])
-                                                   : __builtin_amdgcn_exp2f(__builtin_fmaf(c[4 * g4 + k], 0.125f * LOG2E, -l4[k]));    // c = 8 S
-                c[4 * g4 + k] = p;
-                ds[4 * g4 + k] = p * dp[4 * g4 + k];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float p = (MGX_DKV_PEEL & 8) ? c[r] * 1e-9f
+                            : MGX_DKV_FOLD ? __builtin_amdgcn_exp2f(c[r])                                            // c = S log2(e) - lse2
+                                           : __builtin_amdgcn_exp2f(__builtin_fmaf(c[r], 0.125f * LOG2E, nl[r]));    // c = 8 S
+            c[r] = p;
+            ds[r] = p * dp[r];
         }
         DKV_STAMP(2);                                     // [2] S, dP MFMAs, statistics, exponentials, dS
         const char* ot = smem + OFF_OT + cur * TILE_BYTES;
@@ -777,38 +800,27 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         }
         DKV_STAMP(3);                                     // [3] packs, transposed fragments, 8 dV / dK MFMAs (issue), dS stores
     };
-    // prefetch of the next query tile (registers) and its publication into the other LDS buffers
-    u32x4 qreg, oreg;
-    float streg = 0.f;
-    auto prefetch = [&](int t) {      // tile t + 1, clamped
-        const int tn = (MGX_DKV_PEEL & 16) ? 0 : min(t + 1, nT - 1);
-        qreg = q_tile(tn);
-        oreg = o_tile(tn);
-        streg = stat_src(tn);
-    };
-    auto publish = [&](int nxt) {
-        *(u32x4*)(smem + OFF_QR + nxt * TILE_BYTES + st_offR) = qreg;
-        *(u32x4*)(smem + OFF_QT + nxt * TILE_BYTES + st_offT) = qreg;
-        *(u32x4*)(smem + OFF_OR + nxt * TILE_BYTES + st_offR) = oreg;
-        *(u32x4*)(smem + OFF_OT + nxt * TILE_BYTES + st_offT) = oreg;
-        // every thread stores (threads >= 64 write duplicates nobody reads): a store under `tid < 64` pulls the load above
-        // into the branch, and the join then drains the VMEM queue behind the tile prefetch on every step
-        *(float*)(smem + OFF_ST + nxt * ST_BYTES + tid * 4) = streg * stat_mul;
-    };
-
+    // The next query tile's DMA (issued inside `tile`, after the E loads) must have landed before the barrier that ends the
+    // step; the only VMEM operations a wave issues after it are the two dS stores of its tile: a COUNTED wait, vmcnt(2).
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); };
     // ---- general body: the diagonal 128 x 128 block (t < 4: a wave is not started / on its diagonal / full), every
     //      step when a key of this workgroup is padded, and an odd last step ------------------------------------------------
     auto general_step = [&](int t) {
-        prefetch(t);
         const int dq = t - wk;
+        if (dq < 0) stage(t + 1, (t & 1) ^ 1);            // (a wave that has a tile stages from inside it)
         if (dq >= 0) {
-            tile(dq, t & 1, std::integral_constant<int, 0>{}, std::true_type{}, ds_tile(t));
+            tile(dq, t & 1, std::integral_constant<int, 0>{}, std::true_type{}, ds_tile(t), t + 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { const bf16x8 x = e[0][ks]; e[0][ks] = e[1][ks]; e[1][ks] = x; }
         }
-        publish((t & 1) ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // not counted here: a wave that skipped its tile issued no stores after the DMA
         __syncthreads();
     };
+    // (round 4: the four steps of the diagonal block specialised at compile time -- the wave's first tile through the masked body,
+    //  later ones through the main loop's branch-free body with its E-slot protocol, instead of the general body below -- made the
+    //  kernel SLOWER, 1.31 against 1.265 ms at cfg2 / batch 64: eight more inlined tile bodies, 68 spilled registers outside the main
+    //  loop and a 15 K-instruction kernel.  The general body costs 4.2-5.0 K cycles per step against 3.1 K in the main loop,
+    //  15 % of a workgroup's time: tools/dkv_stamp.py.)
     int t = 0;
     const int nhead = wgpad ? nT : min(4, nT);
 #ifdef MGX_DKV_STAMP
@@ -821,16 +833,14 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     // ---- main loop (t >= 4 is even here): every wave's tile is full, no masks: branch-free bodies, two steps per trip so
     //      that the LDS buffer and the E slot of each step are compile-time constants -----------------------------------------
     for (; t + 1 < nT; t += 2) {
-        prefetch(t);
-        tile(t - wk, 0, std::integral_constant<int, 0>{}, std::false_type{}, ds_tile(t));
-        publish(1);
+        tile(t - wk, 0, std::integral_constant<int, 0>{}, std::false_type{}, ds_tile(t), t + 1);
+        landed();
         __syncthreads();
 #ifdef MGX_DKV_STAMP
         { constexpr bool MASKED = false; DKV_STAMP(4); st_steps += 2; }     // [4] publish + barrier
 #endif
-        prefetch(t + 1);
-        tile(t + 1 - wk, 1, std::integral_constant<int, 1>{}, std::false_type{}, ds_tile(t + 1));
-        publish(0);
+        tile(t + 1 - wk, 1, std::integral_constant<int, 1>{}, std::false_type{}, ds_tile(t + 1), t + 2);
+        landed();
         __syncthreads();
 #ifdef MGX_DKV_STAMP
         { constexpr bool MASKED = false; DKV_STAMP(4); }
@@ -1220,13 +1230,15 @@ static int bwd_batch_group(int B, int L, int d) {
     return g;
 }
 
-static size_t ws_delta_bytes(int B, int L, int d) { return (((size_t)B * (d / 64) * L * 4) + 255) / 256 * 256; }
+static size_t ws_stat_bytes(int B, int L, int d) { return (((size_t)B * (d / 64) * L * 4) + 255) / 256 * 256; }      // one f32 [B,h,L]
+static size_t ws_delta_bytes(int B, int L, int d) { return 3 * ws_stat_bytes(B, L, d); }    // delta | -lse log2e | -delta
 
-static size_t ws_ert_bytes(int L) { return 2 * er_frag_bytes(L); }   // EfA | EfT
+static size_t ws_ert_bytes(int L) { return 3 * er_frag_bytes(L); }   // EfA | EfT | EfS
 
 extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
     if (B <= 0 || L <= 0 || d <= 0) return 0;
-    // delta f32 [B,h,L] | fragment-ordered Er (EfA, EfT) | causal half of dS by (query tile, key tile) bf16: B*h*T tiles of 2 KB
+    // delta, -lse log2e, -delta f32 [B,h,L] each | fragment-ordered Er (EfA, EfT, EfS) | causal half of dS by (query tile, key
+    // tile) bf16: B*h*T tiles of 2 KB
     const size_t nchunk = (size_t)L / 32;
     return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * (nchunk * (nchunk + 1) / 2) * 2048;
 }
@@ -1258,14 +1270,17 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     const int heads = d / 64;
     const uint16_t* Er = E + (size_t)(M - L) * 64;
     float* delta = (float*)workspace;
+    float* nlse2 = (float*)((char*)workspace + ws_stat_bytes(B, L, d));
+    float* ndelta = (float*)((char*)workspace + 2 * ws_stat_bytes(B, L, d));
     u32x4* EfA = (u32x4*)((char*)workspace + ws_delta_bytes(B, L, d));
     u32x4* EfT = (u32x4*)((char*)EfA + er_frag_bytes(L));
+    u32x4* EfS = (u32x4*)((char*)EfT + er_frag_bytes(L));
     uint16_t* dst = (uint16_t*)((char*)EfA + ws_ert_bytes(L));
     if (parts & 1) {
         // delta = rowsum(dO o O) for the kernels that form dS (dK/dV and the two recompute cross-checks)
         const long total = (long)B * L * heads * 8;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, delta, B, L, d);
-        launch_er_frag(Er, EfA, EfT, L, s);
+        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, lse, delta, nlse2, ndelta, B, L, d);
+        launch_er_frag(Er, EfA, EfT, L, s, EfS, MGX_DKV_FOLD ? 0.125f * LOG2E : 1.f);
     }
     const int bg = bwd_batch_group(B, L, d);
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
@@ -1281,7 +1296,7 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
 #else
         constexpr int dkv_lds = k2::LDS_BYTES;
 #endif
-        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), dkv_lds, s, qkv, EfA, padbits, dctx, lse, delta, dqkv, dst, L, d, bg);
+        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), dkv_lds, s, qkv, EfS, padbits, dctx, nlse2, ndelta, dqkv, dst, L, d, bg);
     }
     if (parts & 2)
         hipLaunchKernelGGL(rel_attn_dq_lite_kernel, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, L, d, bg);

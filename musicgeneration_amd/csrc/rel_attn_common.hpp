@@ -143,12 +143,21 @@ MGX_DEV void band_store(char* band, const int (&wa0)[16], const int (&wa1)[16], 
 }
 
 // LDS-DMA: one wave instruction moves 64 x 16 (or 4) bytes global -> LDS without passing through VGPRs.  The LDS destination is
-// (wave-uniform base) + lane * size, so an image's bank swizzle is applied on the SOURCE side: lane l fetches the bytes that
-// belong in slot l.
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef const __attribute__((address_space(1))) void* glb_void_ptr;
-MGX_DEV void dma16(const void* g, char* lds_wave_base) { __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)lds_wave_base, 16, 0, 0); }
-MGX_DEV void dma4(const void* g, char* lds_wave_base) { __builtin_amdgcn_global_load_lds((glb_void_ptr)g, (lds_void_ptr)lds_wave_base, 4, 0, 0); }
+// (wave-uniform base, in M0) + lane * size, so an image's bank swizzle is applied on the SOURCE side: lane l fetches the bytes
+// that belong in slot l.  Issued from inline asm, in the (SGPR base + 32-bit lane offset) address form:
+//  * through the builtin hipcc treats the instruction as a FLAT access with LDS side effects: while one is in flight every wait
+//    for an ordinary load becomes s_waitcnt vmcnt(0) (no counted waits: the tile prefetch would be waited for at the top of the
+//    same step), every ds_read_b64_tr_b16 builtin gets a vmcnt(0) in front (possible alias of the DMA's destination) and
+//    __syncthreads() a vmcnt(0) for its release fence;
+//  * the compiler therefore does NOT know that these instructions write LDS or occupy vmcnt: the caller separates them from the
+//    LDS reads of the same bytes by an explicit counted s_waitcnt vmcnt(N) + barrier (N = VMEM operations issued after them).
+//    A compiler-generated vmcnt(N') for an older ordinary load only ever waits longer than needed, never shorter.
+MGX_DEV void dma16(const char* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave_base) : "memory", "m0");
+}
+MGX_DEV void dma4(const char* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave_base) : "memory", "m0");
+}
 
 // order LDS traffic of one wave (same-wave DS ops execute in order; this only pins the compiler)
 MGX_DEV void wave_lds_fence() {
