@@ -1083,7 +1083,7 @@ constexpr int SLOTS = 2;                                   // tiles per wave and
 
 __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dst, float* __restrict__ dEr /* = dE + (M-L)*64 */,
-    int bgroup, int wg_per_group, int L, int d) {
+    int bgroup, int ngroups, int wg_per_group, int L, int d) {
     using namespace k3t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1095,9 +1095,14 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
     // workgroup -> (batch group, diagonal group t, slice of its flattened (bh, row-block) sweep); inside a batch group the
     // diagonal groups are laid out longest sweep first
     int t = 0, first = 0, ns = 0;
-    const int grp = blockIdx.x / wg_per_group;
+    // Batch groups are dealt to the XCDs (workgroups b and b + 8 share one, MI355X_MICROARCH.md): workgroup 8 k + x belongs to group
+    // 8 (k / wg_per_group) + x.  A group's workgroups -- all the diagonal groups that re-read the same q rows -- then share an L2,
+    // and with groups of ONE batch row (2 MB of q at cfg2) the re-reads are L2 hits instead of fabric reads.  Speed only.
+    const int xk = blockIdx.x >> 3;
+    const int grp = (xk / wg_per_group) * 8 + (blockIdx.x & 7);
+    if (grp >= ngroups) return;                            // padding of the last round of eight groups
     {
-        int rest = blockIdx.x - grp * wg_per_group;
+        int rest = xk % wg_per_group;
         const int ntile = (nchunk + DIAGS - 1) / DIAGS;
         for (t = 0; t < ntile; ++t) {
             ns = (L - t * DIAGS * 32 + RS - 1) / RS;       // row blocks i0 = 32 c0, +64, ... < L (query tiles I >= c0)
@@ -1303,12 +1308,17 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     if (parts & 32)
         hipLaunchKernelGGL(rel_attn_dq_kernel, gq, dim3(256), k1::LDS_BYTES, s, qkv, EfA, EfT, padbits, dctx, lse, delta, dqkv, L, d, bg);
     if (parts & 8) {
+#ifndef MGX_DET_BG
+#define MGX_DET_BG 1        // batch rows per group of the dE kernel (A/B builds: the attention kernels' bgroup is 8 at cfg2 / batch 64)
+#endif
+        const int bgd = (B % MGX_DET_BG == 0) ? MGX_DET_BG : 1, ngr = B / bgd;
         long nwg = 0;                                   // workgroups of ONE batch group
         for (int t = 0; t < (L / 32 + k3t::DIAGS - 1) / k3t::DIAGS; ++t)
-            nwg += ((long)bg * heads * ((L - t * k3t::DIAGS * 32 + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
-        MGX_REQUIRE(nwg * (B / bg) < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
-        hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)(nwg * (B / bg))), dim3(64 * k3t::NW), k3t::LDS_BYTES, s, qkv, dst,
-                           dE + (size_t)(M - L) * 64, bg, (int)nwg, L, d);
+            nwg += ((long)bgd * heads * ((L - t * k3t::DIAGS * 32 + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
+        const long grid = nwg * 8 * ((ngr + 7) / 8);    // groups in rounds of eight, one per XCD
+        MGX_REQUIRE(grid < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
+        hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)grid), dim3(64 * k3t::NW), k3t::LDS_BYTES, s, qkv, dst,
+                           dE + (size_t)(M - L) * 64, bgd, ngr, (int)nwg, L, d);
     }
     if (parts & 16) {
         const dim3 ge(B * heads, ((L >> 5) + k3::W3 - 1) / k3::W3);

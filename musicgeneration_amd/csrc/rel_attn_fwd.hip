@@ -38,10 +38,9 @@ using namespace relattn;
 #ifndef MGX_EXPERIMENTS
 #define MGX_EXPERIMENTS 0   // 1 (experiment builds only): environment knobs that change which kernel runs / its residency, and the two
 #endif                      // alternative forward kernels of tools/experiments/.  The product library reads no environment variable here.
-#ifndef MGX_FWD_AHEAD
-#define MGX_FWD_AHEAD 0   // 1: main loop with the Q.Er^T product one step ahead of its tile (experiment: 0.567-0.569 ms against 0.562-0.563
-                          // at cfg2 batch 64 -- with three waves per SIMD the shorter per-wave chain buys nothing; 168 VGPRs, 2 spilled)
-#endif
+// (round 3 experiment, removed in round 4: the Q.Er^T product one step ahead of its tile -- band read at the top of the step, the
+//  product's MFMAs under the softmax -- ran 0.567-0.569 ms against 0.562-0.563 at cfg2 batch 64: with three waves per SIMD the
+//  shorter per-wave chain buys nothing; profiles/README.md)
 #ifndef MGX_FWD_PEEL
 #define MGX_FWD_PEEL 0      // timing experiments only (tools/peel_fwd.sh): 1 no E-fragment loads in the main loop | 2 no band round trip |
 #endif                      // 4 no exponentials | 8 K / V prefetch re-reads tile 0 | 16 no parity XOR of the band-store addresses | 32 no row-sum
@@ -94,25 +93,31 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     const size_t ld = (size_t)3 * d;                     // qkv row stride (elements)
     const uint16_t* qkv_b = qkv + (size_t)b * L * ld;
 
-    // ---- staging roles: thread -> (row, 16-byte chunk) of a 32x64 tile -------------------------
-    const int srow = tid >> 3, sch = tid & 7;
-    const int st_offR = imgR_off(srow, sch), st_offT = imgT_off(srow, sch);
-    // Every global address of the sweep is (wave-uniform base in SGPRs) + (32-bit per-lane offset) + immediate, so a load costs
-    // no vector address arithmetic.  Every load is unconditional with a clamped index: a load inside a branch makes the
-    // compiler drain the whole VMEM queue where the branch rejoins.  Data of clamped tiles / chunks is never used.
+    // ---- staging: K and V tiles go global -> LDS by DMA (rel_attn_common.hpp: dma16).  Thread tid owns the 16-byte slot tid of
+    // both images -- row tid >> 3, PHYSICAL chunk tid & 7 -- and fetches the logical chunk the image's swizzle puts there: a tile
+    // costs a wave two DMA instructions, no registers and no ds_write (until round 4: two loads parked in registers for a step,
+    // then two stores).  Every global address of the sweep is (wave-uniform base in SGPRs) + (32-bit per-lane offset), every
+    // request unconditional with a clamped index.
+    const int srow = tid >> 3, spc = tid & 7;
     const char* kv_base = (const char*)(qkv_b + d + hd * 64);                 // K columns of this head; V is d elements further
-    const uint32_t kv_voff = (uint32_t)((srow * ld + sch * 8) * 2);            // bytes
+    const uint32_t k_voff = (uint32_t)((srow * ld + (spc ^ ((srow >> 1) & 7)) * 8) * 2);              // image R (imgR_off inverted)
+    const uint32_t v_voff = (uint32_t)((srow * ld + (spc ^ (((srow >> 1) & 1) << 2)) * 8) * 2 + d * 2);   // image T (imgT_off)
     const uint32_t tile_bytes = (uint32_t)(32 * ld * 2);                       // one 32-row step of qkv
-    auto k_tile = [&](int t) { return *(const u32x4*)(kv_base + (size_t)t * tile_bytes + kv_voff); };
-    auto v_tile = [&](int t) { return *(const u32x4*)(kv_base + (size_t)t * tile_bytes + (size_t)d * 2 + kv_voff); };
+    const uint32_t lds_w = lds_addr_of(smem) + w * 1024;                        // this wave's 1 KB of a 4 KB image
+    auto stage_kv = [&](int t, int buf) {                                      // key tile t -> LDS buffers `buf`
+        const char* tb = kv_base + (size_t)t * tile_bytes;
+        dma16(tb, k_voff, lds_w + OFF_K + buf * TILE_BYTES);
+        dma16(tb, v_voff, lds_w + OFF_V + buf * TILE_BYTES);
+    };
+    // the DMA of a step is the last VMEM operation the wave issues in it: everything has landed at vmcnt(0)
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     const uint32_t lane16 = (uint32_t)lane * 16u;
     auto ef = [&](int q, int ks) {
         return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)Ef + (size_t)max(q, 0) * 4096 + ks * 1024 + lane16));
     };
 
     // ---- prologue: K/V tile 0, key-padding words ---------------------------------------------------
-    *(u32x4*)(smem + OFF_K + st_offR) = k_tile(0);
-    *(u32x4*)(smem + OFF_V + st_offT) = v_tile(0);
+    stage_kv(0, 0);
     // (no __syncthreads_or: it allocates static LDS, which moves the dynamic base off 0 and costs one v_add per band store)
     int anypad = 0;
     if (padbits) {
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
             e[ks] = ef(q0, ks);
         }
     }
+    landed();
     __syncthreads();
 
     // band addressing (rel_attn_common.hpp): register r writes row slot r of region hh.  wcl[r] = absolute LDS address of
@@ -243,53 +249,9 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     // ---- main loop: tiles strictly below every wave's diagonal, no padded keys: ONE branch-free body -------------
     const int nmain = (WRITE_W || anypad || !CAUSAL) ? 0 : Q0;       // Q0 <= ntw - 1: a next tile always exists inside this loop
     int s = 0;
-#if MGX_FWD_AHEAD
-    // The Q.Er^T product runs ONE STEP AHEAD of the tile that needs it: on entry of step s the band already holds both chunks of
-    // the tile (dq and dq-1), so the step starts with the band read and its chain is band read -> K.Q^T -> softmax -> P.V; the
-    // product of chunk dq-2 (for the next step) is independent of that chain -- its MFMAs run under the softmax's VALU work and its
-    // 16 band stores go out behind the P.V MFMAs (they overwrite the slot of chunk dq, which was read at the top).
-    if (nmain > 0) {
-        f32x16 qe = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
-        band_put(qe, q0 - 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(q0 - 2, ks);
-    }
     for (; s < nmain; ++s) {
         const int cur = s & 1;
         const int tn = (MGX_FWD_PEEL & 8) ? 0 : min(s + 1, ntw - 1);
-        const u32x4 kreg = k_tile(tn);
-        const u32x4 vreg = v_tile(tn);
-        const int dq = q0 - s;                            // >= 1
-        wave_lds_fence();
-        f32x16 c = band_get(dq);
-        wave_lds_fence();
-        const char* kt = smem + OFF_K + cur * TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
-        f32x16 qe = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qe = mfma(qf[ks], e[ks], qe);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(dq - 3, ks);              // chunk of the next step's product
-        __builtin_amdgcn_sched_barrier(0x78F);             // VMEM may not sink below: the fragments are needed in the next step
-        softmax_pv(c, cur);
-        band_put(qe, dq - 2);
-        *(u32x4*)(smem + OFF_K + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
-        *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
-        __syncthreads();
-    }
-    if (nmain > 0) {                                      // hand-over to the general body: it forms chunk dq-1 itself (again)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) e[ks] = ef(q0 - s - 1, ks);
-    }
-#else
-    for (; s < nmain; ++s) {
-        const int cur = s & 1;
-        const int tn = (MGX_FWD_PEEL & 8) ? 0 : min(s + 1, ntw - 1);
-        const u32x4 kreg = k_tile(tn);
-        const u32x4 vreg = v_tile(tn);
         const int dq = q0 - s;                            // >= 1
         f32x16 c = zero16();
 #pragma unroll
@@ -304,17 +266,17 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) e[ks] = ef(dq - 2, ks);          // chunk of the next step
         }
+        // the next key tile, into the buffers every wave left at the last barrier.  AFTER the E loads: the compiler's wait for
+        // those at the top of the next step (it does not know about the DMA) then is the vmcnt(0) this step ends with anyway
+        stage_kv(tn, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0x78F);             // VMEM may not sink below: the fragments are needed at the top of the next step
         const char* kt = smem + OFF_K + cur * TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) c = mfma(frag_R(kt, a, hh, ks), qf[ks], c);
         softmax_pv(c, cur);
-        *(u32x4*)(smem + OFF_K + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
-        *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
+        landed();
         __syncthreads();
     }
-
-#endif
 
     // ---- general body: the diagonal 128 x 128 block (a wave is full / on its diagonal / done), padded keys,
     //      weights output ------------------------------------------------------------------------------------------
@@ -322,8 +284,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     for (; s < ntw; ++s) {
         const int cur = s & 1;
         const int tn = min(s + 1, ntw - 1);
-        const u32x4 kreg = k_tile(tn);
-        const u32x4 vreg = v_tile(tn);
+        stage_kv(tn, cur ^ 1);
         const int dq = q0 - s;                            // causal: wave active iff dq >= 0
         if (!CAUSAL || dq >= 0) {
             const uint32_t pw = CAUSAL ? padword(s) : 0u;
@@ -377,10 +338,7 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
                 softmax_pv(c, cur);
             }
         }
-        if (s + 1 < ntw) {
-            *(u32x4*)(smem + OFF_K + (cur ^ 1) * TILE_BYTES + st_offR) = kreg;
-            *(u32x4*)(smem + OFF_V + (cur ^ 1) * TILE_BYTES + st_offT) = vreg;
-        }
+        landed();
         __syncthreads();
     }
 
