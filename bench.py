@@ -61,6 +61,8 @@ def parse():
                     "workload.  cfg4: BASELINE configs[3] at its single-GPU share (MuMIDI V=486, 12 layers, d=768, L=4096, batch 4) as "
                     "the main line -- for profiling; the default run already reports it in its `cfg4` block")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the cfg4 block (N=1 only)")
+    ap.add_argument("--deterministic", action="store_true", help="run with mgx_set_deterministic (order-independent integer "
+                    "atomics for the cross-workgroup sums; also MGX_DETERMINISTIC=1): reported in config.deterministic")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); rounds 1-3 were quoted at 32, which "
                     "reads about 2 %% lower on the same box (profiles/README.md)")
     ap.add_argument("--seq-len", type=int, default=None)
@@ -408,6 +410,9 @@ def main():
     from musicgeneration_amd.optim import FusedAdam
 
     V, d, nl, L, B = args.vocab, args.d_model, args.layers, args.seq_len, args.batch
+    from musicgeneration_amd import ops as _ops
+    if args.deterministic:
+        _ops.set_deterministic(True, dev)
     torch.manual_seed(0)
     mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=args.dropout).to(dev)
     mt.train()
@@ -468,7 +473,7 @@ def main():
         "config": {"workload": f"{'cfg2 REMI_EventSeq' if args.workload == 'cfg2' else 'cfg4 MuMIDI_EventSeq'} MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} "
                                f"bf16, fwd+smoothed-CE+bwd+Adam/Noam, dropout {args.dropout}",
                    "global_batch": world * B, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
-                   "final_loss": loss_val},
+                   "final_loss": loss_val, "deterministic": _ops.deterministic()},
         "model_mfma_frac": value * train_flops_per_event(nl, d, L, V) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
     if world > 1:

@@ -34,10 +34,26 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows */
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows; 16: mgx_smooth_ce_bwd takes a device-side scale, mgx_pad_bitmap a flag, mgx_set_deterministic */
 #define MGX_ABI_VERSION 16
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
+
+/* ---- deterministic-reduction mode (ABI 16)                               SURVEY 5.2 / 8c "DP N-GPU vs 1-GPU"
+ * The sums that cross workgroups -- dE (mgx_rel_attn_bwd), the dW / db of mgx_linear_dw (the vocabulary projection), the bias
+ * gradients of mgx_linear_dw_grouped, the embedding gradient (mgx_embed_bwd) and the four statistics of mgx_smooth_ce_fwd --
+ * end in fp32 atomics, so their last bits depend on the order in which workgroups arrive.  After
+ * mgx_set_deterministic(scratch, bytes) those kernels add 64-bit FIXED-POINT integers (value * 2^30, each partial sum rounded
+ * once) into `scratch` and a fold pass converts the totals: integer addition is associative, so two runs on the same inputs
+ * -- and a data-parallel run against a single-process run of the same global batch, up to the all-reduce's own order -- give
+ * the same bits.  Partial sums are quantised to 2^-30 ~ 9.3e-10 and must stay below 8.6e9 in magnitude; speed is within a
+ * few percent of the default.  Everything else in the library is deterministic as it is.
+ *   scratch: device memory, 8-byte aligned, owned by the caller and alive until the mode is switched off with
+ *            mgx_set_deterministic(NULL, 0); the largest user needs 8 * max(N*K + N, V*d, 64*L) bytes (16 MiB covers cfg4).
+ *   The setting is process-wide (the one piece of mutable state in the library); calls that use the scratch must be issued on
+ *   ONE stream at a time.                                                                                       */
+int mgx_set_deterministic(void* scratch, size_t bytes);
+int mgx_deterministic(void);          /* 1 while a scratch is registered */
 
 /* ---- K1: token embedding * sqrt(d) + sinusoid PE (+dropout)      layers.py:226-229, 22-39 ----
  * tok int32 [rows] (rows = B*L), table f32 [V,d], pe f32 [L,d] (precomputed once, device resident),

@@ -19,6 +19,8 @@ EXPECTED_ABI = 16
 SIGNATURES = {
     "mgx_abi_version": [],
     "mgx_device_count": [],
+    "mgx_set_deterministic": [_vp, _sz],
+    "mgx_deterministic": [],
     "mgx_embed_pe_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_pad_bitmap": [_vp, _vp, _vp, _i, _i, _i, _vp],

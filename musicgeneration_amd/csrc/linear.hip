@@ -678,7 +678,9 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 3) void linear_dx_kernel(const uint
 // unconditional, columns beyond N / K clamped into range (they only feed accumulator entries that are never added).
 template <bool EXACT>
 MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, float* __restrict__ gW,
-                     float* __restrict__ gb, int M, int N, int K, int tile, int mbeg, int mend, char* smem) {
+                     float* __restrict__ gb, int M, int N, int K, int tile, int mbeg, int mend, char* smem,
+                     long long* __restrict__ detW = nullptr, long long* __restrict__ detb = nullptr) {
+    // detW / detb (deterministic mode): fixed-point images of this launch's updates of gW / gb; the M-splits add integers
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 1, wn = w & 1;
@@ -817,7 +819,10 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
         }
         if (lane < 16 && n0 + ch * 8 < N) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) atomicAdd(gb + n0 + ch * 8 + k, bsum[k]);
+            for (int k = 0; k < 8; ++k) {
+                if (detb) det_add(detb + n0 + ch * 8 + k, bsum[k]);
+                else atomicAdd(gb + n0 + ch * 8 + k, bsum[k]);
+            }
         }
     }
     // D[n][k]: k on the lane -> one register = two 128-byte row segments per wave-instruction
@@ -830,7 +835,10 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + 64 * wm + 32 * rt + crow(r, hh);
-                if (n < N) atomicAdd(gW + (size_t)n * K + k, acc[rt][ct][r]);
+                if (n < N) {
+                    if (detW) det_add(detW + (size_t)n * K + k, acc[rt][ct][r]);
+                    else atomicAdd(gW + (size_t)n * K + k, acc[rt][ct][r]);
+                }
             }
         }
     }
@@ -839,14 +847,15 @@ MGX_DEV void dw_tile(const uint16_t* __restrict__ dY, const uint16_t* __restrict
 __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const uint16_t* __restrict__ dY,
                                                            const uint16_t* __restrict__ X,
                                                            float* __restrict__ gW, float* __restrict__ gb, int M, int N,
-                                                           int K, int mchunk, int tiles) {
+                                                           int K, int mchunk, int tiles, long long* __restrict__ detW,
+                                                           long long* __restrict__ detb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 1-D grid of tiles x splits units, unit = split * tiles + tile; each XCD walks a contiguous run of units, i.e.
     // (mostly) the tiles of ONE row chunk: the dY / X blocks those tiles share are fetched into that XCD's L2 once
     const int u = xcd_remap(blockIdx.x, gridDim.x);
     const int mbeg = (u / tiles) * mchunk;
-    if (M % mchunk == 0 && mchunk % BK == 0) dw_tile<true>(dY, X, gW, gb, M, N, K, u % tiles, mbeg, mbeg + mchunk, smem);
-    else dw_tile<false>(dY, X, gW, gb, M, N, K, u % tiles, mbeg, min(M, mbeg + mchunk), smem);
+    if (M % mchunk == 0 && mchunk % BK == 0) dw_tile<true>(dY, X, gW, gb, M, N, K, u % tiles, mbeg, mbeg + mchunk, smem, detW, detb);
+    else dw_tile<false>(dY, X, gW, gb, M, N, K, u % tiles, mbeg, min(M, mbeg + mchunk), smem, detW, detb);
 }
 
 // Several weight gradients that share the row count M (one encoder block's QKV / fc / FFN projections) in ONE launch:
@@ -893,6 +902,7 @@ struct DwRing {
     const uint16_t* X[MGX_DW_MAX_GROUP];
     float* gW[MGX_DW_MAX_GROUP];
     float* gb[MGX_DW_MAX_GROUP];
+    long long* detb[MGX_DW_MAX_GROUP];                     // deterministic mode: fixed-point images of the bias-gradient updates (else NULL)
     int N[MGX_DW_MAX_GROUP], K[MGX_DW_MAX_GROUP];
     int first_tile[MGX_DW_MAX_GROUP + 1];                  // prefix sums of the 256 x 256 tile counts
     int n, splits, steps_per_split;
@@ -1083,7 +1093,10 @@ __global__ __launch_bounds__(512, 1) void linear_dw_ring_kernel(const DwRing g, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = gsum[i] + __shfl_xor(gsum[i], 32, 64);
-            if (hh == 0) atomicAdd(g.gb[p] + n0 + 128 * wm + 32 * i + l31, v);
+            if (hh == 0) {
+                if (g.detb[p]) det_add(g.detb[p] + n0 + 128 * wm + 32 * i + l31, v);
+                else atomicAdd(g.gb[p] + n0 + 128 * wm + 32 * i + l31, v);
+            }
         }
     }
 }
@@ -1431,8 +1444,15 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;
     if (mchunk < 64) mchunk = 64;
     splits = (M + mchunk - 1) / mchunk;
+    int rc;
+    long long* det = mgx_det_scratch((size_t)N * K + N, stream, &rc);      // deterministic mode: integer atomics + fold
+    if (rc != MGX_OK) return rc;
     hipLaunchKernelGGL(linear_dw_kernel, dim3(tiles * splits), dim3(256), LDS_BYTES, (hipStream_t)stream, dY, X, gW, gb, M,
-                       N, K, mchunk, tiles);
+                       N, K, mchunk, tiles, det, det ? det + (size_t)N * K : nullptr);
+    if (det) {
+        launch_det_fold(det, gW, (size_t)N * K, 1.f, 1, (hipStream_t)stream);
+        if (gb) launch_det_fold(det + (size_t)N * K, gb, (size_t)N, 1.f, 1, (hipStream_t)stream);
+    }
     MGX_CHECK_LAUNCH("mgx_linear_dw");
     return MGX_OK;
 }
@@ -1449,7 +1469,7 @@ static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRin
     for (int i = 0; i < count; ++i) {
         const mgx_dw_problem& q = problems[i];
         if (q.N % 256 != 0 || q.K % 256 != 0) return false;
-        g.dY[i] = q.dY; g.X[i] = q.X; g.gW[i] = q.gW; g.gb[i] = q.gb; g.N[i] = q.N; g.K[i] = q.K;
+        g.dY[i] = q.dY; g.X[i] = q.X; g.gW[i] = q.gW; g.gb[i] = q.gb; g.detb[i] = nullptr; g.N[i] = q.N; g.K[i] = q.K;
         g.first_tile[i + 1] = g.first_tile[i] + (q.N / 256) * (q.K / 256);
     }
     const int tiles = g.first_tile[count];
@@ -1499,10 +1519,31 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, 
                     "mgx_linear_dw_grouped: workspace must be 16-byte aligned and >= mgx_linear_dw_grouped_workspace() = %zu bytes "
                     "(got %zu)", need, ws_bytes);
         const int tiles = rg.first_tile[rg.n];
+        // deterministic mode: the weight tiles already are (partial tiles in the workspace, added in split order by the fix-up
+        // pass); the bias gradients, which the M-splits add with atomics, go through the fixed-point scratch
+        size_t nb = 0;
+        for (int i = 0; i < count; ++i) nb += problems[i].gb ? (size_t)problems[i].N : 0;
+        int rc;
+        long long* det = nb ? mgx_det_scratch(nb, stream, &rc) : (rc = MGX_OK, nullptr);
+        if (rc != MGX_OK) return rc;
+        if (det) {
+            size_t o = 0;
+            for (int i = 0; i < count; ++i)
+                if (problems[i].gb) { rg.detb[i] = det + o; o += (size_t)problems[i].N; }
+        }
         hipLaunchKernelGGL(linear_dw_ring_kernel, dim3(tiles * rg.splits), dim3(512), RG_LDS, (hipStream_t)stream, rg, M,
                            (float*)workspace);
         hipLaunchKernelGGL(dw_fixup_kernel, dim3(64, tiles), dim3(256), 0, (hipStream_t)stream, rg, (const float*)workspace);
+        if (det)
+            for (int i = 0; i < count; ++i)
+                if (rg.detb[i]) launch_det_fold(rg.detb[i], problems[i].gb, (size_t)problems[i].N, 1.f, 1, (hipStream_t)stream);
         MGX_CHECK_LAUNCH("mgx_linear_dw_grouped");
+        return MGX_OK;
+    }
+    if (mgx_deterministic()) {          // no ring plan for these shapes: one deterministic launch per weight
+        for (int i = 0; i < count; ++i)
+            if (int rc = mgx_linear_dw(problems[i].dY, problems[i].X, problems[i].gW, problems[i].gb, M, problems[i].N, problems[i].K, stream))
+                return rc;
         return MGX_OK;
     }
     const int tiles = g.first_tile[count];

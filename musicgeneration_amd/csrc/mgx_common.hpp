@@ -110,6 +110,29 @@ static inline int env_digit(const char* name, int dflt) {      // first characte
 
 // ---- host-side error plumbing -----------------------------------------------------------------
 void mgx_set_error(const char* fmt, ...);
+
+// ---- deterministic-reduction mode (api.cpp) ------------------------------------------------------------------------------
+// Cross-workgroup sums as 64-bit fixed-point integer atomics (value * 2^30) into a caller-registered scratch, folded back to
+// fp32 by det_fold_kernel: the total is independent of the order in which the workgroups arrive.
+long long* mgx_det_scratch(size_t elems, void* stream, int* rc);
+constexpr float MGX_DET_SCALE = 1073741824.f;              // 2^30: range +-8.6e9, resolution 9.3e-10
+MGX_DEV void det_add(long long* dst, float v) {
+    atomicAdd((unsigned long long*)dst, (unsigned long long)__float2ll_rn(v * MGX_DET_SCALE));   // two's complement: wraps like a signed add
+}
+// dst[i] (+)= scale * src[i] / 2^30
+static __global__ __launch_bounds__(256) void det_fold_kernel(const long long* __restrict__ src, float* __restrict__ dst, size_t n,
+                                                              float scale, int accumulate) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = (float)((double)src[i] * (1.0 / 1073741824.0)) * scale;
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+static inline void launch_det_fold(const long long* src, float* dst, size_t n, float scale, int accumulate, hipStream_t s) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(det_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n, scale, accumulate);
+}
 #define MGX_REQUIRE(cond, code, ...)            \
     do {                                        \
         if (!(cond)) {                          \

@@ -1083,7 +1083,8 @@ constexpr int SLOTS = 2;                                   // tiles per wave and
 
 __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dst, float* __restrict__ dEr /* = dE + (M-L)*64 */,
-    int bgroup, int ngroups, int wg_per_group, int L, int d) {
+    int bgroup, int ngroups, int wg_per_group, int L, int d,
+    long long* __restrict__ det /* deterministic mode: [L][64] fixed-point image of this launch's dEr */) {
     using namespace k3t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1216,6 +1217,12 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
     for (int r = 0; r < 16; ++r) {
         const int dl = d0 - 32 + 32 * w + crow(r, hh);
         if (dl >= 0 && dl < L) {
+            if (det) {
+                long long* drow = det + (size_t)(L - 1 - dl) * 64;
+                det_add(drow + l31, 0.125f * de0[r]);
+                det_add(drow + 32 + l31, 0.125f * de1[r]);
+                continue;
+            }
             float* row = dEr + (size_t)(L - 1 - dl) * 64;
             atomicAdd(row + l31, 0.125f * de0[r]);
             atomicAdd(row + 32 + l31, 0.125f * de1[r]);
@@ -1317,8 +1324,12 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
             nwg += ((long)bgd * heads * ((L - t * k3t::DIAGS * 32 + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
         const long grid = nwg * 8 * ((ngr + 7) / 8);    // groups in rounds of eight, one per XCD
         MGX_REQUIRE(grid < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
+        int rc;
+        long long* det = mgx_det_scratch((size_t)L * 64, stream, &rc);      // deterministic mode: integer atomics + fold
+        if (rc != MGX_OK) return rc;
         hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)grid), dim3(64 * k3t::NW), k3t::LDS_BYTES, s, qkv, dst,
-                           dE + (size_t)(M - L) * 64, bgd, ngr, (int)nwg, L, d);
+                           dE + (size_t)(M - L) * 64, bgd, ngr, (int)nwg, L, d, det);
+        if (det) launch_det_fold(det, dE + (size_t)(M - L) * 64, (size_t)L * 64, 1.f, 1, s);
     }
     if (parts & 16) {
         const dim3 ge(B * heads, ((L >> 5) + k3::W3 - 1) / k3::W3);

@@ -1,6 +1,7 @@
 // HBM-bound satellites of the hot path: embedding+PE, residual+LayerNorm, smoothed CE, Adam.
 // All are streaming kernels: 16-byte vector loads/stores, one wave per row for the row ops,
 // wave-shuffle reductions, fp32 statistics.  Roofline: HBM (algorithmic bytes in DESIGN.md).
+#include <type_traits>
 #include "mgx_common.hpp"
 
 // =================================================================================================
@@ -37,9 +38,14 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(
 // element -- gridDim.y adds per element, not one per token.  (One block per vocabulary row, as until round 3, is a chain of
 // dependent scan / gather phases over the whole batch: 235 us at cfg2 / batch 64 for a 67 MB read.)
 constexpr int EB_CHUNK = 4096;
+// DET (deterministic mode): the order of the LDS hit list depends on the arrival order of the LDS atomics and the token
+// ranges' sums arrive in any order, so every addend (one bf16 gradient element, times its dropout multiplier) is accumulated as
+// a 64-bit fixed-point integer, in the thread, across the waves and across the ranges: the sum is independent of all three
+// orders.  `det` is the [V, d] int64 image of dtable's update (folded in, times sqrt(d), by the caller).
+template <bool DET>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int32_t* __restrict__ tok, const uint16_t* __restrict__ dout, float* __restrict__ dtable,
-    int rows, int d, float scale, DropCfg dc) {
+    int rows, int d, float scale, DropCfg dc, long long* __restrict__ det) {
     const int v = blockIdx.x;
     const int gpr = d >> 3;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -47,10 +53,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int r_lo = blockIdx.y * per, r_hi = min(rows, r_lo + per);
     __shared__ int hits[EB_CHUNK];
     __shared__ int nhit;
-    __shared__ float part[3][64][8];
+    using acc_t = typename std::conditional<DET, long long, float>::type;
+    __shared__ acc_t part[3][64][8];
     for (int g0 = 0; g0 < gpr; g0 += 64) {                  // column pass (one for d <= 512)
         const int gi = g0 + lane;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        acc_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int base = r_lo; base < r_hi; base += EB_CHUNK) {
             if (tid == 0) nhit = 0;
             __syncthreads();
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
                         for (int q = 0; q < 8; ++q) f[q] *= m[q];
                     }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] += f[q];
+                    for (int q = 0; q < 8; ++q) acc[q] += DET ? (acc_t)__float2ll_rn(f[q] * MGX_DET_SCALE) : (acc_t)f[q];
                 }
             }
             __syncthreads();
@@ -84,9 +91,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
             float* dp = dtable + (size_t)v * d + gi * 8;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float sum = (acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]) * scale;
-                if (gridDim.y == 1) dp[q] += sum;
-                else if (sum != 0.f) atomicAdd(dp + q, sum);
+                if (DET) {
+                    const long long isum = (long long)(acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]);
+                    if (isum != 0) atomicAdd((unsigned long long*)(det + (size_t)v * d + gi * 8 + q), (unsigned long long)isum);
+                } else {
+                    const float sum = (float)(acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]) * scale;
+                    if (gridDim.y == 1) dp[q] += sum;
+                    else if (sum != 0.f) atomicAdd(dp + q, sum);
+                }
             }
         }
         __syncthreads();
@@ -118,8 +130,17 @@ extern "C" int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dt
     const long rows = (long)B * L;
     int split = (int)std::min<long>(16, std::max<long>(1, rows / (2 * EB_CHUNK)));
     while (split > 1 && (long)V * split > 8192) --split;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(V, split), dim3(256), 0, (hipStream_t)stream, tok, dout, dtable, B * L, d,
-                       sqrtf((float)d), make_drop(p_drop, seed));
+    int rc;
+    long long* det = mgx_det_scratch((size_t)V * d, stream, &rc);
+    if (rc != MGX_OK) return rc;
+    if (det) {
+        hipLaunchKernelGGL(embed_bwd_kernel<true>, dim3(V, split), dim3(256), 0, (hipStream_t)stream, tok, dout, dtable, B * L, d,
+                           sqrtf((float)d), make_drop(p_drop, seed), det);
+        launch_det_fold(det, dtable, (size_t)V * d, sqrtf((float)d), 1, (hipStream_t)stream);
+    } else {
+        hipLaunchKernelGGL(embed_bwd_kernel<false>, dim3(V, split), dim3(256), 0, (hipStream_t)stream, tok, dout, dtable, B * L, d,
+                           sqrtf((float)d), make_drop(p_drop, seed), (long long*)nullptr);
+    }
     MGX_CHECK_LAUNCH("mgx_embed_bwd");
     return MGX_OK;
 }
@@ -453,7 +474,8 @@ extern "C" int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uin
 // =================================================================================================
 __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
     const uint16_t* __restrict__ logits, const int32_t* __restrict__ target, float* __restrict__ stats,
-    int32_t* __restrict__ argmax_o, float* __restrict__ row_lse, int rows, int V, int ld, float eps_ls, int pad) {
+    int32_t* __restrict__ argmax_o, float* __restrict__ row_lse, int rows, int V, int ld, float eps_ls, int pad,
+    long long* __restrict__ det /* deterministic mode: the four sums as fixed-point integers, folded into stats afterwards */) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwave = (gridDim.x * blockDim.x) >> 6;
@@ -495,8 +517,11 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
     __shared__ float red[4][4];
     if (lane == 0) { red[wid][0] = loss_acc; red[wid][1] = cnt_acc; red[wid][2] = hit_acc; red[wid][3] = row_acc; }
     __syncthreads();
-    if (threadIdx.x < 4) atomicAdd(stats + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] +
-                                                            red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 4) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (det) det_add(det + threadIdx.x, v);
+        else atomicAdd(stats + threadIdx.x, v);
+    }
 }
 
 __global__ __launch_bounds__(256) void smooth_ce_bwd_kernel(
@@ -533,8 +558,12 @@ extern "C" int mgx_smooth_ce_fwd(const uint16_t* logits, const int32_t* target, 
                 rows, V, ld);
     int grid = (rows + 3) / 4;
     if (grid > 2048) grid = 2048;
+    int rc;
+    long long* det = mgx_det_scratch(4, stream, &rc);
+    if (rc != MGX_OK) return rc;
     hipLaunchKernelGGL(smooth_ce_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
-                       argmax, row_lse, rows, V, ld, eps_ls, pad);
+                       argmax, row_lse, rows, V, ld, eps_ls, pad, det);
+    if (det) launch_det_fold(det, stats, 4, 1.f, 1, (hipStream_t)stream);
     MGX_CHECK_LAUNCH("mgx_smooth_ce_fwd");
     return MGX_OK;
 }

@@ -73,6 +73,8 @@ class MusicTransformer(torch.nn.Module):
                                         "device first (model.to('cuda')); there is no CPU fallback")
             named, buckets, padded = self._flat_order()
             self._store = FlatStore(named, dev, buckets, padded)
+            if os.environ.get("MGX_DETERMINISTIC", "0") == "1" and not ops.deterministic():
+                ops.set_deterministic(True, dev)
         return self._store
 
     def _apply(self, fn, *a, **k):     # .to()/.cuda() re-materialise parameters: rebuild lazily

@@ -28,6 +28,33 @@ def _need_cuda(*ts):
 
 
 # --------------------------------------------------------------------------------------------------
+# deterministic-reduction mode (include/mgx.h: mgx_set_deterministic)
+# --------------------------------------------------------------------------------------------------
+_det_scratch = None          # the registered buffer must outlive the mode: kept here
+
+
+def set_deterministic(on: bool = True, device=None, nbytes: int = 32 << 20) -> None:
+    """Switch the library's cross-workgroup sums (dE, vocabulary dW / db, block bias gradients, embedding gradient, loss
+    statistics) to order-independent fixed-point integer atomics: repeated runs -- and a data-parallel run against the
+    single-process run of the same global batch -- then agree bit for bit on everything the kernels compute.  Costs a few
+    percent; ``MGX_DETERMINISTIC=1`` in the environment switches it on when the first model moves to the GPU.  Process-wide;
+    use ONE stream for the training kernels while it is on."""
+    global _det_scratch
+    lib = _lib.load()
+    if not on:
+        check(lib.mgx_set_deterministic(None, 0), "mgx_set_deterministic")
+        _det_scratch = None
+        return
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device if device is not None else torch.device("cuda"))
+    check(lib.mgx_set_deterministic(ptr(buf), buf.numel()), "mgx_set_deterministic")
+    _det_scratch = buf
+
+
+def deterministic() -> bool:
+    return bool(_lib.load().mgx_deterministic())
+
+
+# --------------------------------------------------------------------------------------------------
 # raw launchers (no autograd)
 # --------------------------------------------------------------------------------------------------
 def pad_bitmap(tok: torch.Tensor, pad: int, flag: torch.Tensor | None = None) -> torch.Tensor:

@@ -46,12 +46,20 @@ def main(out_path):
         if rccl1:                                                       # the loss-weight all-reduce too (== 1 here)
             loss = loss * dp.loss_weight((y != V - 1).sum())
         loss.backward()
+        if it == 0:                                                     # the (all-reduced) gradient of the first step, before Adam
+            dp.wait_all()
+            torch.cuda.synchronize()
+            gr = mt.store().grad.double() * dp.grad_scale
+            first = {"grad_sum": float(gr.sum()), "grad_abs": float(gr.abs().sum()), "grad_l2": float(gr.norm())}
         sch.step()                                                      # waits for the bucket all-reduces, then Adam
         opt.zero_grad()
         losses.append(float(dp.all_reduce_scalar_mean(loss.detach())))
     st = mt.store()
+    import hashlib
+    from musicgeneration_amd import ops
     res = {"losses": losses, "param_sum": float(st.param.double().sum()), "param_abs": float(st.param.double().abs().sum()),
-           "buckets": len(st.buckets), "bytes_reduced": dp.bytes_reduced, "describe": dp.describe()}
+           "param_hash": hashlib.sha256(st.param.detach().cpu().numpy().tobytes()).hexdigest(), "deterministic": ops.deterministic(),
+           "buckets": len(st.buckets), "bytes_reduced": dp.bytes_reduced, "describe": dp.describe(), **first}
     if rank == 0:
         json.dump(res, open(out_path, "w"))
     if world > 1 or rccl1:

@@ -67,3 +67,36 @@ def test_rccl_world_of_one_matches_no_dp(tmp_path):
         assert abs(a - b) <= tol * abs(a), (one["losses"], rccl["losses"], noise)
     pnoise = abs(one["param_sum"] - again["param_sum"]) / one["param_abs"]
     assert abs(one["param_sum"] - rccl["param_sum"]) <= max(10 * pnoise, 1e-5) * one["param_abs"]
+
+
+def test_deterministic_mode_repeats_bit_for_bit_and_rccl_world_of_one_equals_no_dp(tmp_path):
+    """MGX_DETERMINISTIC=1 (include/mgx.h: mgx_set_deterministic): the cross-workgroup sums become order-independent integer
+    atomics, so (a) two runs of the same six training steps end in the SAME parameter bytes and the same losses, and (b) the run
+    whose every collective goes through RCCL (a world of one: the sum over one rank is the identity) equals them bit for bit --
+    the noise floor test_rccl_world_of_one_matches_no_dp has to measure is gone."""
+    one = _run(1, str(tmp_path / "one.json"), 0, MGX_DETERMINISTIC="1")
+    again = _run(1, str(tmp_path / "again.json"), 0, MGX_DETERMINISTIC="1")
+    rccl = _run(1, str(tmp_path / "rccl.json"), 0, MGX_DETERMINISTIC="1", MGX_TEST_RCCL1="1", MGX_TEST_PORT=str(_free_port()))
+    assert one["deterministic"] and again["deterministic"] and rccl["deterministic"]
+    assert one["losses"] == again["losses"] and one["param_hash"] == again["param_hash"]
+    assert rccl["bytes_reduced"] > 0 and rccl["describe"]["backend"] == "nccl"
+    assert one["losses"] == rccl["losses"] and one["param_hash"] == rccl["param_hash"]
+    # ... and the mode changes the numbers only by the fixed-point quantisation of the partial sums
+    plain = _run(1, str(tmp_path / "plain.json"), 0)
+    assert not plain["deterministic"]
+    assert abs(plain["losses"][0] - one["losses"][0]) <= 1e-6 * abs(one["losses"][0])
+    assert abs(plain["grad_l2"] - one["grad_l2"]) <= 1e-5 * one["grad_l2"]
+
+
+def test_deterministic_two_ranks_match_one_process_to_fp32_rounding(tmp_path):
+    """data-parallel N ranks vs one process on the same global batch, loss rtol 1e-5 (fp32 reduce).  In deterministic
+    mode nothing but the grouping of the sums differs between the two (each rank sums its rows, the all-reduce adds the ranks):
+    the first step's loss and its gradient agree to fp32 rounding; later steps stay within the bf16-shadow flip noise."""
+    one = _run(1, str(tmp_path / "one.json"), 0, MGX_DETERMINISTIC="1")
+    two = _run(2, str(tmp_path / "two.json"), _free_port(), MGX_DETERMINISTIC="1")
+    assert two["deterministic"] and two["bytes_reduced"] > 0
+    assert abs(one["losses"][0] - two["losses"][0]) <= 1e-5 * abs(one["losses"][0])
+    assert abs(one["grad_l2"] - two["grad_l2"]) <= 1e-5 * one["grad_l2"]
+    assert abs(one["grad_sum"] - two["grad_sum"]) <= 1e-5 * one["grad_abs"]
+    for a, b in zip(one["losses"], two["losses"]):
+        assert abs(a - b) <= 1e-3 * abs(a), (one["losses"], two["losses"])

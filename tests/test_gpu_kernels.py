@@ -476,3 +476,49 @@ def test_rel_attn_fwd_redoes_a_main_loop_tile_that_leaves_the_safe_range():
     v70 = qkv[0, 70, 2 * d:2 * d + 64].float()
     assert (ctx[0, 400, :64] - v70).abs().max().item() < 2e-2
     assert abs(lse.view(B, d // 64, L)[0, 0, 400].item() - 128.0) < 4.0          # 128 + the relative term of that pair
+
+
+def test_deterministic_mode_kernels_repeat_and_agree_with_the_default():
+    """mgx_set_deterministic: the kernels that end in atomics (dE, single-weight dW / db, embedding gradient, CE statistics), run
+    twice on the same inputs, give identical bits; against the default (fp32 atomics) they differ only by summation order and the
+    2^-30 quantisation of the partial sums."""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    B, L, d, V = 3, 256, 128, 90
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    E = (torch.randn(L, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dctx = torch.randn(B, L, d, generator=g).to(torch.bfloat16).to(dev)
+    ctx, lse = ops.rel_attn_fwd(qkv, E, None)
+    tok = torch.randint(0, V, (B, L), generator=g, dtype=torch.int32).to(dev)
+    dout = torch.randn(B, L, d, generator=g).to(torch.bfloat16).to(dev)
+    M = 4096
+    dy = torch.randn(M, 384, generator=g).to(torch.bfloat16).to(dev)
+    x = torch.randn(M, 128, generator=g).to(torch.bfloat16).to(dev)
+    logits = (torch.randn(B * L, V, generator=g) * 3).to(torch.bfloat16).to(dev)
+    tgt = torch.randint(0, V, (B * L,), generator=g, dtype=torch.int32).to(dev)
+
+    def run():
+        dE = torch.zeros(L, 64, device=dev)
+        ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE)
+        dtab = torch.zeros(V, d, device=dev)
+        ops.embed_bwd(tok, dout, dtab, 0.1, 5)
+        gw, gb = torch.zeros(384, 128, device=dev), torch.zeros(384, device=dev)
+        ops.linear_dw(dy, x, gw, gb)
+        stats, _, _ = ops.smooth_ce_fwd(logits, tgt, V, 0.1, V - 1)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (dE, dtab, gw, gb, stats)]
+
+    plain = run()
+    assert not ops.deterministic()
+    ops.set_deterministic(True)
+    try:
+        assert ops.deterministic()
+        d1, d2 = run(), run()
+    finally:
+        ops.set_deterministic(False)
+    assert not ops.deterministic()
+    for a, b, p, name in zip(d1, d2, plain, ("dE", "dtable", "gW", "gb", "stats")):
+        assert torch.equal(a, b), name
+        assert _relerr(a, p) < 1e-5, (name, _relerr(a, p))
+        assert (a - p).abs().max().item() <= 1e-5 * p.abs().max().item() + 1e-8, name
