@@ -8,7 +8,7 @@ with the source tree (it is git-ignored, not gpurun-ignored).
 macros: the timing-only "peel" / in-kernel "stamp" builds the profile notes quote are made this way, from the
 tracked sources, and loaded with `MGX_LIB_PATH=musicgeneration_amd/libmgx_NAME.so` (tools/peel_*.sh, tools/ab.sh).
 `--experiments` additionally compiles the alternative kernels kept under tools/experiments/ (two forward-attention
-structures that measured slower) and defines MGX_EXPERIMENTS=1, which is also what enables the environment knobs
+structures and the 64-keys-per-wave dK/dV kernel, all measured slower) and defines MGX_EXPERIMENTS=1, which is also what enables the environment knobs
 (MGX_ATTN_FWD64, MGX_FWD_LDS, MGX_DKV_LDS, MGX_ATTN_BGROUP): the product library reads none of them."""
 from __future__ import annotations
 
@@ -24,7 +24,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgx.so")
 SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_bwd.hip", "linear.hip", "decode.hip", "gru_train.hip"]
 EXPERIMENT_DIR = os.path.join(ROOT, "tools", "experiments")
-EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip"]      # --experiments builds only
+EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip", "rel_attn_bwd64.hip"]      # --experiments builds only
 # per-file flags.  The 64-rows-per-wave attention kernels run one wave per SIMD with the whole 512-entry register file:
 # MFMA results that VALU code reads (scores) must stay in arch VGPRs (with more than 256 registers available hipcc otherwise
 # gives every MFMA an AGPR destination and copies each result out), and the SLP vectoriser must not pair the two blocks'

@@ -1310,6 +1310,14 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
 #endif
         hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), dkv_lds, s, qkv, EfS, padbits, dctx, nlse2, ndelta, dqkv, dst, L, d, bg);
     }
+#if MGX_EXPERIMENTS
+    if (parts & 64) {                                   // experiment builds: dK/dV with 64 keys per wave (tools/experiments/rel_attn_bwd64.hip)
+        MGX_REQUIRE(L % 128 == 0 && !(parts & 4), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: parts bit 6 needs L%%128==0 and excludes bit 2");
+        dkv64_launch(qkv, EfA, padbits, dctx, nlse2, ndelta, dqkv, dst, B, L, d, bg, stream);
+    }
+#else
+    MGX_REQUIRE(!(parts & 64), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: parts bit 6 (64-key dK/dV) exists in experiment builds only");
+#endif
     if (parts & 2)
         hipLaunchKernelGGL(rel_attn_dq_lite_kernel, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, L, d, bg);
     if (parts & 32)

@@ -52,6 +52,8 @@ if a.parts & 4:
 if a.parts & 8:
     for _ in range(a.rounds):
         timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
+        if a.L % 128 == 0 and os.environ.get("MGX_LIB_PATH", "").endswith("_exp.so"):        # experiment build only
+            timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 64, dqkv, ws), 5.5, "dkv64")
 if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de_tiles")
 if a.parts & 32: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 16, dqkv, ws), 6, "de_rec")
 if a.parts & 64:
