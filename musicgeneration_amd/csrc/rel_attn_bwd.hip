@@ -382,8 +382,11 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_kernel(
 #ifndef MGX_DQL_PEEL
 #define MGX_DQL_PEEL 0      // timing experiments only (tools/peel_dq_lite.sh): bits drop parts of the dq_lite step, results are then wrong
 #endif                    // 1 dS^T patch stores | 2 three quarters of the band stores | 4 half of dS K | 8 half of dS_rel ErT | 16 K / ErT ring refills
+#ifndef MGX_DQL_KT
+#define MGX_DQL_KT 1        // K staged as image T (conflict-free transposing reads); 0 (A/B builds): image R, 2-way conflicts (rounds 1-3)
+#endif
 namespace k1l {
-constexpr int OFF_KR = 0;                                  // 2 x 4K  K image R (tile t in slot t & 1)
+constexpr int OFF_KR = 0;                                  // 2 x 4K  K image (tile t in slot t & 1)
 constexpr int OFF_ET = OFF_KR + 2 * TILE_BYTES;            // 8 x 4K  ErT chunk fragments, ring: chunk Q0 - k in slot k & 7
 constexpr int XROW = 72;                                   // bytes per row of the dS^T patch: 32 queries + pad (lane-per-row writes and the
                                                            // transposing reads both hit distinct 8-byte bank groups)
@@ -420,7 +423,10 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
     // (K tile k / chunk Q0 - k) is requested at the end of step k - 3, parked in registers for two steps, written to LDS at the
     // end of step k - 1 and read from step k on.
     const int srow = tid >> 3, sch = tid & 7;
-    const int st_offR = imgR_off(srow, sch);
+    // K is only ever read transposed here (A operand of dq^T += K^T dS^T): image T, whose ds_read_b64_tr_b16 are conflict-free (on
+    // image R -- the layout the recompute dQ kernel shares with its row reads -- they are 2-way conflicted: 27 M of this kernel's
+    // 151 M LDS cycles at cfg2 / batch 64, r03_pmc_attn_b64.json)
+    const int st_offR = MGX_DQL_KT ? imgT_off(srow, sch) : imgR_off(srow, sch);
     const char* k_base = (const char*)(qkv_b + d + hd * 64);
     const uint32_t k_voff = (uint32_t)((srow * ld + sch * 8) * 2);
     const uint32_t tile_bytes = (uint32_t)(32 * ld * 2);
@@ -488,8 +494,8 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 #pragma unroll
         for (int ss = 0; ss < ((MGX_DQL_PEEL & 4) ? 1 : 2); ++ss) {
             const bf16x8 df = frag_X(ss);
-            dq0 = mfma(frag_T_onR(kt, lane, ss, 0), df, dq0);
-            dq1 = mfma(frag_T_onR(kt, lane, ss, 1), df, dq1);
+            dq0 = mfma(MGX_DQL_KT ? frag_T(kt, lane, ss, 0) : frag_T_onR(kt, lane, ss, 0), df, dq0);
+            dq1 = mfma(MGX_DQL_KT ? frag_T(kt, lane, ss, 1) : frag_T_onR(kt, lane, ss, 1), df, dq1);
         }
 #pragma unroll
         for (int ks = 0; ks < ((MGX_DQL_PEEL & 8) ? 1 : 2); ++ks) {
