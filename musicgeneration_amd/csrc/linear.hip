@@ -1490,16 +1490,41 @@ static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRin
     return true;
 }
 
+// The problems of a group whose weights tile into whole 256 x 256 tiles go to the ring kernel, the others (cfg4's FFN weights,
+// 384 x 768: d/2 is not a multiple of 256) to the 128 x 128 grouped kernel -- until round 4 one such weight sent the whole block
+// there (cfg4: 219 us per block, 12 % of the step).
+static int dw_split(const mgx_dw_problem* problems, int count, mgx_dw_problem* ring, int* nring, mgx_dw_problem* rest, int* nrest) {
+    *nring = *nrest = 0;
+    for (int i = 0; i < count; ++i) {
+        if (problems[i].N % 256 == 0 && problems[i].K % 256 == 0) ring[(*nring)++] = problems[i];
+        else rest[(*nrest)++] = problems[i];
+    }
+    return *nring;
+}
+
 extern "C" size_t mgx_linear_dw_grouped_workspace(const mgx_dw_problem* problems, int count, int M) {
     DwRing g;
-    if (!problems || count <= 0 || count > MGX_DW_MAX_GROUP || !dw_ring_plan(problems, count, M, &g)) return 0;
+    if (!problems || count <= 0 || count > MGX_DW_MAX_GROUP) return 0;
+    mgx_dw_problem ring[MGX_DW_MAX_GROUP], rest[MGX_DW_MAX_GROUP];
+    int nr, ns;
+    if (!dw_split(problems, count, ring, &nr, rest, &ns) || !dw_ring_plan(ring, nr, M, &g)) return 0;
     return (size_t)g.first_tile[g.n] * g.splits * 65536 * sizeof(float);
 }
 
-extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* workspace, size_t ws_bytes,
+extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int count_in, int M, void* workspace, size_t ws_bytes,
                                      void* stream) {
-    MGX_REQUIRE(problems && count > 0 && count <= MGX_DW_MAX_GROUP && M > 0, MGX_ERR_SHAPE,
-                "mgx_linear_dw_grouped: need 1..%d problems and M > 0 (got %d, M=%d)", MGX_DW_MAX_GROUP, count, M);
+    MGX_REQUIRE(problems_in && count_in > 0 && count_in <= MGX_DW_MAX_GROUP && M > 0, MGX_ERR_SHAPE,
+                "mgx_linear_dw_grouped: need 1..%d problems and M > 0 (got %d, M=%d)", MGX_DW_MAX_GROUP, count_in, M);
+    // a mixed group: its ring-shaped weights first (one recursive call on that sub-group), the others below
+    mgx_dw_problem ring_p[MGX_DW_MAX_GROUP], rest_p[MGX_DW_MAX_GROUP];
+    int nring, nrest;
+    const mgx_dw_problem* problems = problems_in;
+    int count = count_in;
+    if (dw_split(problems_in, count_in, ring_p, &nring, rest_p, &nrest) && nrest > 0 && dw_ring_plan(ring_p, nring, M, nullptr)) {
+        if (int rc = mgx_linear_dw_grouped(ring_p, nring, M, workspace, ws_bytes, stream)) return rc;
+        problems = rest_p;
+        count = nrest;
+    }
     DwGroup g;
     g.n = count;
     g.first_tile[0] = 0;

@@ -1105,9 +1105,11 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
     // Batch groups are dealt to the XCDs (workgroups b and b + 8 share one, MI355X_MICROARCH.md): workgroup 8 k + x belongs to group
     // 8 (k / wg_per_group) + x.  A group's workgroups -- all the diagonal groups that re-read the same q rows -- then share an L2,
     // and with groups of ONE batch row (2 MB of q at cfg2) the re-reads are L2 hits instead of fabric reads.  Speed only.
-    const int xk = blockIdx.x >> 3;
-    const int grp = (xk / wg_per_group) * 8 + (blockIdx.x & 7);
-    if (grp >= ngroups) return;                            // padding of the last round of eight groups
+    // (ngroups % 8 == 0 on this path; otherwise -- e.g. cfg4's four batch rows per GPU -- the host passes ngroups < 0 and the
+    // groups are laid out one after the other: a round of eight with idle XCDs would leave part of the chip without work)
+    const bool dealt = ngroups > 0;
+    const int xk = dealt ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int grp = dealt ? (xk / wg_per_group) * 8 + (int)(blockIdx.x & 7) : xk / wg_per_group;
     {
         int rest = xk % wg_per_group;
         const int ntile = (nchunk + DIAGS - 1) / DIAGS;
@@ -1332,17 +1334,18 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
 #ifndef MGX_DET_BG
 #define MGX_DET_BG 1        // batch rows per group of the dE kernel (A/B builds: the attention kernels' bgroup is 8 at cfg2 / batch 64)
 #endif
-        const int bgd = (B % MGX_DET_BG == 0) ? MGX_DET_BG : 1, ngr = B / bgd;
+        const bool dealt = B % (8 * MGX_DET_BG) == 0;   // whole rounds of eight groups of MGX_DET_BG rows: one group per XCD
+        const int bgd = dealt ? MGX_DET_BG : bg, ngr = B / bgd;
         long nwg = 0;                                   // workgroups of ONE batch group
         for (int t = 0; t < (L / 32 + k3t::DIAGS - 1) / k3t::DIAGS; ++t)
             nwg += ((long)bgd * heads * ((L - t * k3t::DIAGS * 32 + k3t::RS - 1) / k3t::RS) + k3t::STEPS - 1) / k3t::STEPS;
-        const long grid = nwg * 8 * ((ngr + 7) / 8);    // groups in rounds of eight, one per XCD
+        const long grid = nwg * ngr;
         MGX_REQUIRE(grid < (1L << 31), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: grid too large");
         int rc;
         long long* det = mgx_det_scratch((size_t)L * 64, stream, &rc);      // deterministic mode: integer atomics + fold
         if (rc != MGX_OK) return rc;
         hipLaunchKernelGGL(rel_attn_de_tiles_kernel, dim3((unsigned)grid), dim3(64 * k3t::NW), k3t::LDS_BYTES, s, qkv, dst,
-                           dE + (size_t)(M - L) * 64, bgd, ngr, (int)nwg, L, d, det);
+                           dE + (size_t)(M - L) * 64, bgd, dealt ? ngr : -ngr, (int)nwg, L, d, det);
         if (det) launch_det_fold(det, dE + (size_t)(M - L) * 64, (size_t)L * 64, 1.f, 1, s);
     }
     if (parts & 16) {

@@ -87,6 +87,9 @@ def test_ring_matches_tiled_kernels_bitwise(tmp_path):
     (4096 + 32 * 5, [(768, 256, True), (256, 256, False), (512, 256, True), (256, 512, False)]),   # 12 steps per unit, ragged last split
     (4096, [(256, 256, True)]),                          # one tile, 128 splits of ONE 32-row step (the short-stream paths)
     (12288, [(256, 256, False), (256, 256, True)]),      # 2-3 steps per unit
+    # a MIXED group (cfg4's block at d = 768: the FFN weights are 384 x 768, not whole 256 x 256 tiles): the ring-shaped weights
+    # take the ring kernel, the others the 128 x 128 grouped kernel, from one call
+    (4096, [(2304, 768, True), (768, 768, False), (384, 768, True), (768, 384, False)]),
 ])
 def test_dw_ring_against_fp64_reference(M, shapes):
     """weight / bias gradients of a block's four projections through the ring TN kernel + fix-up pass (whole 256 x 256
