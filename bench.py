@@ -296,7 +296,7 @@ def pmc_traffic(kernel, B, L, d):
     FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
     Only reported when this run has a shape the counters were collected on (cfg2 at the per-GPU batch in the file name)."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(prof, f) for f in (f"r03_traffic_cfg2_b{B}.json", f"r02_traffic_cfg2_b{B}.json", f"r01_traffic_cfg2_b{B}.json")
+    path = next((os.path.join(prof, f) for f in (f"r04_traffic_cfg2_b{B}.json", f"r03_traffic_cfg2_b{B}.json", f"r02_traffic_cfg2_b{B}.json", f"r01_traffic_cfg2_b{B}.json")
                  if os.path.exists(os.path.join(prof, f))), None)
     if path is None or (L, d) != (2048, 512):
         return {"traffic": None}

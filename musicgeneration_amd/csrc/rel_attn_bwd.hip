@@ -44,9 +44,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;   // total is a multiple of 8 and blockDim of 64: whole 8-lane groups exit together
     const int sub = (int)(gid & 7);
-    const long rh = gid >> 3;                     // (row, head)
-    const int hd = (int)(rh % heads);
-    const long row = rh / heads;                  // b*L + i
+    // group g = ((b * heads + hd) * L + i): consecutive 8-lane groups are consecutive rows i of ONE head, so the per-row results
+    // are written (and lse is read) contiguously -- with the head on the fast axis (rounds 1-3) every 4-byte store went to its own
+    // cache line.  The 128-byte reads of ctx / dctx are whole lines either way.
+    const long grp = gid >> 3;
+    const int i = (int)(grp % L);
+    const int hd = (int)((grp / L) % heads);
+    const long row = (grp / ((long)L * heads)) * L + i;      // b*L + i
     const size_t off = (size_t)row * d + hd * 64 + sub * 8;
     float a[8], g[8];
     unpack8(*(const u32x4*)(ctx + off), a);
@@ -58,8 +62,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
     if (sub == 0) {
-        const int bb = (int)(row / L), i = (int)(row % L);
-        const size_t si = ((size_t)bb * heads + hd) * L + i;
+        const size_t si = (size_t)grp;
         delta[si] = s;
         // the dK/dV kernel's copies, in the form it consumes them (the initial accumulators of its S and dP products), so
         // that its LDS-DMA staging needs no arithmetic on the way
