@@ -816,13 +816,15 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     //      step when a key of this workgroup is padded, and an odd last step ------------------------------------------------
     auto general_step = [&](int t) {
         const int dq = t - wk;
-        if (dq < 0) stage(t + 1, (t & 1) ^ 1);            // (a wave that has a tile stages from inside it)
         if (dq >= 0) {
             tile(dq, t & 1, std::integral_constant<int, 0>{}, std::true_type{}, ds_tile(t), t + 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { const bf16x8 x = e[0][ks]; e[0][ks] = e[1][ks]; e[1][ks] = x; }
+            landed();                                     // counted, as in the main loop: the two dS stores may stay in flight
+        } else {
+            stage(t + 1, (t & 1) ^ 1);                    // (a wave that has a tile stages from inside it)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a wave that skipped its tile issued nothing after the DMA
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // not counted here: a wave that skipped its tile issued no stores after the DMA
         __syncthreads();
     };
     // (round 4: the four steps of the diagonal block specialised at compile time -- the wave's first tile through the masked body,
