@@ -569,24 +569,30 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 #endif                      //    the exponent's argument (16 fewer VALU per tile).  Measured at cfg2 / batch 64: 1.258 ms against 1.262 for 0 -- nothing;
                             //    and the rounding of K changes (the backward's P no longer equals the forward's bit for bit), so the default
                             //    stays 0: exponent = fma(8 S, log2(e)/8, -lse log2(e)) on unscaled operands
+#ifndef MGX_DKV_WAVES
+#define MGX_DKV_WAVES 4     // waves (= 32-key tiles) per workgroup of the dK/dV kernel: 4 (128 keys) or 2 (64 keys, A/B builds: a shorter diagonal
+#endif                      // block and twice the workgroups, but every wave stages twice as much: 1.315 against 1.246 ms at cfg2 / batch 64)
+#if 0
+#endif
 namespace k2 {
+constexpr int KW = MGX_DKV_WAVES;
 constexpr int OFF_QR = 0;                                  // 2 x 4K  qs image R
 constexpr int OFF_QT = OFF_QR + 2 * TILE_BYTES;            // 2 x 4K  qs image T
 constexpr int OFF_OR = OFF_QT + 2 * TILE_BYTES;            // 2 x 4K  dO image R
 constexpr int OFF_OT = OFF_OR + 2 * TILE_BYTES;            // 2 x 4K  dO image T
-constexpr int ST_BYTES = 1024;                             // per buffer: 4 waves x (-lse2[32], -delta[32]): every wave stages and reads its own copy
+constexpr int ST_BYTES = 256 * KW;                         // per buffer: KW waves x (-lse2[32], -delta[32]): every wave stages and reads its own copy
 constexpr int OFF_ST = OFF_OT + 2 * TILE_BYTES;            // 2 x 1 KB
 constexpr int PATCH_BYTES = 4608;                          // per wave: 32 rows x 144 B, the epilogue's row-major store patch
-constexpr int OFF_BAND = OFF_ST + 2 * ST_BYTES;
-constexpr int OFF_FLAG = OFF_BAND + WAVES * PATCH_BYTES;   // "a key of this workgroup is padded" flag
-constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 51,728 B (the 256 VGPRs limit the kernel to 2 workgroups per CU)
+constexpr int OFF_BAND = KW == 4 ? OFF_ST + 2 * ST_BYTES : 0;      // (64-key workgroups: the patches reuse the image buffers after the sweep)
+constexpr int OFF_FLAG = KW == 4 ? OFF_BAND + KW * PATCH_BYTES : OFF_ST + 2 * ST_BYTES;   // "a key of this workgroup is padded" flag
+constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 51,728 B (the 256 VGPRs limit the kernel to 2 waves per SIMD)
 // The Er chunks (B operand of Q.Er^T: column t = lane&31, 16 contiguous bytes of row L-1-32q-t) are
 // loaded straight from global/L2 into registers, one new chunk per step (the previous "hi" chunk is
 // the next "lo" chunk), so E needs no LDS here.
 }  // namespace k2
 
 template <bool EXPORT_DS>     // always true (one instantiation): as a plain function hipcc builds a 36 % longer main loop from the same source
-__global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
+__global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
     const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfS /* Er fragments x log2(e)/8 */, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ nlse2 /* -lse log2(e) */, const float* __restrict__ ndelta /* -delta */,
     uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dst, int L, int d, int bgroup) {
@@ -596,9 +602,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bl = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
-    const int nkb = (L + 127) >> 7;                        // y = (batch group, key block): groups as in the dQ kernel
+    const int nkb = (L + 32 * KW - 1) / (32 * KW);         // y = (batch group, key block): groups as in the dQ kernel
     const int b = (blockIdx.y / nkb) * bgroup + blockIdx.x / heads, hd = blockIdx.x % heads;
-    const int J0 = (blockIdx.y % nkb) * 128;               // small J0 = longest sweep = dispatched first
+    const int J0 = (blockIdx.y % nkb) * 32 * KW;           // small J0 = longest sweep = dispatched first
     const int nchunk = L >> 5;
     const int nT = (L - J0) >> 5;                          // query tiles i0 = J0 + 32 t
     const bool wave_on = J0 + w * 32 < L;
@@ -614,12 +620,18 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     // swizzle puts there (rel_attn_common.hpp: dma16), so a tile costs a wave five DMA instructions and neither registers nor
     // ds_write (round 3: 2 loads into registers, then 5 stores).  Every global address of the sweep is (wave-uniform base in
     // SGPRs) + (32-bit per-lane offset).
-    const int srow = tid >> 3, spc = tid & 7;
-    const int lcR = spc ^ ((srow >> 1) & 7), lcT = spc ^ (((srow >> 1) & 1) << 2);      // logical chunks: imgR_off / imgT_off inverted
+    // (a workgroup of KW waves covers the 256 slots of an image in NS = 4 / KW rounds: slot = tid + 64 KW i)
+    constexpr int NS = 4 / KW;
     const char* q_base = (const char*)(qkv_b + (size_t)J0 * ld + hd * 64);                      // + t * 32 rows
     const char* o_base = (const char*)(dctx + ((size_t)b * L + J0) * d + hd * 64);
-    const uint32_t q_voffR = (uint32_t)((srow * ld + lcR * 8) * 2), q_voffT = (uint32_t)((srow * ld + lcT * 8) * 2);
-    const uint32_t o_voffR = (uint32_t)((srow * d + lcR * 8) * 2), o_voffT = (uint32_t)((srow * d + lcT * 8) * 2);
+    uint32_t q_voffR[NS], q_voffT[NS], o_voffR[NS], o_voffT[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int slot = tid + 64 * KW * i, srow = slot >> 3, spc = slot & 7;
+        const int lcR = spc ^ ((srow >> 1) & 7), lcT = spc ^ (((srow >> 1) & 1) << 2);   // logical chunks: imgR_off / imgT_off inverted
+        q_voffR[i] = (uint32_t)((srow * ld + lcR * 8) * 2); q_voffT[i] = (uint32_t)((srow * ld + lcT * 8) * 2);
+        o_voffR[i] = (uint32_t)((srow * d + lcR * 8) * 2);  o_voffT[i] = (uint32_t)((srow * d + lcT * 8) * 2);
+    }
     const uint32_t q_step = (uint32_t)(32 * ld * 2), o_step = (uint32_t)(32 * d * 2);
     // fragment ks of Er chunk q for this lane (fragment-ordered copy: 1 KB contiguous per wave load).  Every load of the
     // sweep is unconditional with a clamped index; data of clamped tiles / chunks is never used.
@@ -638,10 +650,14 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
         const int tn = (MGX_DKV_PEEL & 16) ? 0 : min(t, nT - 1);
         const char* qb = q_base + (size_t)tn * q_step;
         const char* ob = o_base + (size_t)tn * o_step;
-        dma16(qb, q_voffR, lds_w + OFF_QR + buf * TILE_BYTES);
-        dma16(qb, q_voffT, lds_w + OFF_QT + buf * TILE_BYTES);
-        dma16(ob, o_voffR, lds_w + OFF_OR + buf * TILE_BYTES);
-        dma16(ob, o_voffT, lds_w + OFF_OT + buf * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const uint32_t dw = lds_w + KW * 1024 * i + buf * TILE_BYTES;       // slots 64 (w + KW i) .. + 63
+            dma16(qb, q_voffR[i], dw + OFF_QR);
+            dma16(qb, q_voffT[i], dw + OFF_QT);
+            dma16(ob, o_voffR[i], dw + OFF_OR);
+            dma16(ob, o_voffT[i], dw + OFF_OT);
+        }
         dma4(st_base + (size_t)tn * 128, st_voff, lds_addr_of(smem) + OFF_ST + buf * ST_BYTES + w * 256);
     };
     stage(0, 0);
@@ -833,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
     //  loop and a 15 K-instruction kernel.  The general body costs 4.2-5.0 K cycles per step against 3.1 K in the main loop,
     //  15 % of a workgroup's time: tools/dkv_stamp.py.)
     int t = 0;
-    const int nhead = wgpad ? nT : min(4, nT);
+    const int nhead = wgpad ? nT : min(KW, nT);           // (KW is even: the main loop starts on an even step)
 #ifdef MGX_DKV_STAMP
     const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();      // end of the prologue
 #endif
@@ -862,6 +878,7 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dkv_kernel(
 #endif
     for (; t < nT; ++t) general_step(t);
 
+    if (KW != 4) __syncthreads();                         // the patches reuse the image buffers: every wave is done reading them
     if (wave_on) {
         uint16_t* row0 = dqkv + ((size_t)b * L + j0) * ld + hd * 64;
         store_rows_lds(row0 + d, ld, dk0, dk1, lane, 0.125f, band);      // dk = dS^T (q/8)
@@ -1321,7 +1338,9 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
 #else
         constexpr int dkv_lds = k2::LDS_BYTES;
 #endif
-        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gq, dim3(256), dkv_lds, s, qkv, EfS, padbits, dctx, nlse2, ndelta, dqkv, dst, L, d, bg);
+        const dim3 gk(bg * heads, ((L + 32 * k2::KW - 1) / (32 * k2::KW)) * (B / bg));
+        MGX_REQUIRE(gk.y <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: too many key blocks for the grid");
+        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gk, dim3(64 * k2::KW), dkv_lds, s, qkv, EfS, padbits, dctx, nlse2, ndelta, dqkv, dst, L, d, bg);
     }
 #if MGX_EXPERIMENTS
     if (parts & 64) {                                   // experiment builds: dK/dV with 64 keys per wave (tools/experiments/rel_attn_bwd64.hip)
