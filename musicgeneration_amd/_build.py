@@ -30,7 +30,9 @@ EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip", "rel_attn_bwd64.
 # gives every MFMA an AGPR destination and copies each result out), and the SLP vectoriser must not pair the two blocks'
 # row sums into v_pk_add_f32 (slower than two v_add_f32 beside MFMAs).
 _W64 = ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]
-EXTRA_FLAGS = {"rel_attn_fwd2.hip": _W64}
+EXTRA_FLAGS = {"rel_attn_fwd2.hip": _W64,
+               # the 64-key dK/dV kernel: accumulators in AGPRs through inline-asm MFMAs, every other MFMA the builtin in VGPR form
+               "rel_attn_bwd64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DMGX_K64_ASMACC=1"]}
 
 
 def _hipcc() -> str:

@@ -9,16 +9,19 @@
 // the K / V fragments + three E chunks -- one wave per SIMD with the whole 512-entry register file.
 //
 // RESULT (round 4, MI355X, cfg2 at batch 64; profiles/r04_dkv64.txt): bit-identical dk, dv and dS tiles, and SLOWER than the
-// 32-key kernel -- 1.46-1.47 ms against 1.15-1.25 (1.65 with the phase order below pinned by sched_barrier).  Why, from the ISA
-// of the six-step main loop (tools/isa_loop_stats.py): with more than 256 registers hipcc builds every MFMA in its AGPR form
-// (-amdgpu-mfma-vgpr-form=1 does not compile this kernel at all), so each of the seven 16-register score tiles of a step that
-// VALU code touches -- three chunk products, two S, two dP -- is copied out of, and the two S tiles into, the accumulator file:
-// 144 v_accvgpr moves per step.  With them a step has 502 instructions for two tiles, MORE than two steps of the 32-key kernel
-// (447), and a wave that is alone on its SIMD issues them one per ~7 cycles (dependent latencies nobody else fills).  The saving
-// the design is after -- 44 instead of 48 MFMAs, 64 instead of 96 LDS reads -- is real but smaller than that overhead.  What
-// it would take: MFMA forms chosen per instruction (accumulators in AGPRs, score tiles in VGPRs), the skew permuting straight
-// between accumulator registers (ds_bpermute with AGPR data under per-register EXEC masks), and a hand-scheduled loop -- i.e. a
-// main loop written in assembly.  Kept here, with its parity check (check_dkv64.py), as the starting point for that.
+// 32-key kernel -- 1.44-1.47 ms against 1.11-1.26, in both of its builds:
+//  (a) plain: with more than 256 registers hipcc builds every MFMA in its AGPR form, so each of the seven 16-register score tiles
+//      of a step that VALU code touches (three chunk products, two S, two dP) is copied between the register files: 144
+//      v_accvgpr moves, 502 instructions per step of two tiles (two steps of the 32-key kernel: 447);
+//  (b) MGX_K64_ASMACC (how _build.py --experiments builds it): -amdgpu-mfma-vgpr-form=1 for this file, with the 128 accumulators
+//      kept in AGPRs by inline-asm MFMAs ("+a" operands, s_nop 1 in front for their just-packed operands) -- without that the flag
+//      does not compile this kernel.  No accumulator copy is left in the main loop, 381 instructions per step ... and the SAME time.
+// So the instruction count was not it: a wave that is alone on its SIMD has nobody to fill the latencies of its own dependent
+// chain (LDS fragment read -> MFMA chain -> 12 wait states -> VALU -> pack -> MFMA ...), and hipcc does not software-pipeline the
+// two sub-tiles against each other (pinning the sub-tile order with sched_barrier makes it worse, 1.65 ms).  The 44 MFMAs of a step
+// need 1,408 cycles; the step takes about 3,700.  What it would take is the schedule written by hand -- the MFMAs of one sub-tile
+// issued every ~8 instructions between the VALU / LDS work of the other and of the next step's chunk products -- i.e. a main loop in
+// assembly.  Kept here, with its parity check (check_dkv64.py), as the starting point for that.
 //
 // Work decomposition: workgroup = 2 waves = 128 keys of one (batch, head) (the same 128-key blocks, grid and dispatch order
 // as the 32-key kernel, so two workgroups share a CU = one wave per SIMD); wave w owns key tiles 2w, 2w+1 of the block.
@@ -37,6 +40,18 @@ using namespace relattn;
 #else
 #define K64_SB()
 #endif
+#ifndef MGX_K64_ASMACC
+#define MGX_K64_ASMACC 0    // 1 (with -mllvm -amdgpu-mfma-vgpr-form=1 for this file): the dK / dV accumulators live in AGPRs through
+#endif                      //    inline-asm MFMAs, every other MFMA is the builtin in its VGPR form (no v_accvgpr copies of score tiles)
+// acc (AGPRs) += a * b.  The operands may have just been written by VALU code (the bf16 packs): s_nop 1 = the two wait states an MFMA
+// operand needs after a VALU write (cdna_hip_programming.md 5.7 item 2).  The accumulators are only read in the epilogue.
+MGX_DEV void mfma_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+#if MGX_K64_ASMACC
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#else
+    acc = mfma(a, b, acc);
+#endif
+}
 namespace k64 {   // (LDS layout)
 constexpr int WAVES = 2;
 constexpr int OFF_QR = 0;                                  // 2 x 4K  q image R
@@ -251,8 +266,8 @@ __global__ __launch_bounds__(128, 1) void rel_attn_dkv64_kernel(
         for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                dv[0][ct] = mfma(frag_T(ot, lane, ss, ct), pf0[ss], dv[0][ct]);
-                dk[0][ct] = mfma(frag_T(qt, lane, ss, ct), df0[ss], dk[0][ct]);
+                mfma_acc(dv[0][ct], frag_T(ot, lane, ss, ct), pf0[ss]);
+                mfma_acc(dk[0][ct], frag_T(qt, lane, ss, ct), df0[ss]);
             }
         soft(c1, dp1, pf1, df1);
         K64_SB();
@@ -260,8 +275,8 @@ __global__ __launch_bounds__(128, 1) void rel_attn_dkv64_kernel(
         for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                dv[1][ct] = mfma(frag_T(ot, lane, ss, ct), pf1[ss], dv[1][ct]);
-                dk[1][ct] = mfma(frag_T(qt, lane, ss, ct), df1[ss], dk[1][ct]);
+                mfma_acc(dv[1][ct], frag_T(ot, lane, ss, ct), pf1[ss]);
+                mfma_acc(dk[1][ct], frag_T(qt, lane, ss, ct), df1[ss]);
             }
         u32x4 dfx[2][2];
         dfx[0][0] = __builtin_bit_cast(u32x4, df0[0]); dfx[0][1] = __builtin_bit_cast(u32x4, df0[1]);
