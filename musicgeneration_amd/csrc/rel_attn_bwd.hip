@@ -603,8 +603,20 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
     const int bl = lane & 31, hh = lane >> 5;
     const int heads = d >> 6;
     const int nkb = (L + 32 * KW - 1) / (32 * KW);         // y = (batch group, key block): groups as in the dQ kernel
-    const int b = (blockIdx.y / nkb) * bgroup + blockIdx.x / heads, hd = blockIdx.x % heads;
-    const int J0 = (blockIdx.y % nkb) * 32 * KW;           // small J0 = longest sweep = dispatched first
+#ifndef MGX_DKV_XCD
+#define MGX_DKV_XCD 0       // 1 (A/B builds): the (b,h) of a batch group dealt to the XCDs, see below
+#endif
+    int bh_l = blockIdx.x, kbr = blockIdx.y % nkb;         // (b,h) inside the batch group, key-block rank (0 = longest sweep, dispatched first)
+    if (MGX_DKV_XCD && (gridDim.x & 7) == 0) {
+        // workgroups r and r + 8 share an XCD (MI355X_MICROARCH.md): XCD x = r & 7 works through the (b,h) with bh % 8 == x only, key
+        // blocks in the same heaviest-first order, so the 16 key-block workgroups of a (b,h) -- which all read its q / dO rows --
+        // share one L2 (8 (b,h) x 2 MB of q + dO per XCD at cfg2)
+        const int r = kbr * gridDim.x + bh_l, per = gridDim.x >> 3, m = r >> 3;
+        kbr = m / per;
+        bh_l = (m % per) * 8 + (r & 7);
+    }
+    const int b = (blockIdx.y / nkb) * bgroup + bh_l / heads, hd = bh_l % heads;
+    const int J0 = kbr * 32 * KW;
     const int nchunk = L >> 5;
     const int nT = (L - J0) >> 5;                          // query tiles i0 = J0 + 32 t
     const bool wave_on = J0 + w * 32 < L;
@@ -1101,7 +1113,10 @@ __global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
 #define MGX_DET_PEEL 0      // timing experiments only (tools/peel_de_tiles.sh): 1 three quarters of the scatter stores | 2 no products |
 #endif                      // 4 q tile re-read from row block 0 (L2-resident); results are then wrong
 namespace k3t {
-constexpr int DIAGS = 4, RS = 64, STEPS = 32, NW = 5;
+#ifndef MGX_DET_STEPS
+#define MGX_DET_STEPS 32
+#endif
+constexpr int DIAGS = 4, RS = 64, STEPS = MGX_DET_STEPS, NW = 5;
 constexpr int AROW = 352;                                  // bytes per image row: 160 bf16 + pad (4 consecutive rows -> 4 bank groups)
 constexpr int OFF_A = 0;                                   // [64 i][160 distance columns]
 constexpr int OFF_Q = RS * AROW;                           // q tile [64 i][64 c]: 2 sub-tiles image T

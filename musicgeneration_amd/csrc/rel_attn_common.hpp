@@ -152,11 +152,13 @@ MGX_DEV void band_store(char* band, const int (&wa0)[16], const int (&wa1)[16], 
 //  * the compiler therefore does NOT know that these instructions write LDS or occupy vmcnt: the caller separates them from the
 //    LDS reads of the same bytes by an explicit counted s_waitcnt vmcnt(N) + barrier (N = VMEM operations issued after them).
 //    A compiler-generated vmcnt(N') for an older ordinary load only ever waits longer than needed, never shorter.
+//  * hazards inside the string are the author's: the s_nop 0 is the wait state an LDS-DMA needs after the SALU write of M0 (hipcc pads
+//    nothing inside an asm statement; M0 is written in the same statement that uses it because the compiler does not preserve it).
 MGX_DEV void dma16(const char* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave_base) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave_base) : "memory", "m0");
 }
 MGX_DEV void dma4(const char* sbase /* wave-uniform */, uint32_t voff, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave_base) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave_base) : "memory", "m0");
 }
 
 // order LDS traffic of one wave (same-wave DS ops execute in order; this only pins the compiler)
