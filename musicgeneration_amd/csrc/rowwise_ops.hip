@@ -472,6 +472,10 @@ extern "C" int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uin
 // K9+K10  label-smoothed CE + accuracy + argmax, one wave per row     criterion.py:51-67
 //   loss_r = lse - (1-eps) x_t - (eps/V) sum_v x_v      (closed form of -sum q' log softmax)
 // =================================================================================================
+// NC > 0: rows of ld % 8 == 0 elements, 16-byte aligned, V <= 512 NC (the model's logits: vocabulary rows padded to the GEMM tile):
+//   lane l holds columns 512 c + 8 l .. + 7 of chunk c in registers -- one 16-byte load per chunk instead of eight 2-byte ones, and
+//   the row is read ONCE (the scalar path, NC = 0, reads it for the maximum and again for the exponentials).
+template <int NC>
 __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
     const uint16_t* __restrict__ logits, const int32_t* __restrict__ target, float* __restrict__ stats,
     int32_t* __restrict__ argmax_o, float* __restrict__ row_lse, int rows, int V, int ld, float eps_ls, int pad,
@@ -484,10 +488,28 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
         const uint16_t* lp = logits + (size_t)r * ld;
         float mx = -INFINITY, sx = 0.f;
         int am = 0x7fffffff;
-        for (int v = lane; v < V; v += 64) {
-            const float xv = bf16_to_f32(lp[v]);
-            sx += xv;
-            if (xv > mx) { mx = xv; am = v; }
+        float xr[NC > 0 ? NC : 1][8];
+        if (NC > 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int col = 512 * c + 8 * lane;
+                if (col < V) unpack8(*(const u32x4*)(lp + col), xr[c]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (col + k < V) {                         // ascending columns: the first maximum of a lane is its lowest index
+                        sx += xr[c][k];
+                        if (xr[c][k] > mx) { mx = xr[c][k]; am = col + k; }
+                    } else {
+                        xr[c][k] = -INFINITY;                  // exp(-inf - mx) = 0 below
+                    }
+                }
+            }
+        } else {
+            for (int v = lane; v < V; v += 64) {
+                const float xv = bf16_to_f32(lp[v]);
+                sx += xv;
+                if (xv > mx) { mx = xv; am = v; }
+            }
         }
         // wave arg-max: max value, lowest index among ties (torch.argmax picks the first)
 #pragma unroll
@@ -497,7 +519,14 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
             if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
         }
         float se = 0.f;
-        for (int v = lane; v < V; v += 64) se += __expf(bf16_to_f32(lp[v]) - mx);
+        if (NC > 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) se += __expf(xr[c][k] - mx);
+        } else {
+            for (int v = lane; v < V; v += 64) se += __expf(bf16_to_f32(lp[v]) - mx);
+        }
         se = wave_sum(se);
         sx = wave_sum(sx);
         const float lse = mx + __logf(se);
@@ -524,6 +553,7 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
     }
 }
 
+template <bool VEC>     // VEC: ld % 8 == 0, 16-byte aligned rows: 16-byte loads and stores (8 columns per lane and pass)
 __global__ __launch_bounds__(256) void smooth_ce_bwd_kernel(
     const uint16_t* __restrict__ logits, const int32_t* __restrict__ target, const float* __restrict__ stats,
     const float* __restrict__ row_lse, uint16_t* __restrict__ dlogits, int rows, int V, int ld, float eps_ls,
@@ -540,6 +570,19 @@ __global__ __launch_bounds__(256) void smooth_ce_bwd_kernel(
         const int t = target[r];
         const float lse = row_lse[r];
         const bool keep = (t != pad);
+        if (VEC) {
+            for (int col = 8 * lane; col < ld; col += 512) {
+                float x[8], gv[8];
+                if (keep && col < V) unpack8(*(const u32x4*)(lp + col), x);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int v = col + k;
+                    gv[k] = (keep && v < V) ? sc * (__expf(x[k] - lse) - u - ((v == t) ? (1.f - eps_ls) : 0.f)) : 0.f;
+                }
+                *(u32x4*)(dp + col) = pack8(gv);
+            }
+            continue;
+        }
         for (int v = lane; v < ld; v += 64) {
             float gval = 0.f;
             if (keep && v < V) {
@@ -561,8 +604,18 @@ extern "C" int mgx_smooth_ce_fwd(const uint16_t* logits, const int32_t* target, 
     int rc;
     long long* det = mgx_det_scratch(4, stream, &rc);
     if (rc != MGX_OK) return rc;
-    hipLaunchKernelGGL(smooth_ce_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
-                       argmax, row_lse, rows, V, ld, eps_ls, pad, det);
+    const bool vec = ld % 8 == 0 && ((uintptr_t)logits & 15) == 0 && V <= 2048;
+    const int nc = vec ? (V + 511) / 512 : 0;
+#define MGX_CE_FWD(NC) hipLaunchKernelGGL(smooth_ce_fwd_kernel<NC>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats, \
+                                          argmax, row_lse, rows, V, ld, eps_ls, pad, det)
+    switch (nc) {
+        case 1: MGX_CE_FWD(1); break;
+        case 2: MGX_CE_FWD(2); break;
+        case 3: MGX_CE_FWD(3); break;
+        case 4: MGX_CE_FWD(4); break;
+        default: MGX_CE_FWD(0); break;
+    }
+#undef MGX_CE_FWD
     if (det) launch_det_fold(det, stats, 4, 1.f, 1, (hipStream_t)stream);
     MGX_CHECK_LAUNCH("mgx_smooth_ce_fwd");
     return MGX_OK;
@@ -575,8 +628,12 @@ extern "C" int mgx_smooth_ce_bwd(const uint16_t* logits, const int32_t* target, 
                 rows, V, ld);
     int grid = (rows + 3) / 4;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(smooth_ce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
-                       row_lse, dlogits, rows, V, ld, eps_ls, pad, gscale, gscale_dev);
+    if (ld % 8 == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0)
+        hipLaunchKernelGGL(smooth_ce_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
+                           row_lse, dlogits, rows, V, ld, eps_ls, pad, gscale, gscale_dev);
+    else
+        hipLaunchKernelGGL(smooth_ce_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats,
+                           row_lse, dlogits, rows, V, ld, eps_ls, pad, gscale, gscale_dev);
     MGX_CHECK_LAUNCH("mgx_smooth_ce_bwd");
     return MGX_OK;
 }

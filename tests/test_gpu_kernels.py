@@ -251,6 +251,36 @@ def test_smooth_ce_golden_and_random(golden_dir):
         assert _relerr(lg_dev.grad.cpu(), 0.25 * ref_in.grad) < 1e-2
 
 
+@pytest.mark.parametrize("V,ld", [(337, 384), (486, 512), (1100, 1104), (20, 64)])
+def test_smooth_ce_padded_rows_take_the_vector_path_and_agree_with_the_scalar_one(V, ld):
+    """the model hands the loss its logits as a [rows, V] view of a [rows, ld] buffer (vocabulary rows padded to the GEMM tile):
+    rows of ld % 8 == 0 elements go through the 16-byte-per-lane kernels, a contiguous [rows, V] copy (ld = V, odd) through the
+    scalar ones -- same statistics, same arg-max, same gradient, and zeros in the padding columns of dlogits."""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(V)
+    rows, eps, pad = 77, 0.1, V - 1
+    base = torch.zeros(rows, ld, dtype=torch.bfloat16)
+    base[:, :V] = (torch.randn(rows, V, generator=g) * 3).to(torch.bfloat16)
+    base[3, 5:9] = base[3, :V].max() + 1                      # a tie for the maximum: arg-max must be the FIRST index
+    tgt = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    tgt[-5:] = pad
+    based, tg = base.to(dev), tgt.to(dev)
+    flat = based[:, :V].contiguous() if V % 8 else None
+    s1, a1, l1 = ops.smooth_ce_fwd(based, tg, V, eps, pad)
+    d1 = ops.smooth_ce_bwd(based, tg, s1, l1, V, eps, pad, 1.0)
+    ref = base[:, :V].float()
+    assert (a1.cpu().long() == ref.argmax(-1)).all() and a1[3].item() == 5
+    assert torch.allclose(l1.cpu(), torch.logsumexp(ref, -1), rtol=1e-5, atol=1e-5)
+    assert (d1[:, V:] == 0).all()
+    if flat is not None:
+        s2, a2, l2 = ops.smooth_ce_fwd(flat, tg, V, eps, pad)
+        d2 = ops.smooth_ce_bwd(flat, tg, s2, l2, V, eps, pad, 1.0)
+        assert torch.equal(a1, a2) and torch.allclose(l1, l2, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(s1, s2, rtol=1e-5)
+        assert torch.equal(d1[:, :V], d2)
+
+
 def test_adam_matches_torch():
     from musicgeneration_amd import ops
     dev = _dev()
