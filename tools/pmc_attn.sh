@@ -13,7 +13,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; do
   n=$(echo $set | cut -c1-14 | tr " " "_")
   rm -rf /tmp/${TAG}_$n
-  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/${TAG}_$n -- python3 $ROOT/tools/attn_bench.py --B $B --reps 1 --parts $PARTS > $ROOT/gpurun_out/pmc_attn_pass_$n.log 2>&1) \
+  (cd /tmp && timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/${TAG}_$n -- python3 $ROOT/tools/attn_bench.py --B $B --reps 1 --parts $PARTS $ATTN_ARGS > $ROOT/gpurun_out/pmc_attn_pass_$n.log 2>&1) \
     || { echo "pmc pass $n failed (rc $?):"; tail -5 gpurun_out/pmc_attn_pass_$n.log; exit 1; }
 done
 python3 - "$OUT" "$B" "$TAG" "$PARTS" <<'PY'
