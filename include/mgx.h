@@ -46,8 +46,8 @@ int mgx_device_count(void);
  * mgx_set_deterministic(scratch, bytes) those kernels add 64-bit FIXED-POINT integers (value * 2^30, each partial sum rounded
  * once) into `scratch` and a fold pass converts the totals: integer addition is associative, so two runs on the same inputs
  * -- and a data-parallel run against a single-process run of the same global batch, up to the all-reduce's own order -- give
- * the same bits.  Partial sums are quantised to 2^-30 ~ 9.3e-10 and must stay below 8.6e9 in magnitude; speed is within a
- * few percent of the default.  Everything else in the library is deterministic as it is.
+ * the same bits.  Partial sums are quantised to 2^-30 ~ 9.3e-10 and must stay below 8.6e9 in magnitude; the cfg2 training
+ * step takes 1.1 % longer.  Everything else in the library is deterministic as it is.
  *   scratch: device memory, 8-byte aligned, owned by the caller and alive until the mode is switched off with
  *            mgx_set_deterministic(NULL, 0); the largest user needs 8 * max(N*K + N, V*d, 64*L) bytes (16 MiB covers cfg4).
  *   The setting is process-wide (the one piece of mutable state in the library); calls that use the scratch must be issued on
