@@ -61,23 +61,46 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
         for (int base = r_lo; base < r_hi; base += EB_CHUNK) {
             if (tid == 0) nhit = 0;
             __syncthreads();
-            for (int r = base + tid; r < min(r_hi, base + EB_CHUNK); r += 256)
-                if (tok[r] == v) hits[atomicAdd(&nhit, 1)] = r;
+            {   // the thread's 16 tokens of the chunk are requested together (as a loop of load-compare-branch they were 16 dependent
+                // L2 round trips per chunk: most of this kernel's time)
+                int tk[EB_CHUNK / 256];
+#pragma unroll
+                for (int i = 0; i < EB_CHUNK / 256; ++i) {
+                    const int r = base + tid + 256 * i;
+                    tk[i] = r < r_hi ? tok[r] : -1;
+                }
+#pragma unroll
+                for (int i = 0; i < EB_CHUNK / 256; ++i)
+                    if (tk[i] == v) hits[atomicAdd(&nhit, 1)] = base + tid + 256 * i;
+            }
             __syncthreads();
             const int n = nhit;
             if (gi < gpr) {
-                for (int k = w; k < n; k += 4) {
-                    const int rr = hits[k];
-                    float f[8];
-                    unpack8(*(const u32x4*)(dout + (size_t)rr * d + gi * 8), f);
-                    if (dc.thr16) {
-                        float m[8];
-                        drop_mult8(dc, (uint32_t)((size_t)rr * gpr + gi), m);
+                // four hit rows in flight per wave (every row is a dependent 1 KB gather from HBM: one at a time, a block's
+                // ~24 rows were six serial round trips per wave)
+                for (int k0 = w; k0 < n; k0 += 16) {
+                    u32x4 raw[4];
+                    int rrs[4];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) f[q] *= m[q];
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + 4 * j;
+                        rrs[j] = hits[min(k, n - 1)];
+                        raw[j] = *(const u32x4*)(dout + (size_t)rrs[j] * d + gi * 8);
                     }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] += DET ? (acc_t)__float2ll_rn(f[q] * MGX_DET_SCALE) : (acc_t)f[q];
+                    for (int j = 0; j < 4; ++j) {
+                        if (k0 + 4 * j >= n) break;
+                        float f[8];
+                        unpack8(raw[j], f);
+                        if (dc.thr16) {
+                            float m[8];
+                            drop_mult8(dc, (uint32_t)((size_t)rrs[j] * gpr + gi), m);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) f[q] *= m[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[q] += DET ? (acc_t)__float2ll_rn(f[q] * MGX_DET_SCALE) : (acc_t)f[q];
+                    }
                 }
             }
             __syncthreads();
