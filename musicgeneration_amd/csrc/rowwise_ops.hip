@@ -498,8 +498,13 @@ extern "C" int mgx_add_ln_bwd(const uint16_t* dout, const uint16_t* x, const uin
 // NC > 0: rows of ld % 8 == 0 elements, 16-byte aligned, V <= 512 NC (the model's logits: vocabulary rows padded to the GEMM tile):
 //   lane l holds columns 512 c + 8 l .. + 7 of chunk c in registers -- one 16-byte load per chunk instead of eight 2-byte ones, and
 //   the row is read ONCE (the scalar path, NC = 0, reads it for the maximum and again for the exponentials).
+#ifndef MGX_CE_GRID
+#define MGX_CE_GRID 512
+#endif
+// Blocks of 16 waves: every block ends with four atomics on the SAME 16 bytes of `stats`, which the L2 serialises at ~12 ns each --
+// with 2,048 blocks of 4 waves those 8,192 atomics, not the 100 MB of logits, were the kernel's time (62 us at cfg2 / batch 64).
 template <int NC>
-__global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
+__global__ __launch_bounds__(1024) void smooth_ce_fwd_kernel(
     const uint16_t* __restrict__ logits, const int32_t* __restrict__ target, float* __restrict__ stats,
     int32_t* __restrict__ argmax_o, float* __restrict__ row_lse, int rows, int V, int ld, float eps_ls, int pad,
     long long* __restrict__ det /* deterministic mode: the four sums as fixed-point integers, folded into stats afterwards */) {
@@ -509,7 +514,8 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
     float loss_acc = 0.f, cnt_acc = 0.f, hit_acc = 0.f, row_acc = 0.f;
     for (int r = wave; r < rows; r += nwave) {
         const uint16_t* lp = logits + (size_t)r * ld;
-        float mx = -INFINITY, sx = 0.f;
+        const int t = target[r];                               // requested with the row, not after its reductions
+        float mx = -INFINITY, sx = 0.f, xt_part = 0.f;
         int am = 0x7fffffff;
         float xr[NC > 0 ? NC : 1][8];
         if (NC > 0) {
@@ -522,6 +528,8 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
                     if (col + k < V) {                         // ascending columns: the first maximum of a lane is its lowest index
                         sx += xr[c][k];
                         if (xr[c][k] > mx) { mx = xr[c][k]; am = col + k; }
+                        if (col + k == t) xt_part = xr[c][k];  // the target's logit sits in some lane's registers: no second, dependent
+                                                               // global load of lp[t] per row (it was a third of this kernel's time)
                     } else {
                         xr[c][k] = -INFINITY;                  // exp(-inf - mx) = 0 below
                     }
@@ -553,9 +561,9 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
         se = wave_sum(se);
         sx = wave_sum(sx);
         const float lse = mx + __logf(se);
-        const int t = target[r];
+        const float xt_vec = NC > 0 ? wave_sum(xt_part) : 0.f;
         if (lane == 0) {
-            const float xt = (t >= 0 && t < V) ? bf16_to_f32(lp[t]) : 0.f;
+            const float xt = NC > 0 ? xt_vec : ((t >= 0 && t < V) ? bf16_to_f32(lp[t]) : 0.f);
             row_lse[r] = lse;
             argmax_o[r] = am;
             if (t != pad) {
@@ -566,11 +574,12 @@ __global__ __launch_bounds__(256) void smooth_ce_fwd_kernel(
             row_acc += 1.f;
         }
     }
-    __shared__ float red[4][4];
+    __shared__ float red[16][4];
     if (lane == 0) { red[wid][0] = loss_acc; red[wid][1] = cnt_acc; red[wid][2] = hit_acc; red[wid][3] = row_acc; }
     __syncthreads();
     if (threadIdx.x < 4) {
-        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float v = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) v += red[i][threadIdx.x];
         if (det) det_add(det + threadIdx.x, v);
         else atomicAdd(stats + threadIdx.x, v);
     }
@@ -622,14 +631,14 @@ extern "C" int mgx_smooth_ce_fwd(const uint16_t* logits, const int32_t* target, 
     MGX_REQUIRE(logits && target && stats && argmax && row_lse, MGX_ERR_NULL, "mgx_smooth_ce_fwd: NULL pointer");
     MGX_REQUIRE(rows > 0 && V > 0 && ld >= V, MGX_ERR_SHAPE, "mgx_smooth_ce_fwd: need ld>=V (rows=%d V=%d ld=%d)",
                 rows, V, ld);
-    int grid = (rows + 3) / 4;
-    if (grid > 2048) grid = 2048;
+    int grid = (rows + 15) / 16;                             // 16 waves = 16 rows in flight per block
+    if (grid > MGX_CE_GRID) grid = MGX_CE_GRID;
     int rc;
     long long* det = mgx_det_scratch(4, stream, &rc);
     if (rc != MGX_OK) return rc;
     const bool vec = ld % 8 == 0 && ((uintptr_t)logits & 15) == 0 && V <= 2048;
     const int nc = vec ? (V + 511) / 512 : 0;
-#define MGX_CE_FWD(NC) hipLaunchKernelGGL(smooth_ce_fwd_kernel<NC>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, target, stats, \
+#define MGX_CE_FWD(NC) hipLaunchKernelGGL(smooth_ce_fwd_kernel<NC>, dim3(grid), dim3(1024), 0, (hipStream_t)stream, logits, target, stats, \
                                           argmax, row_lse, rows, V, ld, eps_ls, pad, det)
     switch (nc) {
         case 1: MGX_CE_FWD(1); break;
