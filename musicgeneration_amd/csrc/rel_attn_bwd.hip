@@ -564,11 +564,9 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 #else
 #define DKV_STAMP(i)
 #endif
-#ifndef MGX_DKV_FOLD
-#define MGX_DKV_FOLD 0      // 1: log2(e)/8 rides in K and in the Er copy, -lse log2(e) is the initial accumulator of the Q.Er^T products: S arrives as
-#endif                      //    the exponent's argument (16 fewer VALU per tile).  Measured at cfg2 / batch 64: 1.258 ms against 1.262 for 0 -- nothing;
-                            //    and the rounding of K changes (the backward's P no longer equals the forward's bit for bit), so the default
-                            //    stays 0: exponent = fma(8 S, log2(e)/8, -lse log2(e)) on unscaled operands
+// (round 4 experiment, removed: log2(e)/8 folded into K and into a scaled copy of the Er fragments, -lse log2(e) as the initial
+//  accumulator of the Q.Er^T products, so that S arrives as the exponent's argument -- 16 fewer VALU per tile: 1.258 ms against
+//  1.262 at cfg2 / batch 64, nothing; and the backward's P would no longer equal the forward's bit for bit.)
 #ifndef MGX_DKV_WAVES
 #define MGX_DKV_WAVES 4     // waves (= 32-key tiles) per workgroup of the dK/dV kernel: 4 (128 keys) or 2 (64 keys, A/B builds: a shorter diagonal
 #endif                      // block and twice the workgroups, but every wave stages twice as much: 1.315 against 1.246 ms at cfg2 / batch 64)
@@ -593,7 +591,7 @@ constexpr int LDS_BYTES = OFF_FLAG + 16;                   // 51,728 B (the 256 
 
 template <bool EXPORT_DS>     // always true (one instantiation): as a plain function hipcc builds a 36 % longer main loop from the same source
 __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
-    const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfS /* Er fragments x log2(e)/8 */, const uint32_t* __restrict__ padbits,
+    const uint16_t* __restrict__ qkv, const u32x4* __restrict__ EfA, const uint32_t* __restrict__ padbits,
     const uint16_t* __restrict__ dctx, const float* __restrict__ nlse2 /* -lse log2(e) */, const float* __restrict__ ndelta /* -delta */,
     uint16_t* __restrict__ dqkv, uint16_t* __restrict__ dst, int L, int d, int bgroup) {
     using namespace k2;
@@ -649,12 +647,11 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
     // sweep is unconditional with a clamped index; data of clamped tiles / chunks is never used.
     const uint32_t lane16 = (uint32_t)lane * 16u;
     auto e_frag = [&](int q, int ks) {
-        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)EfS + (size_t)min(max(q, 0), nchunk - 1) * 4096 + ks * 1024 + lane16));
+        return __builtin_bit_cast(bf16x8, *(const u32x4*)((const char*)EfA + (size_t)min(max(q, 0), nchunk - 1) * 4096 + ks * 1024 + lane16));
     };
-    // -lse log2(e) (lanes 0..31) / -delta (lanes 32..63) of row (lane & 31) of a query tile, from the pre-pass's copies: both are
-    // INITIAL ACCUMULATORS -- of the two Q.Er^T chunk products (rows = queries; the lane permutation of the skew keeps a value in
-    // its row) and of dP = dO V^T --, so the MFMAs deliver the exponent's argument and dP - delta without a VALU instruction.
-    // Every wave stages (and reads) its own 256-byte copy: no statistic crosses waves.
+    // -lse log2(e) (lanes 0..31) / -delta (lanes 32..63) of row (lane & 31) of a query tile, from the pre-pass's copies, in the form
+    // the kernel consumes them -- the addend of the exponent's fma and the INITIAL ACCUMULATOR of dP = dO V^T (rows = queries) --,
+    // so the DMA needs no arithmetic on the way.  Every wave stages (and reads) its own 256-byte copy: no statistic crosses waves.
     const uint32_t st_voff = (uint32_t)(((lane & 32) ? (const char*)ndelta - (const char*)nlse2 : 0) + (lane & 31) * 4);   // |offset| < 2^31: same allocation
     const char* st_base = (const char*)(nlse2 + stat_base + J0);
     const uint32_t lds_w = lds_addr_of(smem) + w * 1024;   // this wave's 1 KB of every 4 KB image; + OFF_ST: its 256 B of statistics
@@ -683,11 +680,7 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         const uint16_t* kp = qkv_b + (size_t)(j0 + bl) * ld + d + hd * 64 + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            // K carries the exponent's whole multiplier log2(e)/8 (one bf16 rounding per element, here; the Er copy EfS carries the
-            // same factor): S arrives as the argument of exp2.  q stays unscaled -- it is also the operand of dK, whose 1/8 is the
-            // final scale of the accumulators.
-            kf[ks] = MGX_DKV_FOLD ? __builtin_bit_cast(bf16x8, scale8(*(const u32x4*)(kp + ks * 16), 0.125f * LOG2E))
-                                  : __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + ks * 16));
+            kf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + ks * 16));
             vf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(kp + d + ks * 16));
             e[0][ks] = e_frag(0, ks);                       // the wave's first step (t = wk) is its diagonal: hi chunk 0
             e[1][ks] = e[0][ks];
@@ -754,11 +747,11 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
             const f32x4 l4 = (MGX_DKV_PEEL & 32) ? f32x4{-9.f, -9.f, -9.f, -9.f} : *(const f32x4*)(st + (8 * g4 + 4 * hh) * 4);
             nl[4 * g4] = l4.x; nl[4 * g4 + 1] = l4.y; nl[4 * g4 + 2] = l4.z; nl[4 * g4 + 3] = l4.w;
         }
-        f32x16 qe = MGX_DKV_FOLD ? nl : zero16();
+        f32x16 qe = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qe = mfma(qa[ks], e[PAR][ks], qe);
         if (!MASKED || dq >= 1) {
-            f32x16 ql = MGX_DKV_FOLD ? nl : zero16();
+            f32x16 ql = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ql = mfma(qa[ks], e[PAR ^ 1][ks], ql);
 #pragma unroll
@@ -809,9 +802,8 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         f32x16 ds;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = (MGX_DKV_PEEL & 8) ? c[r] * 1e-9f
-                            : MGX_DKV_FOLD ? __builtin_amdgcn_exp2f(c[r])                                            // c = S log2(e) - lse2
-                                           : __builtin_amdgcn_exp2f(__builtin_fmaf(c[r], 0.125f * LOG2E, nl[r]));    // c = 8 S
+            // c = 8 S: q is staged unscaled, 1/8 (exact) rides in this multiplier and in the final scale of dK
+            const float p = (MGX_DKV_PEEL & 8) ? c[r] * 1e-9f : __builtin_amdgcn_exp2f(__builtin_fmaf(c[r], 0.125f * LOG2E, nl[r]));
             c[r] = p;
             ds[r] = p * dp[r];
         }
@@ -1111,7 +1103,7 @@ __global__ __launch_bounds__(512, 2) void rel_attn_de_kernel(
 // ================================================================================================
 #ifndef MGX_DET_PEEL
 #define MGX_DET_PEEL 0      // timing experiments only (tools/peel_de_tiles.sh): 1 three quarters of the scatter stores | 2 no products |
-#endif                      // 4 q tile re-read from row block 0 (L2-resident); results are then wrong
+#endif                      // 4 q tile re-read from row block 0 (L2-resident) | 8 no atomic flush of the chunk sums; results are then wrong
 namespace k3t {
 #ifndef MGX_DET_STEPS
 #define MGX_DET_STEPS 32
@@ -1261,6 +1253,7 @@ __global__ __launch_bounds__(320, 4) void rel_attn_de_tiles_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int dl = d0 - 32 + 32 * w + crow(r, hh);
+        if ((MGX_DET_PEEL & 8) && de0[r] + de1[r] != 12345.f) continue;      // peel: no flush (timing only)
         if (dl >= 0 && dl < L) {
             if (det) {
                 long long* drow = det + (size_t)(L - 1 - dl) * 64;
@@ -1290,12 +1283,12 @@ static int bwd_batch_group(int B, int L, int d) {
 static size_t ws_stat_bytes(int B, int L, int d) { return (((size_t)B * (d / 64) * L * 4) + 255) / 256 * 256; }      // one f32 [B,h,L]
 static size_t ws_delta_bytes(int B, int L, int d) { return 3 * ws_stat_bytes(B, L, d); }    // delta | -lse log2e | -delta
 
-static size_t ws_ert_bytes(int L) { return 3 * er_frag_bytes(L); }   // EfA | EfT | EfS
+static size_t ws_ert_bytes(int L) { return 2 * er_frag_bytes(L); }   // EfA | EfT
 
 extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
     if (B <= 0 || L <= 0 || d <= 0) return 0;
-    // delta, -lse log2e, -delta f32 [B,h,L] each | fragment-ordered Er (EfA, EfT, EfS) | causal half of dS by (query tile, key
-    // tile) bf16: B*h*T tiles of 2 KB
+    // delta, -lse log2e, -delta f32 [B,h,L] each | fragment-ordered Er (EfA, EfT) | causal half of dS by (query tile, key tile) bf16:
+    // B*h*T tiles of 2 KB
     const size_t nchunk = (size_t)L / 32;
     return ws_delta_bytes(B, L, d) + ws_ert_bytes(L) + (size_t)B * (d / 64) * (nchunk * (nchunk + 1) / 2) * 2048;
 }
@@ -1331,13 +1324,12 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     float* ndelta = (float*)((char*)workspace + 2 * ws_stat_bytes(B, L, d));
     u32x4* EfA = (u32x4*)((char*)workspace + ws_delta_bytes(B, L, d));
     u32x4* EfT = (u32x4*)((char*)EfA + er_frag_bytes(L));
-    u32x4* EfS = (u32x4*)((char*)EfT + er_frag_bytes(L));
     uint16_t* dst = (uint16_t*)((char*)EfA + ws_ert_bytes(L));
     if (parts & 1) {
         // delta = rowsum(dO o O) for the kernels that form dS (dK/dV and the two recompute cross-checks)
         const long total = (long)B * L * heads * 8;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ctx, dctx, lse, delta, nlse2, ndelta, B, L, d);
-        launch_er_frag(Er, EfA, EfT, L, s, EfS, MGX_DKV_FOLD ? 0.125f * LOG2E : 1.f);
+        launch_er_frag(Er, EfA, EfT, L, s);
     }
     const int bg = bwd_batch_group(B, L, d);
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
@@ -1355,7 +1347,7 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
 #endif
         const dim3 gk(bg * heads, ((L + 32 * k2::KW - 1) / (32 * k2::KW)) * (B / bg));
         MGX_REQUIRE(gk.y <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: too many key blocks for the grid");
-        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gk, dim3(64 * k2::KW), dkv_lds, s, qkv, EfS, padbits, dctx, nlse2, ndelta, dqkv, dst, L, d, bg);
+        hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gk, dim3(64 * k2::KW), dkv_lds, s, qkv, EfA, padbits, dctx, nlse2, ndelta, dqkv, dst, L, d, bg);
     }
 #if MGX_EXPERIMENTS
     if (parts & 64) {                                   // experiment builds: dK/dV with 64 keys per wave (tools/experiments/rel_attn_bwd64.hip)

@@ -204,24 +204,14 @@ MGX_DEV void store_rows_lds(uint16_t* dst, size_t row_stride, const f32x16& t0, 
 //       fragment of the transposed chunk: A operand of dq^T += Er^T . dQE^T (dQ kernel)
 inline size_t er_frag_bytes(int L) { return (((size_t)L * 64 * 2) + 255) / 256 * 256; }
 
-//   EfS: EfA with every element multiplied by `scale` (rounded to bf16 once, here) -- the dK/dV kernel's copy, scale =
-//       log2(e)/8: its K fragments carry the same factor, so the S MFMAs deliver the exponent's argument directly
 static __global__ __launch_bounds__(256) void er_frag_kernel(const uint16_t* __restrict__ Er, u32x4* __restrict__ EfA,
-                                                             u32x4* __restrict__ EfT, u32x4* __restrict__ EfS, float scale, int L) {
+                                                             u32x4* __restrict__ EfT, int L) {
     const int n = (L >> 5) * 4 * 64;                      // u32x4 units per buffer
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < n) {
         const int lane = gid & 63, ks = (gid >> 6) & 3, q = gid >> 8;
         const int delta = 32 * q + (lane & 31);
-        const u32x4 raw = *(const u32x4*)(Er + (size_t)(L - 1 - delta) * 64 + 16 * ks + 8 * (lane >> 5));
-        EfA[gid] = raw;
-        if (EfS) {
-            float f[8];
-            unpack8(raw, f);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] *= scale;
-            EfS[gid] = pack8(f);
-        }
+        EfA[gid] = *(const u32x4*)(Er + (size_t)(L - 1 - delta) * 64 + 16 * ks + 8 * (lane >> 5));
     } else if (gid < 2 * n && EfT) {
         const int g = gid - n;
         const int lane = g & 63, ct = (g >> 6) & 1, ks = (g >> 7) & 1, q = g >> 8;
@@ -239,10 +229,9 @@ static __global__ __launch_bounds__(256) void er_frag_kernel(const uint16_t* __r
     }
 }
 
-static inline void launch_er_frag(const uint16_t* Er, u32x4* EfA, u32x4* EfT, int L, hipStream_t s, u32x4* EfS = nullptr,
-                                  float scale = 1.f) {
+static inline void launch_er_frag(const uint16_t* Er, u32x4* EfA, u32x4* EfT, int L, hipStream_t s) {
     const int n = (L >> 5) * 4 * 64 * (EfT ? 2 : 1);
-    hipLaunchKernelGGL(er_frag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Er, EfA, EfT, EfS, scale, L);
+    hipLaunchKernelGGL(er_frag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Er, EfA, EfT, L);
 }
 
 // experiment builds only (tools/experiments/rel_attn_bwd64.hip): dK / dV with 64 keys per wave (L % 128 == 0)

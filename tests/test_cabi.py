@@ -66,9 +66,9 @@ def test_shape_errors_have_messages():
     assert rc == -1 and b"K%64==0" in lib.mgx_last_error()
     rc = lib.mgx_add_ln_fwd(one, one, one, one, one, one, one, 4, 4100, 1e-6, 0.0, 0, None)
     assert rc == -1
-    # three f32 [B,h,L] statistics (delta, -lse log2e, -delta) + three fragment-ordered bf16 copies of E [L,64] + the causal half
+    # three f32 [B,h,L] statistics (delta, -lse log2e, -delta) + two fragment-ordered bf16 copies of E [L,64] + the causal half
     # of dS by (query tile, key tile): 64*65/2 tiles of 32x32 bf16 per (b,h)
-    assert lib.mgx_rel_attn_bwd_workspace(8, 2048, 512) == 3 * 8 * 8 * 2048 * 4 + 3 * 64 * 2048 * 2 + 8 * 8 * (64 * 65 // 2) * 2048
+    assert lib.mgx_rel_attn_bwd_workspace(8, 2048, 512) == 3 * 8 * 8 * 2048 * 4 + 2 * 64 * 2048 * 2 + 8 * 8 * (64 * 65 // 2) * 2048
     # deterministic mode: argument validation (no GPU needed)
     assert lib.mgx_deterministic() == 0
     assert lib.mgx_set_deterministic(ctypes.c_void_p(12), 1 << 20) == -1 and b"aligned" in lib.mgx_last_error()
