@@ -519,6 +519,18 @@ def main():
                                   "achieved": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12,
                                   "frac": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}}
         out["roofline"].update(pmc_traffic(dom_k, B, L, d))
+        # MFMA-busy of the attention kernels from the committed PMC passes of this shape (tools/pmc_attn.sh: SQ_VALU_MFMA_BUSY_CYCLES
+        # / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)); like `traffic`, a committed measurement of this command, not of this run
+        pmc_path = os.path.join(ROOT, "profiles", f"r04_pmc_attn_b{B}.json")
+        if (L, d) == (2048, 512) and os.path.exists(pmc_path):
+            pk = json.load(open(pmc_path))["kernels"]
+            for k in per_kernel:
+                m = [v for n, v in pk.items() if k in n]
+                if m:
+                    per_kernel[k]["mfma_busy_pmc"] = m[0]["mfma_busy_frac"]
+            tw = sum(per_kernel[k]["ms"] * per_kernel[k].get("mfma_busy_pmc", 0.0) for k in per_kernel) / sum(per_kernel[k]["ms"] for k in per_kernel)
+            out["attention_mfma_busy_pmc"] = {"time_weighted": tw, "source": os.path.basename(pmc_path),
+                                              "note": "cycle ratio; the chip runs these kernels at 1.5-2.0 GHz (DESIGN.md 2.6)"}
         out["kernel_ms"] = kt
         out["attention_kernels"] = per_kernel
         out["attention_all_kernels"] = {
