@@ -567,6 +567,10 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 // (round 4 experiment, removed: log2(e)/8 folded into K and into a scaled copy of the Er fragments, -lse log2(e) as the initial
 //  accumulator of the Q.Er^T products, so that S arrives as the exponent's argument -- 16 fewer VALU per tile: 1.258 ms against
 //  1.262 at cfg2 / batch 64, nothing; and the backward's P would no longer equal the forward's bit for bit.)
+#ifndef MGX_DKV_ONEIMG
+#define MGX_DKV_ONEIMG 1    // 1: q and dO staged as ONE LDS image each (image R), the transposed fragments read from it with 2-way bank conflicts --
+#endif                      //    two DMA instructions fewer per wave and tile: 1.227 against 1.252 ms at cfg2 / batch 64 (a VMEM instruction costs the
+                            //    issuing wave ~50 cycles here, tools/dkv_stamp.py).  0 (A/B builds): separate images R and T, conflict-free reads
 #ifndef MGX_DKV_WAVES
 #define MGX_DKV_WAVES 4     // waves (= 32-key tiles) per workgroup of the dK/dV kernel: 4 (128 keys) or 2 (64 keys, A/B builds: a shorter diagonal
 #endif                      // block and twice the workgroups, but every wave stages twice as much: 1.315 against 1.246 ms at cfg2 / batch 64)
@@ -663,9 +667,9 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         for (int i = 0; i < NS; ++i) {
             const uint32_t dw = lds_w + KW * 1024 * i + buf * TILE_BYTES;       // slots 64 (w + KW i) .. + 63
             dma16(qb, q_voffR[i], dw + OFF_QR);
-            dma16(qb, q_voffT[i], dw + OFF_QT);
+            if (!MGX_DKV_ONEIMG) dma16(qb, q_voffT[i], dw + OFF_QT);
             dma16(ob, o_voffR[i], dw + OFF_OR);
-            dma16(ob, o_voffT[i], dw + OFF_OT);
+            if (!MGX_DKV_ONEIMG) dma16(ob, o_voffT[i], dw + OFF_OT);
         }
         dma4(st_base + (size_t)tn * 128, st_voff, lds_addr_of(smem) + OFF_ST + buf * ST_BYTES + w * 256);
     };
@@ -815,10 +819,10 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         for (int ss = 0; ss < 2; ++ss) {
             const bf16x8 pf = acc_to_frag(c, ss);
             const bf16x8 df = acc_to_frag(ds, ss);
-            dv0 = mfma(frag_T(ot, lane, ss, 0), pf, dv0);
-            dv1 = mfma(frag_T(ot, lane, ss, 1), pf, dv1);
-            dk0 = mfma(frag_T(qt, lane, ss, 0), df, dk0);
-            dk1 = mfma(frag_T(qt, lane, ss, 1), df, dk1);
+            dv0 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(orr, lane, ss, 0) : frag_T(ot, lane, ss, 0), pf, dv0);
+            dv1 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(orr, lane, ss, 1) : frag_T(ot, lane, ss, 1), pf, dv1);
+            dk0 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(qr, lane, ss, 0) : frag_T(qt, lane, ss, 0), df, dk0);
+            dk1 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(qr, lane, ss, 1) : frag_T(qt, lane, ss, 1), df, dk1);
             dfx[ss] = __builtin_bit_cast(u32x4, df);
         }
         // streamed (read back from HBM by two later kernels): costs this kernel 55-100 us of its 600 at cfg2 (tools/peel_dkv.sh);
