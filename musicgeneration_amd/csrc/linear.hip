@@ -301,6 +301,17 @@ MGX_DEV int imgH_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 
 // through a 4 KB swizzled patch (32 rows x 128 B, 16-byte chunk c of row r at chunk c ^ (r & 7)): every global store
 // instruction writes 8 full 128-byte row segments.  bias / ReLU on the accumulator side; ReLU-backward mask and residual
 // addend on the row-major side (coalesced loads).  The block lies inside the matrix: 16 unconditional stores.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+// max(x, 0) on a packed bf16 pair: as 16-bit integers a negative bf16 (-0 included) is negative and a positive one keeps its order
+// (v_pk_max_i16) -- the same result as v_max_f32 before the conversion, one instruction per pair instead of two per element
+MGX_DEV uint32_t relu_bf16x2(uint32_t p) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), (s16x2)(0)));
+}
+// FWD: bias / ReLU (forward projection); !FWD: ReLU-backward mask / residual addend (dX).  The variants a kernel cannot take are
+// compiled out and `act` selects between two straight-line bodies: the epilogue used to be ~1,500 instructions per wave (per-element
+// v_max + v_cndmask on the runtime `act`, both operand paths) -- 5.5 K cycles per tile with the MFMA pipe idle, 17 % of a K = 512
+// tile and 30 % of a K = 256 one (tools/ring_stamp.py)
+template <bool FWD>
 MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restrict__ relu_y,
                               const uint16_t* __restrict__ addend, f32x16 (&acc)[4][2], bool bias, int act, int mb,
                               int nb, int N, int lane, char* patch) {
@@ -308,7 +319,7 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
     const int rr = lane >> 3, ch = lane & 7;
     // bias: the wave's 64 values were put into its patch by DMA a tile ago (a vector load here would be waited for with
     // the whole DMA ring ahead of it in the in-order VMEM queue); added in place before the patch is reused
-    if (bias) {
+    if (FWD && bias) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -322,21 +333,25 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
             }
         wave_lds_fence();
     }
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    char* wr = patch + l31 * 128 + 8 * hh;
+    const int sw = l31 & 7;
+    auto park = [&](int rt, auto relu_tag) {                 // 32 rows of the block -> the patch, row-major
+        constexpr bool RELU = decltype(relu_tag)::value;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[k] = acc[rt][ct][4 * g4 + k];
-                    if (act == 1) v[k] = fmaxf(v[k], 0.f);
-                }
-                *(u32x2*)(patch + l31 * 128 + (((4 * ct + g4) ^ (l31 & 7)) << 4) + 8 * hh) =
-                    u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                uint32_t p0 = pack_bf16x2(acc[rt][ct][4 * g4 + 0], acc[rt][ct][4 * g4 + 1]);
+                uint32_t p1 = pack_bf16x2(acc[rt][ct][4 * g4 + 2], acc[rt][ct][4 * g4 + 3]);
+                if (RELU) { p0 = relu_bf16x2(p0); p1 = relu_bf16x2(p1); }
+                *(u32x2*)(wr + (((4 * ct + g4) ^ sw) << 4)) = u32x2{p0, p1};
             }
+    };
+    const bool relu = FWD && act == 1;
+    uint16_t* crow = C + (size_t)(mb + rr) * N + nb + ch * 8;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        if (relu) park(rt, std::true_type{}); else park(rt, std::false_type{});
         wave_lds_fence();
         u32x4 o[4];
 #pragma unroll
@@ -344,7 +359,7 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
             const int row = rr + 8 * i;
             o[i] = *(const u32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
         }
-        if (relu_y || addend) {
+        if (!FWD && (relu_y || addend)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const size_t off = (size_t)(mb + 32 * rt + rr + 8 * i) * N + nb + ch * 8;
@@ -365,9 +380,12 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
                 o[i] = pack8(f);
             }
         }
+#ifdef MGX_RING_PEEL_STORE            // diagnostic: the stores of the epilogue left out (the kernel's result is then garbage)
+        if (o[0].x == 0x12345678u && o[1].y == 0x9abcdef0u)
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(C + (size_t)(mb + 32 * rt + rr + 8 * i) * N + nb + ch * 8) = o[i];
+            *(u32x4*)(crow + (size_t)(32 * rt + 8 * i) * N) = o[i];
         }
         wave_lds_fence();
     }
@@ -438,8 +456,6 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         }
     };
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i][0] = zero16(); acc[i][1] = zero16(); }
     bf16x8 fa[2][4], fb[2][2];
     auto rd_a = [&](int stg, int ks, int i) {
         return *(const bf16x8*)(smem + stg * RG_STAGE + imgH_off(128 * wm + 32 * i + l31, 2 * ks + hh));
@@ -474,8 +490,9 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
     auto join = [&](const u32x2 (&h)[2]) { return __builtin_bit_cast(bf16x8, u32x4{h[0].x, h[0].y, h[1].x, h[1].y}); };
     // one block: the 8 MFMAs of fragment set `cur`; each gap carries one fragment read of the NEXT block (into set cur ^ 1)
     // or one DMA piece
-    auto block = [&](auto cur_tag, int nstg, auto nks_tag, const uint16_t* g0, char* l0, const uint16_t* g1, char* l1, bool on) {
+    auto block = [&](auto cur_tag, int nstg, auto nks_tag, const uint16_t* g0, char* l0, const uint16_t* g1, char* l1, bool on, auto first_tag) {
         constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1, NKS = decltype(nks_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;   // a tile's first block: C = 0 (an inline constant) instead of 128 v_mov per tile
         const bf16x8(&a)[4] = fa[CUR];
         bf16x8(&na)[4] = fa[NXT];
         bf16x8 b[2];
@@ -484,27 +501,26 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         MGX_SB();
         // reads in the first three gaps (two per gap), DMA pieces in gaps 3 and 5: by the end of the block the reads have had
         // five MFMAs to return
-        acc[0][0] = mfma(b[0], a[0], acc[0][0]); MGX_SB();
+        // (round 4: which gaps carry the pieces -- 1/3, 3/5, 5/7 -- makes no difference, and neither did spreading the eight waves'
+        //  pieces over all eight gaps, which only cost the scalar branches)
+#define MGX_GAP(i) do { MGX_SB(); if (on && (i) == 3) glds16(g0, l0); if (on && (i) == 5) glds16(g1, l1); MGX_SB(); } while (0)
+        acc[0][0] = mfma(b[0], a[0], FIRST ? zero16() : acc[0][0]); MGX_SB();
         na[0] = rd_a(nstg, NKS, 0);
         if (BTRANS) rd_bt(nstg, nks_tag, 0, hb[NXT][0]); else fb[NXT][0] = rd_b(nstg, NKS, 0);
-        MGX_SB();
-        acc[0][1] = mfma(b[1], a[0], acc[0][1]); MGX_SB();
+        MGX_GAP(0);
+        acc[0][1] = mfma(b[1], a[0], FIRST ? zero16() : acc[0][1]); MGX_SB();
         na[1] = rd_a(nstg, NKS, 1);
         if (BTRANS) rd_bt(nstg, nks_tag, 1, hb[NXT][1]); else fb[NXT][1] = rd_b(nstg, NKS, 1);
-        MGX_SB();
-        acc[1][0] = mfma(b[0], a[1], acc[1][0]); MGX_SB();
+        MGX_GAP(1);
+        acc[1][0] = mfma(b[0], a[1], FIRST ? zero16() : acc[1][0]); MGX_SB();
         na[2] = rd_a(nstg, NKS, 2);
         na[3] = rd_a(nstg, NKS, 3);
-        MGX_SB();
-        acc[1][1] = mfma(b[1], a[1], acc[1][1]); MGX_SB();
-        if (on) glds16(g0, l0);
-        MGX_SB();
-        acc[2][0] = mfma(b[0], a[2], acc[2][0]); MGX_SB();
-        acc[2][1] = mfma(b[1], a[2], acc[2][1]); MGX_SB();
-        if (on) glds16(g1, l1);
-        MGX_SB();
-        acc[3][0] = mfma(b[0], a[3], acc[3][0]); MGX_SB();
-        acc[3][1] = mfma(b[1], a[3], acc[3][1]); MGX_SB();
+        MGX_GAP(2);
+        acc[1][1] = mfma(b[1], a[1], FIRST ? zero16() : acc[1][1]); MGX_GAP(3);
+        acc[2][0] = mfma(b[0], a[2], FIRST ? zero16() : acc[2][0]); MGX_GAP(4);
+        acc[2][1] = mfma(b[1], a[2], FIRST ? zero16() : acc[2][1]); MGX_GAP(5);
+        acc[3][0] = mfma(b[0], a[3], FIRST ? zero16() : acc[3][0]); MGX_GAP(6);
+        acc[3][1] = mfma(b[1], a[3], FIRST ? zero16() : acc[3][1]); MGX_GAP(7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of the block has returned (asm reads included)
         MGX_SB();
     };
@@ -537,37 +553,58 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
     MGX_SB();
     int h = 0, ti = 0, since_epi = 2, cs = 0;
     bool pend = false;                                       // the B pieces of the newest request are still to be issued
+#ifdef MGX_RING_STAMP
+    // diagnostic build only (tools/ring_stamp.py): s_memtime sums per phase, left by lane 0 of every wave in the first bytes of C
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();
+#define RING_STAMP(i) do { MGX_SB(); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); MGX_SB(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define RING_STAMP(i)
+#endif
     for (int g = 0; g < G; ++g) {
         const int ns = (cs + 1) & 3;
         // block 1: multiply (stage cs, k 0..15); its gaps read (cs, k 16..31) and issue the B pieces of the request made at
         // the last barrier
-        block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend);
+        if (h == 0) block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, std::true_type{});
+        else block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, std::false_type{});
+        RING_STAMP(0);
         // (the block ended with lgkmcnt(0): this wave has read everything it needs from stage cs)
         // step g+1 has landed once at most the younger operations are outstanding: requests g+2 and g+3 (4 each) and,
         // for two steps after a tile's epilogue, its 16 stores
         if (g + 3 < G) { if (since_epi < 2) wait_vmcnt<24>(); else wait_vmcnt<8>(); }
         else wait_vmcnt<0>();
+        RING_STAMP(1);
         __builtin_amdgcn_s_barrier();
+        RING_STAMP(2);
         pend = (g + 4 < G);
         if (pend) dma_begin();                                // request g+4 goes into the stage everyone has just left
         // block 2: multiply (cs, k 16..31); its gaps read (ns, k 0..15) and issue the A pieces of the new request
-        block(T1{}, ns, T0{}, ap[0] + d_k0, d_at, ap[1] + d_k0, d_at + 1024, pend);
+        block(T1{}, ns, T0{}, ap[0] + d_k0, d_at, ap[1] + d_k0, d_at + 1024, pend, std::false_type{});
+        RING_STAMP(3);
         ++since_epi;
         if (h == nh - 1) {
             int m0, n0;
             tile_origin(ti, m0, n0);
             // (the host only takes this kernel for M % 256 == 0 and NO % 256 == 0: every tile is whole, 16 unconditional
             //  stores per wave -- the count the waits above rely on)
-            store_wave_block(C, relu_y, addend, acc, bias != nullptr, act, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+            store_wave_block<!BTRANS>(C, relu_y, addend, acc, bias != nullptr, act, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
             since_epi = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { acc[i][0] = zero16(); acc[i][1] = zero16(); }
             ++ti;
             if (bias && ti < my_tiles) dma_bias(ti);
+            RING_STAMP(4);
         }
         h = (h + 1 == nh) ? 0 : h + 1;
         cs = ns;
     }
+#ifdef MGX_RING_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        float* rec = (float*)C + ((size_t)blockIdx.x * 8 + w) * 16;
+        for (int i = 0; i < 5; ++i) rec[i] = (float)st_acc[i];
+        rec[5] = (float)G; rec[6] = (float)my_tiles; rec[7] = (float)(__builtin_amdgcn_s_memtime() - st_t0);
+        rec[8] = (float)(__builtin_amdgcn_s_memrealtime() - st_r0); rec[9] = (float)w;
+    }
+#endif
 }
 
 // =================================================================================================
