@@ -392,6 +392,13 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
 }
 
 #define MGX_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef MGX_RING_PEEL
+// diagnostic builds only (results are garbage): 1 no barrier in the loop, 2 no DMA in the loop, 4 no fragment reads.  Round 4, per step of
+// cfg2's forward GEMMs at batch 64 (tools/ab_gemm.sh): product 2.71 ms; no barrier 2.70; no DMA 2.31; no fragment reads 2.33; neither
+// 1.83; all three 1.64 (= the MFMAs, the epilogue and the loop: 1.25 PF).  The barrier is free; the DMA pieces and the fragment reads
+// cost 15 % each and add up -- the waves' in-order issue behind the LDS pipe, not its bandwidth (12 reads + 4 pieces per wave and step)
+#define MGX_RING_PEEL 0
+#endif
 template <bool BTRANS>
 __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
                                                             const float* __restrict__ bias,
@@ -503,18 +510,24 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         // five MFMAs to return
         // (round 4: which gaps carry the pieces -- 1/3, 3/5, 5/7 -- makes no difference, and neither did spreading the eight waves'
         //  pieces over all eight gaps, which only cost the scalar branches)
-#define MGX_GAP(i) do { MGX_SB(); if (on && (i) == 3) glds16(g0, l0); if (on && (i) == 5) glds16(g1, l1); MGX_SB(); } while (0)
+#define MGX_GAP(i) do { MGX_SB(); if (!(MGX_RING_PEEL & 2) && on && (i) == 3) glds16(g0, l0); if (!(MGX_RING_PEEL & 2) && on && (i) == 5) glds16(g1, l1); MGX_SB(); } while (0)
         acc[0][0] = mfma(b[0], a[0], FIRST ? zero16() : acc[0][0]); MGX_SB();
-        na[0] = rd_a(nstg, NKS, 0);
-        if (BTRANS) rd_bt(nstg, nks_tag, 0, hb[NXT][0]); else fb[NXT][0] = rd_b(nstg, NKS, 0);
+        if (!(MGX_RING_PEEL & 4)) {
+            na[0] = rd_a(nstg, NKS, 0);
+            if (BTRANS) rd_bt(nstg, nks_tag, 0, hb[NXT][0]); else fb[NXT][0] = rd_b(nstg, NKS, 0);
+        }
         MGX_GAP(0);
         acc[0][1] = mfma(b[1], a[0], FIRST ? zero16() : acc[0][1]); MGX_SB();
-        na[1] = rd_a(nstg, NKS, 1);
-        if (BTRANS) rd_bt(nstg, nks_tag, 1, hb[NXT][1]); else fb[NXT][1] = rd_b(nstg, NKS, 1);
+        if (!(MGX_RING_PEEL & 4)) {
+            na[1] = rd_a(nstg, NKS, 1);
+            if (BTRANS) rd_bt(nstg, nks_tag, 1, hb[NXT][1]); else fb[NXT][1] = rd_b(nstg, NKS, 1);
+        }
         MGX_GAP(1);
         acc[1][0] = mfma(b[0], a[1], FIRST ? zero16() : acc[1][0]); MGX_SB();
-        na[2] = rd_a(nstg, NKS, 2);
-        na[3] = rd_a(nstg, NKS, 3);
+        if (!(MGX_RING_PEEL & 4)) {
+            na[2] = rd_a(nstg, NKS, 2);
+            na[3] = rd_a(nstg, NKS, 3);
+        }
         MGX_GAP(2);
         acc[1][1] = mfma(b[1], a[1], FIRST ? zero16() : acc[1][1]); MGX_GAP(3);
         acc[2][0] = mfma(b[0], a[2], FIRST ? zero16() : acc[2][0]); MGX_GAP(4);
@@ -574,7 +587,7 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         if (g + 3 < G) { if (since_epi < 2) wait_vmcnt<24>(); else wait_vmcnt<8>(); }
         else wait_vmcnt<0>();
         RING_STAMP(1);
-        __builtin_amdgcn_s_barrier();
+        if (!(MGX_RING_PEEL & 1)) __builtin_amdgcn_s_barrier();
         RING_STAMP(2);
         pend = (g + 4 < G);
         if (pend) dma_begin();                                // request g+4 goes into the stage everyone has just left
