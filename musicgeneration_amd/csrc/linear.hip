@@ -392,6 +392,9 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
 }
 
 #define MGX_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef MGX_RING_ALWAYS
+#define MGX_RING_ALWAYS 1
+#endif
 #ifndef MGX_RING_PEEL
 // diagnostic builds only (results are garbage): 1 no barrier in the loop, 2 no DMA in the loop, 4 no fragment reads.  Round 4, per step of
 // cfg2's forward GEMMs at batch 64 (tools/ab_gemm.sh): product 2.71 ms; no barrier 2.70; no DMA 2.31; no fragment reads 2.33; neither
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
     char* patch = smem + RG_NST * RG_STAGE + w * RG_PATCH;
     if (G <= 0) return;
     auto tile_origin = [&](int i, int& m0, int& n0) {        // i-th tile of this workgroup
-        const int t = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles);
+        const int t = min(xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles), ntiles - 1);   // (a request past the last tile re-reads it)
         m0 = (t / ntn) * 256; n0 = (t % ntn) * 256;
     };
 
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         // five MFMAs to return
         // (round 4: which gaps carry the pieces -- 1/3, 3/5, 5/7 -- makes no difference, and neither did spreading the eight waves'
         //  pieces over all eight gaps, which only cost the scalar branches)
-#define MGX_GAP(i) do { MGX_SB(); if (!(MGX_RING_PEEL & 2) && on && (i) == 3) glds16(g0, l0); if (!(MGX_RING_PEEL & 2) && on && (i) == 5) glds16(g1, l1); MGX_SB(); } while (0)
+#define MGX_GAP(i) do { MGX_SB(); if (!(MGX_RING_PEEL & 2) && (MGX_RING_ALWAYS || on) && (i) == 3) glds16(g0, l0); if (!(MGX_RING_PEEL & 2) && (MGX_RING_ALWAYS || on) && (i) == 5) glds16(g1, l1); MGX_SB(); } while (0)
         acc[0][0] = mfma(b[0], a[0], FIRST ? zero16() : acc[0][0]); MGX_SB();
         if (!(MGX_RING_PEEL & 4)) {
             na[0] = rd_a(nstg, NKS, 0);
@@ -566,6 +569,8 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
     MGX_SB();
     int h = 0, ti = 0, since_epi = 2, cs = 0;
     bool pend = false;                                       // the B pieces of the newest request are still to be issued
+    // (ALWAYS: block 1 of step 0 would issue B pieces of a request that was never begun -- the prologue's fourth, whose pieces are
+    //  complete: d_at / b_src still describe it, so the pieces are fetched once more into the same place)
 #ifdef MGX_RING_STAMP
     // diagnostic build only (tools/ring_stamp.py): s_memtime sums per phase, left by lane 0 of every wave in the first bytes of C
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -589,8 +594,8 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         RING_STAMP(1);
         if (!(MGX_RING_PEEL & 1)) __builtin_amdgcn_s_barrier();
         RING_STAMP(2);
-        pend = (g + 4 < G);
-        if (pend) dma_begin();                                // request g+4 goes into the stage everyone has just left
+        pend = MGX_RING_ALWAYS || (g + 4 < G);                // (ALWAYS: past the end of the stream the pieces re-read the last tile into a
+        if (pend) dma_begin();                                //  stage nobody reads again, instead of four scalar branches per step)                                // request g+4 goes into the stage everyone has just left
         // block 2: multiply (cs, k 16..31); its gaps read (ns, k 0..15) and issue the A pieces of the new request
         block(T1{}, ns, T0{}, ap[0] + d_k0, d_at, ap[1] + d_k0, d_at + 1024, pend, std::false_type{});
         RING_STAMP(3);
@@ -609,6 +614,7 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         h = (h + 1 == nh) ? 0 : h + 1;
         cs = ns;
     }
+    if (MGX_RING_ALWAYS) wait_vmcnt<0>();                    // the pieces requested past the end land before the workgroup's LDS is released
 #ifdef MGX_RING_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
