@@ -311,7 +311,8 @@ MGX_DEV uint32_t relu_bf16x2(uint32_t p) {
 // compiled out and `act` selects between two straight-line bodies: the epilogue used to be ~1,500 instructions per wave (per-element
 // v_max + v_cndmask on the runtime `act`, both operand paths) -- 5.5 K cycles per tile with the MFMA pipe idle, 17 % of a K = 512
 // tile and 30 % of a K = 256 one (tools/ring_stamp.py)
-template <bool FWD>
+template <bool FWD, int PRE = 0>     // PRE (dX only): 0 plain, 1 ReLU-backward mask, 2 residual addend -- straight-line variants: across a
+                                     // runtime branch hipcc's wait for the prefetched rows becomes vmcnt(0) again
 MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restrict__ relu_y,
                               const uint16_t* __restrict__ addend, f32x16 (&acc)[4][2], bool bias, int act, int mb,
                               int nb, int N, int lane, char* patch) {
@@ -349,6 +350,19 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
     };
     const bool relu = FWD && act == 1;
     uint16_t* crow = C + (size_t)(mb + rr) * N + nb + ch * 8;
+    // dX with a mask / addend: the rows that belong to a 32-row slice are requested ONE SLICE AHEAD, right before the previous slice's
+    // stores.  Loaded where they are used, every slice was waited for with vmcnt(0) -- behind the previous slice's four stores, a full
+    // store round trip per slice: 19-32 K cycles per tile instead of 4 K (tools/ring_stamp.py), +27 % on the dX of QKV, +80 % on the dX
+    // of FFN_pre.  One ahead, the wait is a counted one that leaves the stores in flight: 12-18 K cycles.  (All sixteen rows up front
+    // would hide the load latency as well, but need 64 registers the accumulators do not leave; the host sends a call with BOTH
+    // operands to the 128 x 128 kernel; the training step never makes one.)
+    const uint16_t* prow = PRE ? (PRE == 2 ? addend : relu_y) + (size_t)(mb + rr) * N + nb + ch * 8 : nullptr;
+    u32x4 pre[4];
+    auto prefetch = [&](int rt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[i] = *(const u32x4*)(prow + (size_t)(32 * rt + 8 * i) * N);
+    };
+    if (PRE) { __builtin_amdgcn_sched_barrier(0); prefetch(0); __builtin_amdgcn_sched_barrier(0); }   // (the scheduler would hoist every slice's loads to the top: spills)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
         if (relu) park(rt, std::true_type{}); else park(rt, std::false_type{});
@@ -359,34 +373,30 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
             const int row = rr + 8 * i;
             o[i] = *(const u32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
         }
-        if (!FWD && (relu_y || addend)) {
+        if (!FWD && PRE) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const size_t off = (size_t)(mb + 32 * rt + rr + 8 * i) * N + nb + ch * 8;
-                float f[8];
+                float f[8], a[8];
                 unpack8(o[i], f);
-                if (relu_y) {
-                    float y[8];
-                    unpack8(*(const u32x4*)(relu_y + off), y);
+                unpack8(pre[i], a);
+                if (PRE == 1) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) f[k] = (y[k] > 0.f) ? f[k] : 0.f;
-                }
-                if (addend) {
-                    float a[8];
-                    unpack8(*(const u32x4*)(addend + off), a);
+                    for (int k = 0; k < 8; ++k) f[k] = (a[k] > 0.f) ? f[k] : 0.f;
+                } else {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) f[k] += a[k];
                 }
                 o[i] = pack8(f);
+                __builtin_amdgcn_sched_barrier(0);            // (row by row: four rows' temporaries at once spill)
             }
+            if (rt + 1 < 4) prefetch(rt + 1);                 // into the registers just consumed, ahead of this slice's stores
+            __builtin_amdgcn_sched_barrier(0);
         }
 #ifdef MGX_RING_PEEL_STORE            // diagnostic: the stores of the epilogue left out (the kernel's result is then garbage)
         if (o[0].x == 0x12345678u && o[1].y == 0x9abcdef0u)
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(crow + (size_t)(32 * rt + 8 * i) * N) = o[i];
-        }
+        for (int i = 0; i < 4; ++i) *(u32x4*)(crow + (size_t)(32 * rt + 8 * i) * N) = o[i];
         wave_lds_fence();
     }
 }
@@ -568,6 +578,7 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MGX_SB();
     int h = 0, ti = 0, since_epi = 2, cs = 0;
+    bool first = true;                                       // the next block 1 starts a tile (set by the epilogue: the accumulators are dead across it)
     bool pend = false;                                       // the B pieces of the newest request are still to be issued
     // (ALWAYS: block 1 of step 0 would issue B pieces of a request that was never begun -- the prologue's fourth, whose pieces are
     //  complete: d_at / b_src still describe it, so the pieces are fetched once more into the same place)
@@ -583,8 +594,9 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         const int ns = (cs + 1) & 3;
         // block 1: multiply (stage cs, k 0..15); its gaps read (cs, k 16..31) and issue the B pieces of the request made at
         // the last barrier
-        if (h == 0) block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, std::true_type{});
+        if (first) block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, std::true_type{});
         else block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, std::false_type{});
+        first = false;
         RING_STAMP(0);
         // (the block ended with lgkmcnt(0): this wave has read everything it needs from stage cs)
         // step g+1 has landed once at most the younger operations are outstanding: requests g+2 and g+3 (4 each) and,
@@ -605,10 +617,23 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
             tile_origin(ti, m0, n0);
             // (the host only takes this kernel for M % 256 == 0 and NO % 256 == 0: every tile is whole, 16 unconditional
             //  stores per wave -- the count the waits above rely on)
-            store_wave_block<!BTRANS>(C, relu_y, addend, acc, bias != nullptr, act, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+            if (BTRANS && addend) store_wave_block<!BTRANS, 2>(C, relu_y, addend, acc, false, 0, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+            else if (BTRANS && relu_y) store_wave_block<!BTRANS, 1>(C, relu_y, addend, acc, false, 0, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+            else store_wave_block<!BTRANS, 0>(C, relu_y, addend, acc, bias != nullptr, act, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
             since_epi = 0;
+            first = true;
             ++ti;
             if (bias && ti < my_tiles) dma_bias(ti);
+            // the fragments block 2 has just prefetched for the next step are read AGAIN here instead of being kept across the
+            // epilogue (48 registers the epilogue's prefetch of the mask / addend rows needs; ~150 cycles per tile)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[0][i] = rd_a(ns, 0, i);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (BTRANS) rd_bt(ns, T0{}, i, hb[0][i]); else fb[0][i] = rd_b(ns, 0, i);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             RING_STAMP(4);
         }
         h = (h + 1 == nh) ? 0 : h + 1;
@@ -1458,7 +1483,7 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
     MGX_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, MGX_ERR_SHAPE,
                 "mgx_linear_dx: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
     set_attrs();
-    if (const int rg = ring_grid(M, K, N)) {          // dX [M,K] = dY [M,N] . W [N,K]: reduction over N, W read transposed
+    if (const int rg = (relu_y && addend) ? 0 : ring_grid(M, K, N)) {   // dX [M,K] = dY [M,N] . W [N,K]: reduction over N, W read transposed
         hipLaunchKernelGGL(linear_ring_kernel<true>, dim3(rg), dim3(512), RG_LDS, (hipStream_t)stream, dY, W,
                            (const float*)nullptr, relu_y, addend, dX, M, K, N, 0);
         MGX_CHECK_LAUNCH("mgx_linear_dx");

@@ -20,7 +20,9 @@ for name, N, K in [("qkv", 1536, 512), ("fc", 512, 512), ("ffn_pre", 256, 512), 
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
     b = torch.randn(N, generator=g).to(dev)
     dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
-    for kind, fn in (("fwd", lambda: ops.linear_fwd(x, w, b, 0)), ("dx", lambda: ops.linear_dx(dy, w, None))):
+    add = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    for kind, fn in (("fwd", lambda: ops.linear_fwd(x, w, b, 0)), ("dx", lambda: ops.linear_dx(dy, w, None)),
+                     ("dx+add", lambda: ops.linear_dx(dy, w, None, add)), ("dx+mask", lambda: ops.linear_dx(dy, w, add, None))):
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,6 +33,6 @@ for name, N, K in [("qkv", 1536, 512), ("fc", 512, 512), ("ffn_pre", 256, 512), 
         mhz = (rec[:, 7].sum() / rec[:, 8].sum()).item() * 100
         m = rec.mean(0)
         steps = [m[i].item() / G for i in range(4)]
-        print(f"{name:8s} {kind:3s} {e0.elapsed_time(e1)*1e3:7.1f} us  clock {mhz:5.0f} MHz  steps/WG {G:5.0f} tiles/WG {T:4.1f} | per step: block1 {steps[0]:6.0f} "
+        print(f"{name:8s} {kind:7s} {e0.elapsed_time(e1)*1e3:7.1f} us  clock {mhz:5.0f} MHz  steps/WG {G:5.0f} tiles/WG {T:4.1f} | per step: block1 {steps[0]:6.0f} "
               f"dma-wait {steps[1]:5.0f} barrier {steps[2]:5.0f} block2 {steps[3]:6.0f} = {sum(steps):6.0f} (MFMA floor 1024 per SIMD, 512 per wave) | "
               f"epilogue {m[4].item() / max(T, 1):7.0f} per tile | total {m[7].item():9.0f} cycles")
