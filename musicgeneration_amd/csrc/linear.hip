@@ -475,7 +475,6 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
             glds16(b_src(j), d_at + 16384 + j * 1024);
         }
     };
-    f32x16 acc[4][2];
     bf16x8 fa[2][4], fb[2][2];
     auto rd_a = [&](int stg, int ks, int i) {
         return *(const bf16x8*)(smem + stg * RG_STAGE + imgH_off(128 * wm + 32 * i + l31, 2 * ks + hh));
@@ -510,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
     auto join = [&](const u32x2 (&h)[2]) { return __builtin_bit_cast(bf16x8, u32x4{h[0].x, h[0].y, h[1].x, h[1].y}); };
     // one block: the 8 MFMAs of fragment set `cur`; each gap carries one fragment read of the NEXT block (into set cur ^ 1)
     // or one DMA piece
-    auto block = [&](auto cur_tag, int nstg, auto nks_tag, const uint16_t* g0, char* l0, const uint16_t* g1, char* l1, bool on, auto first_tag) {
+    auto block = [&](f32x16 (&acc)[4][2], auto cur_tag, int nstg, auto nks_tag, const uint16_t* g0, char* l0, const uint16_t* g1, char* l1, bool on, auto first_tag) {
         constexpr int CUR = decltype(cur_tag)::value, NXT = CUR ^ 1, NKS = decltype(nks_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;   // a tile's first block: C = 0 (an inline constant) instead of 128 v_mov per tile
         const bf16x8(&a)[4] = fa[CUR];
@@ -577,8 +576,7 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     MGX_SB();
-    int h = 0, ti = 0, since_epi = 2, cs = 0;
-    bool first = true;                                       // the next block 1 starts a tile (set by the epilogue: the accumulators are dead across it)
+    int g = 0, since_epi = 2, cs = 0;
     bool pend = false;                                       // the B pieces of the newest request are still to be issued
     // (ALWAYS: block 1 of step 0 would issue B pieces of a request that was never begun -- the prologue's fourth, whose pieces are
     //  complete: d_at / b_src still describe it, so the pieces are fetched once more into the same place)
@@ -590,13 +588,12 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
 #else
 #define RING_STAMP(i)
 #endif
-    for (int g = 0; g < G; ++g) {
+    // one reduction step of the stream (g counts them over all tiles of the workgroup)
+    auto step = [&](f32x16 (&acc)[4][2], auto first_tag) {
         const int ns = (cs + 1) & 3;
         // block 1: multiply (stage cs, k 0..15); its gaps read (cs, k 16..31) and issue the B pieces of the request made at
         // the last barrier
-        if (first) block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, std::true_type{});
-        else block(T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, std::false_type{});
-        first = false;
+        block(acc, T0{}, cs, T1{}, b_src(0), d_at + 16384, b_src(1), d_at + 16384 + 1024, pend, first_tag);
         RING_STAMP(0);
         // (the block ended with lgkmcnt(0): this wave has read everything it needs from stage cs)
         // step g+1 has landed once at most the younger operations are outstanding: requests g+2 and g+3 (4 each) and,
@@ -607,37 +604,40 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
         if (!(MGX_RING_PEEL & 1)) __builtin_amdgcn_s_barrier();
         RING_STAMP(2);
         pend = MGX_RING_ALWAYS || (g + 4 < G);                // (ALWAYS: past the end of the stream the pieces re-read the last tile into a
-        if (pend) dma_begin();                                //  stage nobody reads again, instead of four scalar branches per step)                                // request g+4 goes into the stage everyone has just left
+        if (pend) dma_begin();                                //  stage nobody reads again, instead of four scalar branches per step)
         // block 2: multiply (cs, k 16..31); its gaps read (ns, k 0..15) and issue the A pieces of the new request
-        block(T1{}, ns, T0{}, ap[0] + d_k0, d_at, ap[1] + d_k0, d_at + 1024, pend, std::false_type{});
+        block(acc, T1{}, ns, T0{}, ap[0] + d_k0, d_at, ap[1] + d_k0, d_at + 1024, pend, std::false_type{});
         RING_STAMP(3);
         ++since_epi;
-        if (h == nh - 1) {
-            int m0, n0;
-            tile_origin(ti, m0, n0);
-            // (the host only takes this kernel for M % 256 == 0 and NO % 256 == 0: every tile is whole, 16 unconditional
-            //  stores per wave -- the count the waits above rely on)
-            if (BTRANS && addend) store_wave_block<!BTRANS, 2>(C, relu_y, addend, acc, false, 0, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
-            else if (BTRANS && relu_y) store_wave_block<!BTRANS, 1>(C, relu_y, addend, acc, false, 0, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
-            else store_wave_block<!BTRANS, 0>(C, relu_y, addend, acc, bias != nullptr, act, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
-            since_epi = 0;
-            first = true;
-            ++ti;
-            if (bias && ti < my_tiles) dma_bias(ti);
-            // the fragments block 2 has just prefetched for the next step are read AGAIN here instead of being kept across the
-            // epilogue (48 registers the epilogue's prefetch of the mask / addend rows needs; ~150 cycles per tile)
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[0][i] = rd_a(ns, 0, i);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (BTRANS) rd_bt(ns, T0{}, i, hb[0][i]); else fb[0][i] = rd_b(ns, 0, i);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            RING_STAMP(4);
-        }
-        h = (h + 1 == nh) ? 0 : h + 1;
+        ++g;
         cs = ns;
+    };
+    // The accumulators live inside the tile loop: after the epilogue has read them they are dead, and the compiler knows it (as
+    // one flat loop over steps with a runtime "first step of a tile" test it kept all 128 alive across the epilogue).
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        f32x16 acc[4][2];
+        step(acc, std::true_type{});                         // the tile's first block multiplies with C = 0
+        for (int h = 1; h < nh; ++h) step(acc, std::false_type{});
+        int m0, n0;
+        tile_origin(ti, m0, n0);
+        // (the host only takes this kernel for M % 256 == 0 and NO % 256 == 0: every tile is whole, 16 unconditional
+        //  stores per wave -- the count the waits above rely on)
+        if (BTRANS && addend) store_wave_block<!BTRANS, 2>(C, relu_y, addend, acc, false, 0, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+        else if (BTRANS && relu_y) store_wave_block<!BTRANS, 1>(C, relu_y, addend, acc, false, 0, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+        else store_wave_block<!BTRANS, 0>(C, relu_y, addend, acc, bias != nullptr, act, m0 + 128 * wm, n0 + 64 * wn, NO, lane, patch);
+        since_epi = 0;
+        if (bias && ti + 1 < my_tiles) dma_bias(ti + 1);
+        // the fragments block 2 has just prefetched for the next step are read AGAIN here instead of being kept across the
+        // epilogue (48 registers the epilogue's prefetch of the mask / addend rows needs; ~150 cycles per tile)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[0][i] = rd_a(cs, 0, i);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (BTRANS) rd_bt(cs, T0{}, i, hb[0][i]); else fb[0][i] = rd_b(cs, 0, i);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RING_STAMP(4);
     }
     if (MGX_RING_ALWAYS) wait_vmcnt<0>();                    // the pieces requested past the end land before the workgroup's LDS is released
 #ifdef MGX_RING_STAMP
