@@ -350,35 +350,52 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
     };
     const bool relu = FWD && act == 1;
     uint16_t* crow = C + (size_t)(mb + rr) * N + nb + ch * 8;
-    // dX with a mask / addend: the rows that belong to a 32-row slice are requested ONE SLICE AHEAD, right before the previous slice's
-    // stores.  Loaded where they are used, every slice was waited for with vmcnt(0) -- behind the previous slice's four stores, a full
-    // store round trip per slice: 19-32 K cycles per tile instead of 4 K (tools/ring_stamp.py), +27 % on the dX of QKV, +80 % on the dX
-    // of FFN_pre.  One ahead, the wait is a counted one that leaves the stores in flight: 12-18 K cycles.  (All sixteen rows up front
-    // would hide the load latency as well, but need 64 registers the accumulators do not leave; the host sends a call with BOTH
-    // operands to the 128 x 128 kernel; the training step never makes one.)
-    const uint16_t* prow = PRE ? (PRE == 2 ? addend : relu_y) + (size_t)(mb + rr) * N + nb + ch * 8 : nullptr;
-    u32x4 pre[4];
-    auto prefetch = [&](int rt) {
+    if constexpr (!FWD && PRE != 0) {
+        // dX with a mask / addend.  Loaded where they are used, the rows of a 32-row slice were waited for with vmcnt(0) -- behind the
+        // previous slice's four stores, a full store round trip per slice: 19-32 K cycles per tile instead of 4 K (tools/ring_stamp.py),
+        // +27 % on the dX of QKV, +80 % on the dX of FFN_pre.  Now all sixteen rows of the tile are requested at once, after the
+        // accumulators have been packed to bf16 (64 registers instead of 128: what makes room for 64 registers of rows in flight),
+        // and waited for once: 11-17 K cycles.  What is left is bandwidth, not latency: every workgroup reaches its epilogue at the
+        // same time, and 32 MB of rows in + 32 MB of tile out per round of tiles is ~12 us of HBM on its own (with the operand
+        // these K <= 512 GEMMs sit at 1.4-1.5 x their HBM floors).  (The host sends a call with BOTH operands to the 128 x 128
+        // kernel; the training step never makes one.)
+        const uint16_t* prow = (PRE == 2 ? addend : relu_y) + (size_t)(mb + rr) * N + nb + ch * 8;
+        u32x4 pre[4][4];
+        u32x2 pk[4][8];
+        auto fetch = [&](int rt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pre[i] = *(const u32x4*)(prow + (size_t)(32 * rt + 8 * i) * N);
-    };
-    if (PRE) { __builtin_amdgcn_sched_barrier(0); prefetch(0); __builtin_amdgcn_sched_barrier(0); }   // (the scheduler would hoist every slice's loads to the top: spills)
+            for (int i = 0; i < 4; ++i) pre[rt][i] = *(const u32x4*)(prow + (size_t)(32 * rt + 8 * i) * N);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0); fetch(1);                                  // (hipcc moves these below the packing whatever is put between them)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        if (relu) park(rt, std::true_type{}); else park(rt, std::false_type{});
-        wave_lds_fence();
-        u32x4 o[4];
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = rr + 8 * i;
-            o[i] = *(const u32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
-        }
-        if (!FWD && PRE) {
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    pk[rt][4 * ct + g4] = u32x2{pack_bf16x2(acc[rt][ct][4 * g4 + 0], acc[rt][ct][4 * g4 + 1]),
+                                                pack_bf16x2(acc[rt][ct][4 * g4 + 2], acc[rt][ct][4 * g4 + 3])};
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(2); fetch(3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) *(u32x2*)(wr + ((c8 ^ sw) << 4)) = pk[rt][c8];
+            wave_lds_fence();
+            u32x4 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rr + 8 * i;
+                o[i] = *(const u32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float f[8], a[8];
                 unpack8(o[i], f);
-                unpack8(pre[i], a);
+                unpack8(pre[rt][i], a);
                 if (PRE == 1) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) f[k] = (a[k] > 0.f) ? f[k] : 0.f;
@@ -387,17 +404,30 @@ MGX_DEV void store_wave_block(uint16_t* __restrict__ C, const uint16_t* __restri
                     for (int k = 0; k < 8; ++k) f[k] += a[k];
                 }
                 o[i] = pack8(f);
-                __builtin_amdgcn_sched_barrier(0);            // (row by row: four rows' temporaries at once spill)
             }
-            if (rt + 1 < 4) prefetch(rt + 1);                 // into the registers just consumed, ahead of this slice's stores
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(crow + (size_t)(32 * rt + 8 * i) * N) = o[i];
+            wave_lds_fence();
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            if (relu) park(rt, std::true_type{}); else park(rt, std::false_type{});
+            wave_lds_fence();
+            u32x4 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rr + 8 * i;
+                o[i] = *(const u32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
 #ifdef MGX_RING_PEEL_STORE            // diagnostic: the stores of the epilogue left out (the kernel's result is then garbage)
-        if (o[0].x == 0x12345678u && o[1].y == 0x9abcdef0u)
+            if (o[0].x == 0x12345678u && o[1].y == 0x9abcdef0u)
 #endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(crow + (size_t)(32 * rt + 8 * i) * N) = o[i];
-        wave_lds_fence();
+            for (int i = 0; i < 4; ++i) *(u32x4*)(crow + (size_t)(32 * rt + 8 * i) * N) = o[i];
+            wave_lds_fence();
+        }
     }
 }
 
