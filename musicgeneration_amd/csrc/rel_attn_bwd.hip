@@ -567,6 +567,10 @@ __global__ __launch_bounds__(256, 2) void rel_attn_dq_lite_kernel(
 // (round 4 experiment, removed: log2(e)/8 folded into K and into a scaled copy of the Er fragments, -lse log2(e) as the initial
 //  accumulator of the Q.Er^T products, so that S arrives as the exponent's argument -- 16 fewer VALU per tile: 1.258 ms against
 //  1.262 at cfg2 / batch 64, nothing; and the backward's P would no longer equal the forward's bit for bit.)
+#ifndef MGX_DKV_IMGB
+#define MGX_DKV_IMGB 0      // 1 (A/B builds): the one image of q / dO is image B (rel_attn_common.hpp: conflict-free for the row AND the transposed
+#endif                      //    reads; the 37 M conflict cycles of the kernel's 211 M LDS cycles are gone): 1.262-1.267 against 1.255-1.259 ms with
+                            //    image R and its 2-way conflicted transposed reads -- the conflicts cost nothing, the longer swizzle a little
 #ifndef MGX_DKV_ONEIMG
 #define MGX_DKV_ONEIMG 1    // 1: q and dO staged as ONE LDS image each (image R), the transposed fragments read from it with 2-way bank conflicts --
 #endif                      //    two DMA instructions fewer per wave and tile: 1.227 against 1.252 ms at cfg2 / batch 64 (a VMEM instruction costs the
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int slot = tid + 64 * KW * i, srow = slot >> 3, spc = slot & 7;
-        const int lcR = spc ^ ((srow >> 1) & 7), lcT = spc ^ (((srow >> 1) & 1) << 2);   // logical chunks: imgR_off / imgT_off inverted
+        const int lcR = spc ^ (MGX_DKV_IMGB ? imgB_swz(srow) : ((srow >> 1) & 7)), lcT = spc ^ (((srow >> 1) & 1) << 2);   // logical chunks: imgR_off (imgB_off) / imgT_off inverted
         q_voffR[i] = (uint32_t)((srow * ld + lcR * 8) * 2); q_voffT[i] = (uint32_t)((srow * ld + lcT * 8) * 2);
         o_voffR[i] = (uint32_t)((srow * d + lcR * 8) * 2);  o_voffT[i] = (uint32_t)((srow * d + lcT * 8) * 2);
     }
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         const char* qr = smem + OFF_QR + cur * TILE_BYTES;
         bf16x8 qa[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_R(qr, bl, hh, ks);
+        for (int ks = 0; ks < 4; ++ks) qa[ks] = MGX_DKV_IMGB ? frag_B(qr, bl, hh, ks) : frag_R(qr, bl, hh, ks);
         // Q.Er^T for chunks dq ("hi": keys bl <= query, t = a - bl) and dq-1 ("lo": keys bl > query, t = 32 + a - bl); rows =
         // query a, columns = t.  A tile reads column (a - bl) & 31 of row a and needs the hi chunk there for t <= a and the lo
         // chunk for t > a: the two products are MERGED in registers (one v_cndmask per element) and stored once -- 16 band
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         }
         const char* orr = smem + OFF_OR + cur * TILE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dp = mfma(frag_R(orr, bl, hh, ks), vf[ks], dp);
+        for (int ks = 0; ks < 4; ++ks) dp = mfma(MGX_DKV_IMGB ? frag_B(orr, bl, hh, ks) : frag_R(orr, bl, hh, ks), vf[ks], dp);
         f32x16 ds;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -819,10 +823,10 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         for (int ss = 0; ss < 2; ++ss) {
             const bf16x8 pf = acc_to_frag(c, ss);
             const bf16x8 df = acc_to_frag(ds, ss);
-            dv0 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(orr, lane, ss, 0) : frag_T(ot, lane, ss, 0), pf, dv0);
-            dv1 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(orr, lane, ss, 1) : frag_T(ot, lane, ss, 1), pf, dv1);
-            dk0 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(qr, lane, ss, 0) : frag_T(qt, lane, ss, 0), df, dk0);
-            dk1 = mfma(MGX_DKV_ONEIMG ? frag_T_onR(qr, lane, ss, 1) : frag_T(qt, lane, ss, 1), df, dk1);
+            dv0 = mfma(MGX_DKV_ONEIMG ? (MGX_DKV_IMGB ? frag_T_onB(orr, lane, ss, 0) : frag_T_onR(orr, lane, ss, 0)) : frag_T(ot, lane, ss, 0), pf, dv0);
+            dv1 = mfma(MGX_DKV_ONEIMG ? (MGX_DKV_IMGB ? frag_T_onB(orr, lane, ss, 1) : frag_T_onR(orr, lane, ss, 1)) : frag_T(ot, lane, ss, 1), pf, dv1);
+            dk0 = mfma(MGX_DKV_ONEIMG ? (MGX_DKV_IMGB ? frag_T_onB(qr, lane, ss, 0) : frag_T_onR(qr, lane, ss, 0)) : frag_T(qt, lane, ss, 0), df, dk0);
+            dk1 = mfma(MGX_DKV_ONEIMG ? (MGX_DKV_IMGB ? frag_T_onB(qr, lane, ss, 1) : frag_T_onR(qr, lane, ss, 1)) : frag_T(qt, lane, ss, 1), df, dk1);
             dfx[ss] = __builtin_bit_cast(u32x4, df);
         }
         // streamed (read back from HBM by two later kernels): costs this kernel 55-100 us of its 600 at cfg2 (tools/peel_dkv.sh);

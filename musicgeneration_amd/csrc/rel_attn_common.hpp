@@ -82,6 +82,29 @@ MGX_DEV bf16x8 frag_T_onR(const char* tile, int lane, int s, int ct) {
     return out;
 }
 
+// LDS image "B" (both): the chunk XORed with a permutation of (row>>1)&7 whose bit 2 is bit 1 of the row -- the eight same-parity rows a
+// ds_read_b128 lane group touches still get eight different values (conflict-free row fragments, as on image R), and rows q and q+2 of a
+// 4-row block differ in bit 2 (conflict-free ds_read_b64_tr_b16, as on image T): ONE image serves both kinds of fragment reads.
+MGX_DEV int imgB_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
+MGX_DEV int imgB_off(int row, int chunk) { return row * 128 + ((chunk ^ imgB_swz(row)) << 4); }
+MGX_DEV bf16x8 frag_B(const char* tile, int row, int hh, int ks) {
+    return *(const bf16x8*)(tile + imgB_off(row, 2 * ks + hh));
+}
+MGX_DEV bf16x8 frag_T_onB(const char* tile, int lane, int s, int ct) {      // as frag_T_onR
+    const int i = lane & 15, g = lane >> 4, hh = lane >> 5;
+    const int rq = i >> 2;
+    const int chunk = 4 * ct + 2 * (g & 1) + ((i & 3) >> 1);
+    const int byte_in = 8 * (i & 1);
+    bf16x8 out;
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+        const int row = 16 * s + 8 * jq + 4 * hh + rq;
+        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(tile + imgB_off(row, chunk) + byte_in));
+        out[4 * jq + 0] = t[0]; out[4 * jq + 1] = t[1]; out[4 * jq + 2] = t[2]; out[4 * jq + 3] = t[3];
+    }
+    return out;
+}
+
 MGX_DEV u32x4 scale8(const u32x4& raw, float sc) {
     float f[8];
     unpack8(raw, f);
