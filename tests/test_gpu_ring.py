@@ -39,7 +39,11 @@ for i, (M, N, K, use_b, act) in enumerate([(512, 256, 128, True, 0), (768, 512, 
 # dX: (M, N(reduction), K(out), relu mask, addend)
 for i, (M, N, K, use_y, use_add) in enumerate([(512, 128, 256, False, False), (768, 256, 512, True, False),
                                                (1024, 1536, 512, False, True), (512, 512, 256, True, True),
-                                               (76800, 128, 256, True, True)]):
+                                               (76800, 128, 256, True, True),
+                                               # ring-sized calls with ONE epilogue operand, as the training step makes them (the ring
+                                               # kernel prefetches the operand's rows; a call with both goes to the 128 x 128 kernel)
+                                               (65536, 512, 256, True, False), (49152, 256, 512, False, True),
+                                               (32768, 1536, 512, False, True), (65536, 256, 256, False, False)]):
     dY, W = rnd(M, N), rnd(N, K)
     y = rnd(M, K) if use_y else None
     add = rnd(M, K) if use_add else None
