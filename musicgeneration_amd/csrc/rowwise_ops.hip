@@ -198,6 +198,13 @@ extern "C" int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, uint32_t* flag
 // K6  out = LN(dropout(x) + res)      one wave per row, row held in registers (d <= 2048)
 // =================================================================================================
 constexpr int LN_MAXC = 4;   // chunks of 512 columns per wave
+#ifndef MGX_LNF_GRID
+#define MGX_LNF_GRID 1048576  // cap on the workgroups of the forward (4 waves = 4 rows each): uncapped, one row per wave -- with the cap of 4096 used until
+                              // round 4 a wave looped over 8 rows at batch 64: 78 against 70 us (tools/ln_bench.py)
+#endif
+#ifndef MGX_LNB_BLOCKS
+#define MGX_LNB_BLOCKS 512    // workgroups of the backward (= rows of its column-partial buffer): 512-768 are level (132-134 us at batch 64), 1024 140, 256 154
+#endif
 
 template <int NC>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(
@@ -423,11 +430,11 @@ static void launch_ln_fwd(const uint16_t* x, const uint16_t* res, const float* g
                           uint16_t* out, float* mean, float* rstd, int rows, int d, float eps, DropCfg dc,
                           hipStream_t s) {
     int grid = (rows + 3) / 4;
-    if (grid > 4096) grid = 4096;
+    if (grid > MGX_LNF_GRID) grid = MGX_LNF_GRID;
     hipLaunchKernelGGL(add_ln_fwd_kernel<NC>, dim3(grid), dim3(256), 0, s, x, res, gamma, beta, out, mean, rstd,
                        rows, d, eps, dc);
 }
-constexpr int LN_BWD_BLOCKS = 1024;
+constexpr int LN_BWD_BLOCKS = MGX_LNB_BLOCKS;
 
 template <int NC>
 static void launch_ln_bwd(const uint16_t* dout, const uint16_t* x, const uint16_t* res, const float* gamma,
