@@ -73,7 +73,7 @@ def test_shape_errors_have_messages():
     assert lib.mgx_deterministic() == 0
     assert lib.mgx_set_deterministic(ctypes.c_void_p(12), 1 << 20) == -1 and b"aligned" in lib.mgx_last_error()
     assert lib.mgx_set_deterministic(None, 0) == 0 and lib.mgx_deterministic() == 0
-    assert lib.mgx_add_ln_bwd_workspace(100, 512) == 1024 * 3 * 512 * 4      # 1,024 blocks of column partials
+    assert lib.mgx_add_ln_bwd_workspace(100, 512) == 512 * 3 * 512 * 4       # 512 blocks of column partials
     rc = lib.mgx_add_ln_bwd(one, one, one, one, one, one, one, one, one, one, None, one, 16, 8, 512, 0.0, 0, None)
     assert rc == -1 and b"workspace" in lib.mgx_last_error()
 
