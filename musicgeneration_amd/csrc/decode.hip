@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void decode_embed_kernel(const int32_t* __rest
 // whichever split covers it (another workgroup appends it to the cache in the same launch).
 constexpr int DEC_WAVES = 8;
 constexpr int DEC_PART = 68;                                   // floats per partial: acc[64], m, l, 2 pad (16-byte aligned rows)
+#ifndef MGX_DEC_NT
+#define MGX_DEC_NT 1
+#endif
 __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
     const uint16_t* __restrict__ qkv_new, uint16_t* __restrict__ kcache, uint16_t* __restrict__ vcache,
     const uint16_t* __restrict__ E, const int32_t* __restrict__ pos_dev, uint16_t* __restrict__ ctx,
@@ -82,9 +85,10 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void rel_attn_decode_kernel(
         const uint16_t* kp = (jc == t) ? qrow + d : kc + (size_t)jc * 64;
         const uint16_t* vp = (jc == t) ? qrow + 2 * d : vc + (size_t)jc * 64;
         float kf[8], ef[8], vf[8];
-        unpack8(*(const u32x4*)(kp + dg * 8), kf);
+        // the K / V caches are streamed once per token (3.2 GB per step at cfg5's end): nontemporal; E rows are shared by every (b, h): cached
+        unpack8(MGX_DEC_NT ? __builtin_nontemporal_load((const u32x4*)(kp + dg * 8)) : *(const u32x4*)(kp + dg * 8), kf);
         unpack8(*(const u32x4*)(Eb + (size_t)jc * 64 + dg * 8), ef);
-        unpack8(*(const u32x4*)(vp + dg * 8), vf);
+        unpack8(MGX_DEC_NT ? __builtin_nontemporal_load((const u32x4*)(vp + dg * 8)) : *(const u32x4*)(vp + dg * 8), vf);
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += q[k] * (kf[k] + ef[k]);
