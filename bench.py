@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--decode-batch", type=int, default=32)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "rehearsing the data-parallel path with several ranks on one GPU)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: issue the gradient all-reduces AFTER backward instead of bucket "
+                    "by bucket from inside it (same results).  The step-time difference against the default run is what the overlap "
+                    "buys; with the per-bucket times of the `dp` block it tells \"RCCL slow\" from \"overlap lost\" on a first multi-GPU run")
     ap.add_argument("--one-device", action="store_true", help="all ranks use cuda:0 (rehearsal with --backend gloo)")
     a = ap.parse_args()
     base = CFG4 if a.workload == "cfg4" else CFG2
@@ -242,15 +245,14 @@ def decode_bench(args):
                                  "bound": "launch latency (weights are 9.4 MB: 1.2 us at the HBM peak)"}}
 
 
-def cfg4_block(args, steps=6, warmup=3):
-    """BASELINE configs[3] at its single-GPU share (SURVEY 8d: MuMIDI V=486, 12 layers, d_model=768 = 12 heads, L=4096, per-GPU
-    batch 4): the same training step as the main line, a short run beside it.  Events/s, the model-level fraction of the bf16
-    MFMA peak in algorithmic FLOPs, and the attention kernels' launch times at this shape."""
+def side_block(args, cfg, label, steps=6, warmup=3, kernel_timing=True):
+    """A second configuration beside the main line: the same training step, a short run.  Events/s, the model-level fraction of
+    the bf16 MFMA peak in algorithmic FLOPs, and (optionally) the attention kernels' launch times at this shape."""
     from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
     from musicgeneration_amd.metrics import CategoricalAccuracy, LogitsBucketting, MetricsSet
     from musicgeneration_amd.network import MusicTransformer
     from musicgeneration_amd.optim import FusedAdam
-    V, nl, d, L, B = CFG4["vocab"], CFG4["layers"], CFG4["d_model"], CFG4["seq_len"], CFG4["batch"]
+    V, nl, d, L, B = cfg["vocab"], cfg["layers"], cfg["d_model"], cfg["seq_len"], cfg["batch"]
     dev = torch.device("cuda")
     torch.manual_seed(0)
     mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=args.dropout).to(dev).train()
@@ -276,19 +278,32 @@ def cfg4_block(args, steps=6, warmup=3):
     dt = time.perf_counter() - t0
     mt.check_pads_trail()
     value = B * L * steps / dt
-    out = {"workload": f"cfg4 at its single-GPU share: MuMIDI_EventSeq MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} bf16, "
+    out = {"workload": f"{label}: MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} bf16, "
                        f"per-GPU batch {B}, fwd+smoothed-CE+bwd+Adam/Noam, dropout {args.dropout}",
            "value": value, "unit": "events/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
            "final_loss": float(last["loss"].item()), "train_mflop_per_event": train_flops_per_event(nl, d, L, V) / 1e6,
            "model_mfma_frac": value * train_flops_per_event(nl, d, L, V) / (PEAK_BF16_TFLOPS * 1e12)}
     del mt, opt, sch, ring, last
     torch.cuda.empty_cache()
-    if not args.no_kernel_timing:
+    if kernel_timing and not args.no_kernel_timing:
         kt = time_kernels(B, L, d, L)
         out["kernel_ms"] = kt
         out["attention_all_kernels"] = {"ms_per_layer": sum(kt.values()),
                                         "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12}
     return out
+
+
+def cfg4_block(args):
+    """BASELINE configs[3] at its single-GPU share (SURVEY 8d: MuMIDI V=486, 12 layers, d_model=768 = 12 heads, L=4096, per-GPU
+    batch 4)"""
+    return side_block(args, CFG4, "cfg4 at its single-GPU share, MuMIDI_EventSeq")
+
+
+def batch8_block(args):
+    """"B per GPU = 8 default, also report the largest that fits".  The main line is the large batch (64: twice the
+    workgroups per launch, shorter tails); this is the same cfg2 step at per-GPU batch 8."""
+    return side_block(args, dict(CFG2, batch=8), "cfg2 REMI_EventSeq at per-GPU batch 8 (SURVEY 8d default)", steps=10, warmup=3,
+                      kernel_timing=False)
 
 
 def pmc_traffic(kernel, B, L, d):
@@ -418,6 +433,7 @@ def main():
     mt.train()
     dp = DataParallel(mt)
     dp.measure_overlap = world > 1
+    dp.overlap = not args.no_overlap
     opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale)
     sch = CustomSchedule(d, optimizer=opt)
     ms = MetricsSet({"accuracy": CategoricalAccuracy(), "loss": SmoothCrossEntropyLoss(0.1, V, V - 1),
@@ -478,11 +494,18 @@ def main():
     }
     if world > 1:
         exposed = dp.exposed_ms()
-        out["dp"] = dict(dp.describe(), buckets=len(mt.store().buckets),
+        bms = dp.bucket_ms()
+        out["dp"] = dict(dp.describe(), buckets=len(mt.store().buckets), overlap=dp.overlap,
                          allreduce_bytes_per_step=dp.bytes_reduced // max(1, args.warmup + args.steps),
                          exposed_allreduce_ms_per_step=exposed,
                          exposed_note="compute-stream stall between the end of backward and the Adam kernel (HIP events "
-                                      "around the bucket waits); the rest of the all-reduce ran under backward")
+                                      "around the bucket waits); the rest of the all-reduce ran under backward",
+                         bucket_issue_to_complete_ms=bms,
+                         bucket_note="per bucket, in issue order (fc first, embedding last): mean time from the moment its gradients "
+                                     "are complete (event on the compute stream) to the completion of its all-reduce (event on a side "
+                                     "stream that depends on the collective; host clock with gloo).  Large while `exposed` is small: the "
+                                     "collectives queue behind backward's kernels (co-residency, DESIGN 4) but still finish in time; "
+                                     "large AND exposed large: RCCL itself is slow; compare with a --no-overlap run")
     if rank == 0 and not args.no_kernel_timing:
         kt = time_kernels(B, L, d, L)
         # credited (algorithmic) and executed product-units per kernel; 1 unit = B*L^2*d FLOPs
@@ -541,6 +564,7 @@ def main():
         del mt, opt, sch, ring, last
         torch.cuda.empty_cache()
         out["cfg4"] = cfg4_block(args)
+        out["batch8"] = batch8_block(args)
     if rank == 0 and world == 1 and not args.no_decode:
         out["decode"] = decode_bench(args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -46,12 +46,19 @@ int mgx_device_count(void);
  * mgx_set_deterministic(scratch, bytes) those kernels add 64-bit FIXED-POINT integers (value * 2^30, each partial sum rounded
  * once) into `scratch` and a fold pass converts the totals: integer addition is associative, so two runs on the same inputs
  * -- and a data-parallel run against a single-process run of the same global batch, up to the all-reduce's own order -- give
- * the same bits.  Partial sums are quantised to 2^-30 ~ 9.3e-10 and must stay below 8.6e9 in magnitude; the cfg2 training
- * step takes 1.1 % longer.  Everything else in the library is deterministic as it is.
+ * the same bits.  Partial sums are quantised to 2^-30 ~ 9.3e-10 (a FIXED quantum: an element whose partials are of magnitude m
+ * keeps log2(m) + 30 bits -- tests/test_gpu_fullsize.py::test_deterministic_mode_at_the_bench_shape states the bound) and must
+ * stay below 2^31 ~ 2.1e9 in magnitude: a partial that is NaN, infinite or larger POISONS its destination -- the fold writes NaN
+ * there, as it does for a total outside +-2^31 -- so a diverging run stays recognisable from its loss and gradients (round 5;
+ * until then such a partial was converted to 0 / garbage).  The cfg2 training step takes 1.1 % longer.  Everything else in the
+ * library is deterministic as it is.
  *   scratch: device memory, 8-byte aligned, owned by the caller and alive until the mode is switched off with
  *            mgx_set_deterministic(NULL, 0); the largest user needs 8 * max(N*K + N, V*d, 64*L) bytes (16 MiB covers cfg4).
- *   The setting is process-wide (the one piece of mutable state in the library); calls that use the scratch must be issued on
- *   ONE stream at a time.                                                                                       */
+ *   PROCESS-GLOBAL, SINGLE-STREAM STATE -- the one exception to "every entry point is stateless and takes its stream" (SURVEY
+ *   8b): the registered scratch is shared by every call of the process, so (a) calls that use it must be issued on ONE stream at a
+ *   time (two streams would zero / fold each other's partial sums), (b) the setting applies to all threads and all model instances
+ *   of the process, (c) switching it while such a call is in flight is undefined.  This matches the deployment the library is
+ *   built for -- one process per GPU, one compute stream -- and is why it is a mode and not an argument.             */
 int mgx_set_deterministic(void* scratch, size_t bytes);
 int mgx_deterministic(void);          /* 1 while a scratch is registered */
 

@@ -21,6 +21,23 @@
 #include "rel_attn_common.hpp"
 #include "mgx.h"
 
+// A/B knobs (MGX_GEMM_RING, MGX_GEMM_SINGLE_BUF, MGX_DW_TARGET_WGS, MGX_DW_GROUP_WGS) exist in experiment builds only
+// (`_build.py --variant NAME --experiments`, -DMGX_EXPERIMENTS=1): the product library reads no environment variable.
+// tests/test_gpu_ring.py builds such a variant to run the ring and the 128 x 128 kernels on the same inputs.
+#ifndef MGX_EXPERIMENTS
+#define MGX_EXPERIMENTS 0
+#endif
+static inline int gemm_knob(const char* name, int unset) {
+#if MGX_EXPERIMENTS
+    const char* e = getenv(name);
+    return e ? atoi(e) : unset;
+#else
+    (void)name;
+    return unset;
+#endif
+}
+
+
 using namespace relattn;
 
 namespace {
@@ -1452,7 +1469,7 @@ static void set_attrs() {
 }
 
 // The ring kernel pays when its 256 x 256 tiles fill the chip (one persistent workgroup per CU) without much padding.
-// MGX_GEMM_RING=0 / 1 forces it off / on where the shape allows (A/B timing).
+// MGX_GEMM_RING=0 / 1 forces it off / on where the shape allows (A/B timing; experiment builds only).
 static int ring_grid(int M, int NO, int R) {
     static int cus = 0, env = -2;
     if (!cus) {
@@ -1460,8 +1477,7 @@ static int ring_grid(int M, int NO, int R) {
         int dev = 0;
         hipGetDevice(&dev);
         cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        const char* e = getenv("MGX_GEMM_RING");
-        env = e ? atoi(e) : -1;
+        env = gemm_knob("MGX_GEMM_RING", -1);
     }
     if (env == 0 || R % 32 != 0 || R < 128 || M % 256 != 0 || NO % 256 != 0) return 0;     // whole tiles only
     const long ntm = (M + 255) / 256, ntn = (NO + 255) / 256;
@@ -1495,7 +1511,7 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
     // Large grids (>= 3 workgroups per CU) run the single-LDS-buffer variant: 32 KiB -> 3 workgroups/CU
     // (+8 % on the QKV projection); small grids keep the double-buffered one (one barrier per step).
     static int sbuf_env = -2;
-    if (sbuf_env == -2) { const char* e = getenv("MGX_GEMM_SINGLE_BUF"); sbuf_env = e ? atoi(e) : -1; }
+    if (sbuf_env == -2) sbuf_env = gemm_knob("MGX_GEMM_SINGLE_BUF", -1);
     const bool sbuf = sbuf_env >= 0 ? (sbuf_env != 0) : (nwg >= 768);
     if (sbuf)
         hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3(nwg), dim3(256), LDS_BYTES / 2, (hipStream_t)stream, A, W, bias, C,
@@ -1514,6 +1530,9 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
                 "mgx_linear_dx: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
     set_attrs();
     if (const int rg = (relu_y && addend) ? 0 : ring_grid(M, K, N)) {   // dX [M,K] = dY [M,N] . W [N,K]: reduction over N, W read transposed
+        // linear_ring_kernel<true> has ONE straight-line epilogue per operand (addend, else mask): a call with both would silently
+        // drop the mask, so the invariant is checked where the kernel is launched, not only in the condition above
+        MGX_REQUIRE(!(relu_y && addend), MGX_ERR_SHAPE, "mgx_linear_dx: the ring kernel takes a ReLU mask OR a residual addend, not both");
         hipLaunchKernelGGL(linear_ring_kernel<true>, dim3(rg), dim3(512), RG_LDS, (hipStream_t)stream, dY, W,
                            (const float*)nullptr, relu_y, addend, dX, M, K, N, 0);
         MGX_CHECK_LAUNCH("mgx_linear_dx");
@@ -1521,7 +1540,7 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
     }
     const int nwg = ((M + BM - 1) / BM) * ((K + BN - 1) / BN);
     static int sbuf_env = -2;
-    if (sbuf_env == -2) { const char* e = getenv("MGX_GEMM_SINGLE_BUF"); sbuf_env = e ? atoi(e) : -1; }
+    if (sbuf_env == -2) sbuf_env = gemm_knob("MGX_GEMM_SINGLE_BUF", -1);
     const bool sbuf = sbuf_env >= 0 ? (sbuf_env != 0) : (nwg >= 768);      // as in the forward: 3 workgroups / CU for big grids
     const bool exact = (N % BK == 0);          // no partial reduction tile: the branch-free load path
 #define MGX_DX_LAUNCH(DB, EX, LDS) hipLaunchKernelGGL((linear_dx_kernel<DB, EX>), dim3(nwg), dim3(256), LDS, (hipStream_t)stream, \
@@ -1545,8 +1564,7 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     // as long as the grid still covers the CUs.
     static int target = -1;
     if (target < 0) {
-        const char* e = getenv("MGX_DW_TARGET_WGS");
-        target = e ? atoi(e) : 0;
+        target = gemm_knob("MGX_DW_TARGET_WGS", 0);
     }
     // measured on MI355X at M=16384 (tools/gemm_bench.py): ~384 workgroups for many-tile weights (QKV),
     // ~256 for the small ones
@@ -1572,7 +1590,7 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
 // plan: number of M-splits so that tiles x splits fills the CUs once; every split gets at least one 32-row step.
 static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRing* out) {
     static int env = -2;
-    if (env == -2) { const char* e = getenv("MGX_GEMM_RING"); env = e ? atoi(e) : -1; }
+    if (env == -2) env = gemm_knob("MGX_GEMM_RING", -1);
     if (env == 0 || M % 32 != 0 || M < 4096) return false;
     DwRing g;
     g.n = count;
@@ -1685,8 +1703,7 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int coun
     const int tiles = g.first_tile[count];
     static int target = -1;
     if (target < 0) {
-        const char* e = getenv("MGX_DW_GROUP_WGS");
-        target = e ? atoi(e) : 480;                        // ~2 workgroups on every CU
+        target = gemm_knob("MGX_DW_GROUP_WGS", 480);       // ~2 workgroups on every CU
     }
     int splits = (target + tiles - 1) / tiles;
     int mchunk = ((M + splits - 1) / splits + 63) / 64 * 64;

@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
         }
         // streamed (read back from HBM by two later kernels): costs this kernel 55-100 us of its 600 at cfg2 (tools/peel_dkv.sh);
         // issuing them before the dV / dK products instead of after changes nothing
-        if (EXPORT_DS && !(MGX_DKV_PEEL & 2)) {
+        if (EXPORT_DS && !(MGX_DKV_PEEL & 2)) {           // == DS_STORES below (`landed`)
             __builtin_nontemporal_store(dfx[0], (u32x4*)dsp);
             __builtin_nontemporal_store(dfx[1], (u32x4*)(dsp + 1024));
         }
@@ -839,7 +839,12 @@ __global__ __launch_bounds__(64 * k2::KW, 2) void rel_attn_dkv_kernel(
     };
     // The next query tile's DMA (issued inside `tile`, after the E loads) must have landed before the barrier that ends the
     // step; the only VMEM operations a wave issues after it are the two dS stores of its tile: a COUNTED wait, vmcnt(2).
-    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); };
+    // (the count follows the condition under which the stores are compiled: a peel build without them must wait for vmcnt(0))
+    constexpr bool DS_STORES = EXPORT_DS && !(MGX_DKV_PEEL & 2);
+    auto landed = [&]() {
+        if (DS_STORES) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     // ---- general body: the diagonal 128 x 128 block (t < 4: a wave is not started / on its diagonal / full), every
     //      step when a key of this workgroup is padded, and an odd last step ------------------------------------------------
     auto general_step = [&](int t) {

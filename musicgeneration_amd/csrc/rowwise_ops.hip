@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(
 // element -- gridDim.y adds per element, not one per token.  (One block per vocabulary row, as until round 3, is a chain of
 // dependent scan / gather phases over the whole batch: 235 us at cfg2 / batch 64 for a 67 MB read.)
 constexpr int EB_CHUNK = 4096;
+constexpr long long EB_BAD_MARK = (long long)0x8000000000000000ull;   // deterministic mode: "this wave saw a value with no fixed-point image"
 // DET (deterministic mode): the order of the LDS hit list depends on the arrival order of the LDS atomics and the token
 // ranges' sums arrive in any order, so every addend (one bf16 gradient element, times its dropout multiplier) is accumulated as
 // a 64-bit fixed-point integer, in the thread, across the waves and across the ranges: the sum is independent of all three
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     for (int g0 = 0; g0 < gpr; g0 += 64) {                  // column pass (one for d <= 512)
         const int gi = g0 + lane;
         acc_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned bad = 0;                                  // DET: bit q = a contribution to column q had no fixed-point image (NaN / Inf / huge)
         for (int base = r_lo; base < r_hi; base += EB_CHUNK) {
             if (tid == 0) nhit = 0;
             __syncthreads();
@@ -99,7 +101,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
                             for (int q = 0; q < 8; ++q) f[q] *= m[q];
                         }
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) acc[q] += DET ? (acc_t)__float2ll_rn(f[q] * MGX_DET_SCALE) : (acc_t)f[q];
+                        for (int q = 0; q < 8; ++q) {
+                            if (DET) {
+                                if (det_representable(f[q])) acc[q] += (acc_t)__float2ll_rn(f[q] * MGX_DET_SCALE);
+                                else bad |= 1u << q;
+                            } else {
+                                acc[q] += (acc_t)f[q];
+                            }
+                        }
                     }
                 }
             }
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
         }
         if (w > 0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) part[w - 1][lane][q] = acc[q];
+            for (int q = 0; q < 8; ++q) part[w - 1][lane][q] = (DET && ((bad >> q) & 1u)) ? (acc_t)EB_BAD_MARK : acc[q];
         }
         __syncthreads();
         if (w == 0 && gi < gpr) {
@@ -115,8 +124,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (DET) {
-                    const long long isum = (long long)(acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]);
-                    if (isum != 0) atomicAdd((unsigned long long*)(det + (size_t)v * d + gi * 8 + q), (unsigned long long)isum);
+                    long long* dq = det + (size_t)v * d + gi * 8 + q;
+                    const long long p0 = (long long)part[0][lane][q], p1 = (long long)part[1][lane][q], p2 = (long long)part[2][lane][q];
+                    if (((bad >> q) & 1u) || p0 == EB_BAD_MARK || p1 == EB_BAD_MARK || p2 == EB_BAD_MARK) { det_poison(dq); continue; }
+                    const long long isum = (long long)acc[q] + p0 + p1 + p2;
+                    if (isum != 0) atomicAdd((unsigned long long*)dq, (unsigned long long)isum);
                 } else {
                     const float sum = (float)(acc[q] + part[0][lane][q] + part[1][lane][q] + part[2][lane][q]) * scale;
                     if (gridDim.y == 1) dp[q] += sum;

@@ -35,6 +35,14 @@ class DataParallel:
         self._sync = True
         self._exposed: List = []          # (event before wait, event after wait) pairs of the compute stream
         self.measure_overlap = False
+        # overlap = False ("no-overlap" mode, bench.py --no-overlap): the buckets are only NOTED as they become ready and all
+        # all-reduces are issued after backward, in wait_all().  Same results; the difference in step time against the default is
+        # what the overlap buys -- on a first multi-GPU run it separates "RCCL is slow" from "the overlap was lost" (DESIGN 4).
+        self.overlap = True
+        self._pending: List[str] = []
+        # per-bucket issue -> complete times (measure_overlap): name -> list of (issue event, done event) [nccl] or seconds [gloo]
+        self._bucket_t: Dict[str, List] = {}
+        self._mstream = None              # side stream that waits for each collective and records its completion (nccl only)
         model._dp = self
         if self.world > 1 or self.force:
             st = model.store()
@@ -60,11 +68,37 @@ class DataParallel:
         """called from inside backward when every gradient of bucket ``name`` has been accumulated"""
         if (self.world == 1 and not self.force) or not self._sync:
             return
+        if not self.overlap:
+            self._pending.append(name)
+            return
+        self._issue(name)
+
+    def _issue(self, name: str):
         st = self.model.store()
         for bname, lo, hi in st.buckets:
             if bname == name:
                 t = st.grad[lo:hi]
-                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                timed = self.measure_overlap and t.is_cuda
+                nccl = timed and dist.get_backend(self.pg) == "nccl"
+                if nccl:
+                    ev0 = torch.cuda.Event(enable_timing=True)
+                    ev0.record()                           # compute stream: the moment the bucket's gradients are complete
+                elif timed:
+                    import time
+                    t0 = time.perf_counter()
+                w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if nccl:
+                    # a side stream takes the collective's completion as a dependency and stamps it: the compute stream is not held
+                    if self._mstream is None:
+                        self._mstream = torch.cuda.Stream()
+                    with torch.cuda.stream(self._mstream):
+                        w.wait()
+                        ev1 = torch.cuda.Event(enable_timing=True)
+                        ev1.record()
+                    self._bucket_t.setdefault(name, []).append((ev0, ev1))
+                elif timed:
+                    w._mgx_t0, w._mgx_name = t0, name       # gloo: host clock, closed in wait_all (wait() blocks the host there)
+                self._works.append(w)
                 self.bytes_reduced += t.numel() * 4
                 return
         raise KeyError(name)
@@ -73,14 +107,20 @@ class DataParallel:
         """make the compute stream wait for every outstanding bucket (RCCL: a stream dependency, not a host
         block).  With ``measure_overlap`` the stall of the compute stream is bracketed by two HIP events: the
         time between them is the part of the all-reduce that backward did NOT hide."""
-        if not self._works:
+        if not self._works and not self._pending:
             return
         ev = None
         if self.measure_overlap and torch.cuda.is_available():
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        for name in self._pending:                        # no-overlap mode: everything is issued here, after backward
+            self._issue(name)
+        self._pending.clear()
         for w in self._works:
             w.wait()
+            if hasattr(w, "_mgx_t0"):
+                import time
+                self._bucket_t.setdefault(w._mgx_name, []).append(time.perf_counter() - w._mgx_t0)
         self._works.clear()
         if ev is not None:
             ev[1].record()
@@ -94,6 +134,20 @@ class DataParallel:
         v = [a.elapsed_time(b) for a, b in self._exposed]
         self._exposed.clear()
         return sum(v) / len(v)
+
+    def bucket_ms(self) -> Optional[Dict[str, float]]:
+        """mean issue -> complete time of each bucket's all-reduce in ms (measure_overlap): with RCCL from a HIP event on the compute
+        stream at issue to one on a side stream that depends on the collective; with gloo from the host clock (its wait blocks)."""
+        if not self._bucket_t:
+            return None
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        out = {}
+        for name, v in self._bucket_t.items():
+            ms = [(a[0].elapsed_time(a[1]) if isinstance(a, tuple) else 1e3 * a) for a in v]
+            out[name] = sum(ms) / len(ms)
+        self._bucket_t.clear()
+        return out
 
     def loss_weight(self, n_local: torch.Tensor) -> torch.Tensor:
         """The reference divides the summed loss by the non-pad count of the batch it sees

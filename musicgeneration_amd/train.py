@@ -128,6 +128,10 @@ def main(argv=None):
         mt.eval()
         with torch.no_grad():
             ex, ey = dataset.slide_seq2seq_batch(2, options.max_seq, 'valid')
+            try:                                           # the same host-side guard as on the training batches: early, and it names the phase
+                utils.check_pads_trail(ex, pad)
+            except ValueError as err:
+                raise ValueError(f'evaluation batch: {err}') from err
             pred, _ = mt.forward(to_dev(ex))
             return metric_set(pred, to_dev(ey))
 
@@ -196,9 +200,11 @@ def main(argv=None):
                 if options.max_batches and idx >= options.max_batches:
                     break
             eval_metrics = evaluate()
-            mt.check_pads_trail()        # the device-side record of the same guard (this is a synchronisation point anyway)
             if (e + 1) % options.saving_interval == 0:
                 save_model(e, eval_metrics['accuracy'])
+            # the device-side record of the pads-trail guard (this is a synchronisation point anyway).  AFTER the checkpoint: the
+            # flag is sticky and shared by training and evaluation forwards, so raising first would lose the epoch just trained
+            mt.check_pads_trail()
             dt = time.time() - t_meter
             log('\n====================================================')
             log('Epoch/Batch: {}/{}'.format(e, b))

@@ -95,6 +95,16 @@ def _worker(rank, world, port, q):
         err = (avg - ref).abs().max().item() / ref.abs().max().item()
         assert err < 1e-5, err
         assert dp.bytes_reduced == 4 * n
+        # no-overlap mode (bench.py --no-overlap): buckets are only noted as they become ready, the all-reduces are issued in
+        # wait_all(); the result is the same sum
+        dp.overlap = False
+        st.grad.copy_(grads(mine))
+        dp.bucket_ready("b"); dp.bucket_ready("a")
+        assert torch.equal(st.grad, grads(mine)) and not dp._works          # nothing issued yet
+        dp.wait_all()
+        assert (st.grad * dp.grad_scale - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+        assert dp.bytes_reduced == 8 * n and not dp._pending
+        dp.overlap = True
         with pytest.raises(KeyError):
             dp.bucket_ready("nope")
         m = dp.all_reduce_scalar_mean(torch.tensor(float(rank)))

@@ -47,7 +47,8 @@ def test_cfg2_shape_forward_backward_vs_oracle():
 
 
 # (64, 2048, 512) is bench.py's default per-GPU shape: the first one whose dS workspace (2.18 GB) has byte offsets beyond 2^31
-@pytest.mark.parametrize("B,L,d", [(8, 2048, 512), (64, 2048, 512), (2, 4096, 768)])
+# (4, 4096, 768) is cfg4's single-GPU share, the shape of bench.py's cfg4 block
+@pytest.mark.parametrize("B,L,d", [(8, 2048, 512), (64, 2048, 512), (2, 4096, 768), (4, 4096, 768)])
 def test_full_batch_properties(B, L, d):
     from musicgeneration_amd import ops
     dev = torch.device("cuda")
@@ -203,7 +204,8 @@ def test_cfg4_shaped_model_step():
     opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9)
     sch = CustomSchedule(d, warmup_steps=20, optimizer=opt)
     lossf = SmoothCrossEntropyLoss(0.1, V, pad)
-    xf = torch.randint(0, V - 1, (1, L + 1), device="cuda")
+    # per-GPU batch 4: cfg4's single-GPU share, the shape bench.py's cfg4 block runs
+    xf = torch.randint(0, V - 1, (4, L + 1), device="cuda")
     xi, yi = xf[:, :-1].to(torch.int32), xf[:, 1:].to(torch.int32)
     losses = []
     for _ in range(8):
@@ -214,3 +216,54 @@ def test_cfg4_shaped_model_step():
         losses.append(loss.item())
     assert all(torch.isfinite(torch.tensor(losses))), losses
     assert losses[-1] < losses[0] - 0.1, losses
+
+
+def _det_bench_shape_run(scale):
+    """one attention backward + vocabulary-projection dW + embedding gradient + CE statistics at bench.py's per-GPU shape (cfg2,
+    batch 64), gradients multiplied by `scale`"""
+    from musicgeneration_amd import ops
+    dev = torch.device("cuda")
+    B, L, d, V = 64, 2048, 512, 337
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.6).to(torch.bfloat16).to(dev)
+    E = (torch.randn(L, 64, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    dctx = (torch.randn(B, L, d, generator=g) * scale).to(torch.bfloat16).to(dev)
+    tok = torch.randint(0, V - 1, (B, L), generator=g, dtype=torch.int32).to(dev)
+    dy = (torch.randn(B * L, 384, generator=g) * scale).to(torch.bfloat16).to(dev)
+    x = torch.randn(B * L, d, generator=g).to(torch.bfloat16).to(dev)
+    ctx, lse = ops.rel_attn_fwd(qkv, E, None)
+
+    def run():
+        dE = torch.zeros(L, 64, device=dev)
+        ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE)
+        dtab = torch.zeros(V, d, device=dev)
+        ops.embed_bwd(tok, dctx, dtab, 0.2, 11)
+        gw, gb = torch.zeros(384, d, device=dev), torch.zeros(384, device=dev)
+        ops.linear_dw(dy, x, gw, gb)
+        torch.cuda.synchronize()
+        return dE, dtab, gw, gb
+    return run
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-6])
+def test_deterministic_mode_at_the_bench_shape(scale):
+    """deterministic-reduction mode at cfg2 / batch 64 -- two runs bit-equal, and against the default (fp32
+    atomics) within 1e-5.  scale = 1e-6 shows what the FIXED 2^-30 quantum costs on tiny gradients: a partial sum of magnitude m
+    keeps m * 2^30 integer steps, so the bound there is absolute (quantum x number of partials), stated below."""
+    from musicgeneration_amd import ops
+    run = _det_bench_shape_run(scale)
+    plain = run()
+    ops.set_deterministic(True)
+    try:
+        d1, d2 = run(), run()
+    finally:
+        ops.set_deterministic(False)
+    for a, b, p, name, nparts in zip(d1, d2, plain, ("dE", "dtable", "gW", "gb"), (4096, 4096, 512, 512)):
+        assert torch.equal(a, b), name
+        assert torch.isfinite(a).all(), name
+        # |fixed-point - fp32| <= half a quantum per partial sum (nparts bounds the partials that meet in one element) + the
+        # default path's own fp32 summation noise (1e-5 relative)
+        bound = 1e-5 * p.abs().max().item() + 0.5 * 2.0 ** -30 * nparts
+        assert (a - p).abs().max().item() <= bound, (name, (a - p).abs().max().item(), bound)
+        if scale == 1.0:
+            assert _rel(a, p) < 1e-5, (name, _rel(a, p))

@@ -552,3 +552,39 @@ def test_deterministic_mode_kernels_repeat_and_agree_with_the_default():
         assert torch.equal(a, b), name
         assert _relerr(a, p) < 1e-5, (name, _relerr(a, p))
         assert (a - p).abs().max().item() <= 1e-5 * p.abs().max().item() + 1e-8, name
+
+
+def test_deterministic_mode_keeps_a_nan_a_nan():
+    """a NaN / Inf / out-of-range partial has no fixed-point image; in deterministic mode it must poison its destination
+    (fold -> NaN) instead of silently becoming a finite number -- a diverging run has to stay recognisable from its gradients."""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, L, d, V, M = 2, 128, 128, 50, 2048
+    tok = torch.randint(0, V, (B, L), generator=g, dtype=torch.int32)
+    tok[0, 3] = 7
+    dout = torch.randn(B, L, d, generator=g).to(torch.bfloat16)
+    dout[0, 3, 17] = float("nan")                    # -> dtable[7, 17]
+    dout[1, 9, 40] = float("inf")                    # -> dtable[tok[1, 9], 40]
+    dy = torch.randn(M, 384, generator=g).to(torch.bfloat16)
+    x = torch.randn(M, 128, generator=g).to(torch.bfloat16)
+    dy[100, 5] = float("nan")                        # -> gW[5, :], gb[5]
+    logits = (torch.randn(B * L, V, generator=g) * 3).to(torch.bfloat16)
+    logits[11, 3] = float("nan")                     # -> the loss statistic
+    tgt = torch.randint(0, V - 1, (B * L,), generator=g, dtype=torch.int32)
+    ops.set_deterministic(True)
+    try:
+        dtab = torch.zeros(V, d, device=dev)
+        ops.embed_bwd(tok.to(dev), dout.to(dev), dtab, 0.0, 5)
+        gw, gb = torch.zeros(384, 128, device=dev), torch.zeros(384, device=dev)
+        ops.linear_dw(dy.to(dev), x.to(dev), gw, gb)
+        stats, _, _ = ops.smooth_ce_fwd(logits.to(dev), tgt.to(dev), V, 0.1, V - 1)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(False)
+    dtab, gw, gb, stats = dtab.cpu(), gw.cpu(), gb.cpu(), stats.cpu()
+    assert torch.isnan(dtab[7, 17]) and torch.isnan(dtab[tok[1, 9], 40])
+    assert torch.isfinite(dtab).sum().item() == dtab.numel() - 2          # nothing else was touched
+    assert torch.isnan(gw[5]).all() and torch.isnan(gb[5])
+    assert torch.isfinite(gw[:5]).all() and torch.isfinite(gw[6:]).all() and torch.isfinite(gb[:5]).all() and torch.isfinite(gb[6:]).all()
+    assert torch.isnan(stats[0])                                            # the loss sum

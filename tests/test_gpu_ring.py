@@ -1,5 +1,7 @@
 """The 256 x 256 ring GEMM (linear.hip: linear_ring_kernel) against the 128 x 128 kernels it replaces for the big projections:
-same inputs through both paths in two child processes (the path is chosen once per process, MGX_GEMM_RING), outputs
+same inputs through both paths in two child processes (the path is chosen once per process by MGX_GEMM_RING, a knob that
+exists in EXPERIMENT builds only: the test builds `libmgx_ringab.so` with `_build.py --experiments` and loads it through
+MGX_LIB_PATH; the product library reads no environment variable), outputs
 compared BIT FOR BIT (both accumulate the reduction in the same order), and against an fp32 torch reference.
 The shapes with 300 and 512 tiles give some of the 256 persistent workgroups two tiles: the ring then runs across a
 tile boundary, with the epilogue's stores and the next tile's bias DMA in the in-order queue."""
@@ -60,8 +62,21 @@ np.savez(sys.argv[2], **out)
 '''
 
 
+_VARIANT = None
+
+
+def _variant_lib():
+    """experiment build of the tracked sources (the product's kernels + the A/B knobs), built once per test session"""
+    global _VARIANT
+    if _VARIANT is None:
+        sys.path.insert(0, ROOT)
+        from musicgeneration_amd import _build
+        _VARIANT = _build.build(variant="ringab", experiments=True)
+    return _VARIANT
+
+
 def _run(ring, path):
-    env = dict(os.environ, MGX_GEMM_RING=str(ring))
+    env = dict(os.environ, MGX_GEMM_RING=str(ring), MGX_LIB_PATH=_variant_lib())
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, path], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     return np.load(path)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of library builds on the whole training step (GPU box, repo root): bench.py once per library and round, interleaved.
 #   bash tools/ab_bench.sh "base product" [rounds=2] [extra bench.py args]
-LIBS=${1:?names}; R=${2:-2}; shift 2
+LIBS=${1:?names}; shift; R=${1:-2}; [ $# -gt 0 ] && shift
 for r in $(seq $R); do
   for n in $LIBS; do
     if [ $n = product ]; then L=musicgeneration_amd/libmgx.so; else L=musicgeneration_amd/libmgx_$n.so; fi
