@@ -42,6 +42,7 @@ class DataParallel:
         self._pending: List[str] = []
         # per-bucket issue -> complete times (measure_overlap): name -> list of (issue event, done event) [nccl] or seconds [gloo]
         self._bucket_t: Dict[str, List] = {}
+        self._host_t0: Dict[int, tuple] = {}
         self._mstream = None              # side stream that waits for each collective and records its completion (nccl only)
         model._dp = self
         if self.world > 1 or self.force:
@@ -78,8 +79,8 @@ class DataParallel:
         for bname, lo, hi in st.buckets:
             if bname == name:
                 t = st.grad[lo:hi]
-                timed = self.measure_overlap and t.is_cuda
-                nccl = timed and dist.get_backend(self.pg) == "nccl"
+                timed = self.measure_overlap
+                nccl = timed and t.is_cuda and dist.get_backend(self.pg) == "nccl"
                 if nccl:
                     ev0 = torch.cuda.Event(enable_timing=True)
                     ev0.record()                           # compute stream: the moment the bucket's gradients are complete
@@ -97,7 +98,7 @@ class DataParallel:
                         ev1.record()
                     self._bucket_t.setdefault(name, []).append((ev0, ev1))
                 elif timed:
-                    w._mgx_t0, w._mgx_name = t0, name       # gloo: host clock, closed in wait_all (wait() blocks the host there)
+                    self._host_t0[id(w)] = (name, t0)       # gloo: host clock, closed in wait_all (wait() blocks the host there)
                 self._works.append(w)
                 self.bytes_reduced += t.numel() * 4
                 return
@@ -118,9 +119,10 @@ class DataParallel:
         self._pending.clear()
         for w in self._works:
             w.wait()
-            if hasattr(w, "_mgx_t0"):
+            if id(w) in self._host_t0:
                 import time
-                self._bucket_t.setdefault(w._mgx_name, []).append(time.perf_counter() - w._mgx_t0)
+                name, t0 = self._host_t0.pop(id(w))
+                self._bucket_t.setdefault(name, []).append(time.perf_counter() - t0)
         self._works.clear()
         if ev is not None:
             ev[1].record()

@@ -98,12 +98,16 @@ def _worker(rank, world, port, q):
         # no-overlap mode (bench.py --no-overlap): buckets are only noted as they become ready, the all-reduces are issued in
         # wait_all(); the result is the same sum
         dp.overlap = False
+        dp.measure_overlap = True                          # per-bucket issue -> complete times (host clock with gloo)
         st.grad.copy_(grads(mine))
         dp.bucket_ready("b"); dp.bucket_ready("a")
         assert torch.equal(st.grad, grads(mine)) and not dp._works          # nothing issued yet
         dp.wait_all()
         assert (st.grad * dp.grad_scale - ref).abs().max().item() / ref.abs().max().item() < 1e-5
         assert dp.bytes_reduced == 8 * n and not dp._pending
+        bms = dp.bucket_ms()
+        assert set(bms) == {"a", "b"} and all(v >= 0 for v in bms.values()) and dp.bucket_ms() is None
+        dp.measure_overlap = False
         dp.overlap = True
         with pytest.raises(KeyError):
             dp.bucket_ready("nope")
