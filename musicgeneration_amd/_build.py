@@ -22,17 +22,17 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgx.so")
-SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_bwd.hip", "linear.hip", "decode.hip", "gru_train.hip"]
+SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_bwd.hip", "rel_attn_dkv64.hip", "linear.hip", "decode.hip", "gru_train.hip"]
 EXPERIMENT_DIR = os.path.join(ROOT, "tools", "experiments")
-EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip", "rel_attn_bwd64.hip"]      # --experiments builds only
+EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip"]      # --experiments builds only
 # per-file flags.  The 64-rows-per-wave attention kernels run one wave per SIMD with the whole 512-entry register file:
 # MFMA results that VALU code reads (scores) must stay in arch VGPRs (with more than 256 registers available hipcc otherwise
 # gives every MFMA an AGPR destination and copies each result out), and the SLP vectoriser must not pair the two blocks'
 # row sums into v_pk_add_f32 (slower than two v_add_f32 beside MFMAs).
 _W64 = ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]
 EXTRA_FLAGS = {"rel_attn_fwd2.hip": _W64,
-               # the 64-key dK/dV kernel: accumulators in AGPRs through inline-asm MFMAs, every other MFMA the builtin in VGPR form
-               "rel_attn_bwd64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-DMGX_K64_ASMACC=1"]}
+               # the 64-key dK/dV kernel (HIP steps): accumulators in AGPRs through inline-asm MFMAs, every other MFMA the builtin in VGPR form
+               "rel_attn_dkv64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:

@@ -1,0 +1,764 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled gfx950 main loop of the 64-keys-per-wave dK/dV kernel (rel_attn_dkv64.hip).
+
+    python musicgeneration_amd/csrc/gen_dkv_asm.py            -> musicgeneration_amd/csrc/rel_attn_dkv64_loop.inc
+
+The kernel's prologue, its diagonal (masked) steps and its epilogue stay HIP; the steady-state steps -- every query tile
+t >= 4 of an unpadded key block -- are ONE `asm volatile` block emitted by this script: a fixed register map, every MFMA
+followed by the VALU / LDS / VMEM instructions assigned to its shadow, counted waits, and the hazards hipcc does not pad
+inside an asm statement checked (and padded) here.  What a step computes, and the layouts, are those of rel_attn_bwd.hip
+(dkv_kernel) / tools/experiments/rel_attn_bwd64.hip; results are bit-identical to both.
+
+Structure of one iteration n (query tile n against the wave's key tiles J, J+1 = sub-tiles 0, 1), 44 MFMAs:
+    A  1-16   S0, S1 (c_u += q k_u^T on top of the skewed Q.Er^T term), dP0, dP1 (dp_u = -delta + dO v_u^T)      [tile n]
+    B  17-28  Q.Er^T chunk products t2, t1, t0 of tile n+1                                                         [tile n+1]
+    C  29-36  dV0 += dO^T P0, dK0 += q^T dS0                                                                       [tile n]
+    D  37-44  dV1, dK1                                                                                             [tile n]
+In the shadows: the transposed q / dO fragments and the statistics of tile n (LDS), barrier, DMA of tile n+2, fragments
+of tile n+1, exponentials / dS / bf16 packs of tile n, the E chunk of tile n+2 (global), merge + lane-permutation skew of
+tile n+1, the four dS stores of tile n.  One barrier per iteration; two LDS buffers; E chunks rotate through three AGPR
+slots, so the body exists in 6 variants (buffer parity x E rotation).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+# ---------------------------------------------------------------------------------------------------------------------
+# register map
+# ---------------------------------------------------------------------------------------------------------------------
+V_L16 = 16
+V_AQ = 17            # ..20  q row-fragment addresses (ks = 0..3), LDS buffer 0 of image QR
+V_ATR = 21           # transposed-fragment base address (image QR, buffer 0)
+V_AST = 22           # statistics address (lds0 + OFF_ST + this wave's 256-byte block + 16 hh), buffer 0
+V_QOFF = 23          # ..24  DMA source offsets of q (two 1 KB pieces)
+V_OOFF = 25          # ..26  ... of dO
+V_STOFF = 27         # ... of the statistics
+V_KOFF = 28          # K / V fragment offset (prologue only)
+V_TMP = 238          # ..245 temporaries (prologue)
+V_RD = 30            # ..45  ds_bpermute source-lane addresses of the skew
+V_QA = 46            # ..61  q row fragments (4 x 4)
+V_OF = 62            # ..77  dO row fragments
+V_T = (78, 126)      # two sets of 48: t0 | t1 | t2 chunk products; c0 = t0, c1 = t2 after the skew, nl in t1
+V_DP = 174           # ..205 dp0 | dp1
+V_TR = 206           # ..237 transposed fragments: dO (ss, ct) 4 regs each, then q
+V_FIRST, V_LAST = 16, 245
+
+A_KF = 144           # kf[u][ks] at A_KF + 4 (4u + ks)
+A_VF = 176
+A_E = 208            # E slot s, ks at A_E + 4 (4s + ks)
+A_FIRST, A_LAST = 144, 255
+
+S_MASK = 36          # 16 pairs: lanes with key <= query for accumulator register r
+S_EFA, S_QB, S_OB, S_STB, S_DSB, S_KVB = 68, 70, 72, 74, 76, 78      # 64-bit pointers (even-aligned pairs)
+S_N, S_NT, S_WK, S_I, S_DSOFF, S_QSTEP, S_OSTEP, S_LDS, S_NCH, S_KEXP, S_W = 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 98
+S_T = 90             # ..97 temporaries (even: pointer pairs at +2, +4, +6)
+S_DQ, S_DST = 99, 100  # LDS destinations of this wave's DMA pieces (images / statistics), buffer 0
+S_DV = 101           # d * 2 (byte offset of V behind K)
+S_FIRST, S_LAST = 36, 101
+S_ET, S_EP, S_SP = 32, 34, 30   # E-load temporaries (2), E chunk pointer (2), dS store pointer (2): s30..s35
+S_ST = 29
+S_FIRST = 29
+
+OFF_QR, OFF_OR, OFF_ST = 0, 8192, 16384
+ST_BYTES = 512
+
+MFMA_TO_VALU = 13      # wait states between an MFMA and any other instruction touching its result (hipcc pads s_nop 11)
+VALU_TO_MFMA = 3       # a VALU-written register as an MFMA operand
+TRANS_TO_VALU = 2
+
+
+def v(i, n=1):
+    return f"v{i}" if n == 1 else f"v[{i}:{i + n - 1}]"
+
+
+def a(i, n=1):
+    return f"a{i}" if n == 1 else f"a[{i}:{i + n - 1}]"
+
+
+def s(i, n=1):
+    return f"s{i}" if n == 1 else f"s[{i}:{i + n - 1}]"
+
+
+def regs(prefix, i, n=1):
+    return {f"{prefix}{k}" for k in range(i, i + n)}
+
+
+class Gen:
+    def __init__(self):
+        self.out = []                 # text lines
+        self.pos = 0                  # wait-state clock (instructions issued; s_nop N counts N+1)
+        self.lgkm = []                # outstanding LDS operations: sets of destination registers, oldest first
+        self.vm = []                  # every VMEM operation issued so far: (tag, destination registers)
+        self.vm_done = 0              # operations [0, vm_done) are known complete
+        self.mfma_d = {}              # register -> clock of the last MFMA that wrote it
+        self.mfma_c = {}              # register -> clock of the last MFMA that read it as srcC / A / B (WAR)
+        self.valu_w = {}              # register -> clock of the last VALU write
+        self.trans_w = {}             # register -> clock of the last transcendental write
+        self.store_r = {}             # register -> clock of the last VMEM store that reads it
+        self.nops = 0
+        self.m0_w = None
+        self.stats = {}
+
+    # ---- low level -------------------------------------------------------------------------------------------------
+    def raw(self, text, ws=1):
+        self.out.append(text)
+        self.pos += ws
+
+    def comment(self, text):
+        self.out.append(f"; {text}")
+
+    def nop(self, states):
+        while states > 0:
+            k = min(states, 8)
+            self.raw(f"s_nop {k - 1}", k)
+            self.nops += k
+            states -= k
+
+    def _wait_lgkm(self, touched):
+        idx = -1
+        for i, d in enumerate(self.lgkm):
+            if d & touched:
+                idx = i
+        if idx >= 0:
+            k = len(self.lgkm) - 1 - idx
+            self.raw(f"s_waitcnt lgkmcnt({min(k, 15)})")
+            self.lgkm = self.lgkm[len(self.lgkm) - min(k, 15):] if k > 0 else []
+
+    def _wait_vm(self, touched):
+        idx = -1
+        for i in range(self.vm_done, len(self.vm)):
+            if self.vm[i][1] & touched:
+                idx = i
+        if idx >= 0:
+            self.wait_vm_index(idx)
+
+    def wait_vm_index(self, idx):
+        k = len(self.vm) - 1 - idx
+        self.raw(f"s_waitcnt vmcnt({min(k, 63)})")
+        self.vm_done = max(self.vm_done, idx + 1)
+
+    def wait_vm_tag(self, tag):
+        idx = max((i for i in range(len(self.vm)) if self.vm[i][0] == tag), default=-1)
+        if idx >= self.vm_done:
+            self.wait_vm_index(idx)
+
+    def drain(self):
+        self.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        self.lgkm = []
+        self.vm_done = len(self.vm)
+
+    def _hazards(self, kind, reads, writes):
+        need = 0
+        touched = reads | writes
+        for r in touched:
+            if r in self.mfma_d and kind != "mfma_acc_same":
+                need = max(need, self.mfma_d[r] + MFMA_TO_VALU - self.pos)
+        if kind.startswith("mfma"):
+            for r in reads:
+                if r in self.valu_w:
+                    need = max(need, self.valu_w[r] + VALU_TO_MFMA - self.pos)
+        else:
+            for r in writes:
+                if r in self.mfma_c:                       # WAR on an operand of an MFMA in flight
+                    need = max(need, self.mfma_c[r] + 6 - self.pos)
+                if r in self.store_r:
+                    need = max(need, self.store_r[r] + 3 - self.pos)
+        if kind == "valu":
+            for r in reads:
+                if r in self.trans_w:
+                    need = max(need, self.trans_w[r] + TRANS_TO_VALU - self.pos)
+        if "m0" in reads and kind == "vmem" and self.m0_w is not None:
+            need = max(need, self.m0_w + 2 - self.pos)      # SALU write of M0 -> LDS-DMA: one wait state
+        if need > 0:
+            self.nop(need)
+
+    def emit(self, kind, text, reads=(), writes=()):
+        reads, writes = set(reads), set(writes)
+        self._wait_lgkm(reads | writes)
+        self._wait_vm(reads | writes)
+        self._hazards(kind, reads, writes)
+        self.raw(text)
+        self.stats[kind] = self.stats.get(kind, 0) + 1
+        at = self.pos - 1
+        if kind.startswith("mfma"):
+            for r in writes:
+                self.mfma_d[r] = at
+            for r in reads:
+                self.mfma_c[r] = at
+        else:
+            for r in writes:
+                self.mfma_d.pop(r, None)
+                if kind in ("valu", "trans"):
+                    self.valu_w[r] = at
+                if kind == "trans":
+                    self.trans_w[r] = at
+                elif r in self.trans_w:
+                    del self.trans_w[r]
+        if "m0" in writes:
+            self.m0_w = at
+        if kind == "lds":
+            self.lgkm.append(writes)
+        if kind == "store":
+            for r in reads:
+                self.store_r[r] = at
+
+    # ---- instructions ----------------------------------------------------------------------------------------------
+    def mfma(self, d, a_, b_, c=None, dn=16):
+        """d (+)= a_ * b_; registers given as (prefix, index)"""
+        dr = regs(d[0], d[1], dn)
+        ar, br = regs(a_[0], a_[1], 4), regs(b_[0], b_[1], 4)
+        dt = f"{d[0]}[{d[1]}:{d[1] + dn - 1}]"
+        at = f"{a_[0]}[{a_[1]}:{a_[1] + 3}]"
+        bt = f"{b_[0]}[{b_[1]}:{b_[1] + 3}]"
+        if c == 0:
+            self.emit("mfma", f"v_mfma_f32_32x32x16_bf16 {dt}, {at}, {bt}, 0", ar | br, dr)
+        else:
+            # accumulate chain on the same registers: no wait states needed after the previous MFMA of the chain
+            same = all(r in self.mfma_d for r in dr)
+            self.emit("mfma_acc_same" if same else "mfma", f"v_mfma_f32_32x32x16_bf16 {dt}, {at}, {bt}, {dt}", ar | br | dr, dr)
+
+    def mfma_op(self, opnd, a_, b_):
+        """accumulator given as an asm operand (%N, compiler-allocated AGPRs): never touched by anything else in the block"""
+        ar, br = regs(a_[0], a_[1], 4), regs(b_[0], b_[1], 4)
+        at = f"{a_[0]}[{a_[1]}:{a_[1] + 3}]"
+        bt = f"{b_[0]}[{b_[1]}:{b_[1] + 3}]"
+        self.emit("mfma", f"v_mfma_f32_32x32x16_bf16 {opnd}, {at}, {bt}, {opnd}", ar | br, set())
+
+    def valu(self, text, reads, writes, trans=False):
+        self.emit("trans" if trans else "valu", text, reads, writes)
+
+    def salu(self, text, reads=(), writes=()):
+        self.emit("salu", text, reads, writes)
+
+    def ds_read(self, text, addr, dst):
+        self.emit("lds", text, addr, dst)
+
+    def vmem_load(self, text, tag, reads, dst):
+        self.emit("vmem", text, reads, set())
+        self.vm.append((tag, set(dst)))
+
+    def vmem_dma(self, text, tag, reads):
+        self.emit("vmem", text, reads, set())
+        self.vm.append((tag, set()))
+
+    def vmem_store(self, text, tag, reads):
+        self.emit("store", text, reads, set())
+        self.vm.append((tag, set()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pieces of a step
+# ---------------------------------------------------------------------------------------------------------------------
+def crow(r, hh=0):
+    return (r & 3) + 8 * (r >> 2) + 4 * hh
+
+
+def salu_items(g, ops):
+    """one item per SALU instruction, except that an s_addc_u32 stays glued to the s_add_u32 whose carry (SCC) it consumes:
+    the scheduler interleaves items of different chains, and nearly every SALU instruction rewrites SCC"""
+    out = []
+    i = 0
+    while i < len(ops):
+        grp = [ops[i]]
+        while i + 1 < len(ops) and ops[i + 1][0].startswith("s_addc_u32"):
+            i += 1
+            grp.append(ops[i])
+        out.append(lambda grp=grp: [g.salu(*o) for o in grp])
+        i += 1
+    return out
+
+
+class Step:
+    """instruction groups of iteration n in variant `b` (n = 4 + b mod 6)"""
+
+    def __init__(self, g: Gen, b: int):
+        self.g = g
+        n = 4 + b
+        self.cur = n & 1                       # LDS buffer of tile n; tile n+1 in cur ^ 1; DMA of tile n+2 -> cur
+        self.T = V_T[n & 1]                    # c0 / nl / c1 of tile n
+        self.Tn = V_T[(n + 1) & 1]             # chunk products of tile n+1
+        self.slot_t0 = (n + 1) % 3             # E slots of the products of tile n+1
+        self.slot_t1 = n % 3
+        self.slot_t2 = (n + 2) % 3             # ... and the slot the chunk of tile n+2 is loaded into, once t2 has been issued
+        self.tag = f"it{b}"
+
+    # -- A: S and dP of tile n ------------------------------------------------------------------------------------
+    def mfma_S(self, u):
+        c = self.T + (0 if u == 0 else 32)
+        return [lambda ks=ks: self.g.mfma(("v", c), ("v", V_QA + 4 * ks), ("a", A_KF + 4 * (4 * u + ks))) for ks in range(4)]
+
+    def mfma_dP(self, u):
+        d = V_DP + 16 * u
+        return [lambda ks=ks: self.g.mfma(("v", d), ("v", V_OF + 4 * ks), ("a", A_VF + 4 * (4 * u + ks))) for ks in range(4)]
+
+    # -- B: chunk products of tile n+1 ----------------------------------------------------------------------------
+    def mfma_QE(self, k):
+        """k = 0: t0 (hi chunk of sub-tile 0), 1: t1, 2: t2"""
+        d = self.Tn + 16 * k
+        slot = (self.slot_t0, self.slot_t1, self.slot_t2)[k]
+        return [lambda ks=ks: self.g.mfma(("v", d), ("v", V_QA + 4 * ks), ("a", A_E + 4 * (4 * slot + ks)), c=0 if ks == 0 else None)
+                for ks in range(4)]
+
+    # -- C / D: dV, dK of tile n -------------------------------------------------------------------------------------
+    def mfma_dVdK(self, u):
+        c = self.T + (0 if u == 0 else 32)       # pf_u[ss] = c_u[8ss .. 8ss+3]
+        d = V_DP + 16 * u                       # df_u[ss]
+        out = []
+        for ss in range(2):
+            for ct in range(2):
+                out.append(lambda ss=ss, ct=ct: self.g.mfma_op(f"%{4 * u + 2 + ct}", ("v", V_TR + 4 * (2 * ss + ct)), ("v", c + 8 * ss)))      # dv[u][ct]
+            for ct in range(2):
+                out.append(lambda ss=ss, ct=ct: self.g.mfma_op(f"%{4 * u + ct}", ("v", V_TR + 16 + 4 * (2 * ss + ct)), ("v", d + 8 * ss)))   # dk[u][ct]
+        return out
+
+    # -- LDS reads of tile n (before the barrier) ---------------------------------------------------------------------
+    def rd_tr(self):
+        """transposed fragments of dO (V_TR + 0..15) and q (V_TR + 16..31) of tile n: X[kappa][32 ct + lane&31]"""
+        out = []
+        for img, base in ((OFF_OR, V_TR), (OFF_QR, V_TR + 16)):
+            for ss in range(2):
+                for ct in range(2):
+                    for jq in range(2):
+                        dst = base + 4 * (2 * ss + ct) + 2 * jq
+                        off = img + self.cur * 4096 + (16 * ss + 8 * jq) * 128 + ((ct ^ jq) << 6)
+                        out.append(lambda dst=dst, off=off: self.g.ds_read(f"ds_read_b64_tr_b16 {v(dst, 2)}, {v(V_ATR)} offset:{off}",
+                                                                           regs("v", V_ATR), regs("v", dst, 2)))
+        return out
+
+    def rd_nd(self, u, nxt=False):
+        """-delta of the accumulator rows: initial value of dp_u (nxt: of tile n+1, from the other buffer)"""
+        out = []
+        buf = self.cur ^ 1 if nxt else self.cur
+        for g4 in range(4):
+            dst = V_DP + 16 * u + 4 * g4
+            off = buf * ST_BYTES + 128 + 32 * g4         # (V_AST includes OFF_ST)
+            out.append(lambda dst=dst, off=off: self.g.ds_read(f"ds_read_b128 {v(dst, 4)}, {v(V_AST)} offset:{off}", regs("v", V_AST), regs("v", dst, 4)))
+        return out
+
+    def rd_nl(self):
+        """-lse log2(e) of the accumulator rows -> the t1 registers of this tile's set (free since the merge)"""
+        out = []
+        for g4 in range(4):
+            dst = self.T + 16 + 4 * g4
+            off = self.cur * ST_BYTES + 32 * g4
+            out.append(lambda dst=dst, off=off: self.g.ds_read(f"ds_read_b128 {v(dst, 4)}, {v(V_AST)} offset:{off}", regs("v", V_AST), regs("v", dst, 4)))
+        return out
+
+    # -- barrier, DMA of tile n+2, row fragments of tile n+1 ---------------------------------------------------------------
+    def barrier(self, dma_tag):
+        g = self.g
+
+        def f():
+            g.raw("s_waitcnt lgkmcnt(0)")                # every LDS read of tile n has returned
+            g.lgkm = []
+            g.wait_vm_tag(dma_tag)                         # this wave's pieces of tile n+1 have landed
+            g.raw("s_barrier")
+        return [f]
+
+    def dma_addr(self):
+        """source pointers of tile min(n + 2, nT - 1): q -> S_T+2, dO -> S_T+4, statistics -> S_T+6 (one SALU instruction per item)"""
+        g = self.g
+        ops = [(f"s_add_u32 {s(S_T)}, {s(S_N)}, 2", regs("s", S_N), regs("s", S_T)),
+               (f"s_sub_u32 {s(S_T + 1)}, {s(S_NT)}, 1", regs("s", S_NT), regs("s", S_T + 1)),
+               (f"s_min_u32 {s(S_T)}, {s(S_T)}, {s(S_T + 1)}", regs("s", S_T, 2), regs("s", S_T)),
+               (f"s_mul_i32 {s(S_T + 1)}, {s(S_T)}, {s(S_QSTEP)}", regs("s", S_T) | regs("s", S_QSTEP), regs("s", S_T + 1)),
+               (f"s_add_u32 {s(S_T + 2)}, {s(S_QB)}, {s(S_T + 1)}", regs("s", S_QB) | regs("s", S_T + 1), regs("s", S_T + 2)),
+               (f"s_addc_u32 {s(S_T + 3)}, {s(S_QB + 1)}, 0", regs("s", S_QB + 1), regs("s", S_T + 3)),
+               (f"s_mul_i32 {s(S_T + 1)}, {s(S_T)}, {s(S_OSTEP)}", regs("s", S_T) | regs("s", S_OSTEP), regs("s", S_T + 1)),
+               (f"s_add_u32 {s(S_T + 4)}, {s(S_OB)}, {s(S_T + 1)}", regs("s", S_OB) | regs("s", S_T + 1), regs("s", S_T + 4)),
+               (f"s_addc_u32 {s(S_T + 5)}, {s(S_OB + 1)}, 0", regs("s", S_OB + 1), regs("s", S_T + 5)),
+               (f"s_lshl_b32 {s(S_T + 1)}, {s(S_T)}, 7", regs("s", S_T), regs("s", S_T + 1)),
+               (f"s_add_u32 {s(S_T + 6)}, {s(S_STB)}, {s(S_T + 1)}", regs("s", S_STB) | regs("s", S_T + 1), regs("s", S_T + 6)),
+               (f"s_addc_u32 {s(S_T + 7)}, {s(S_STB + 1)}, 0", regs("s", S_STB + 1), regs("s", S_T + 7))]
+        return salu_items(g, ops)
+
+    def dma(self, tag):
+        """tile min(n + 2, nT - 1) -> buffer cur (pointers from dma_addr)"""
+        g = self.g
+        out = []
+        for i in range(2):
+            for img, ptr, voff in ((OFF_QR, S_T + 2, V_QOFF + i), (OFF_OR, S_T + 4, V_OOFF + i)):
+                def piece(i=i, img=img, ptr=ptr, voff=voff):
+                    g.salu(f"s_add_u32 m0, {s(S_DQ)}, {img + self.cur * 4096 + 2048 * i}", regs("s", S_DQ), {"m0"})
+                    g.vmem_dma(f"global_load_lds_dwordx4 {v(voff)}, {s(ptr, 2)}", tag, regs("v", voff) | regs("s", ptr, 2) | {"m0"})
+                out.append(piece)
+
+        def stat():
+            g.salu(f"s_add_u32 m0, {s(S_DST)}, {self.cur * ST_BYTES}", regs("s", S_DST), {"m0"})
+            g.vmem_dma(f"global_load_lds_dword {v(V_STOFF)}, {s(S_T + 6, 2)}", tag, regs("v", V_STOFF) | regs("s", S_T + 6, 2) | {"m0"})
+        out.append(stat)
+        return out
+
+    def rd_rows(self, which):
+        """row fragments of tile n+1 (buffer cur ^ 1): q -> V_QA, dO -> V_OF"""
+        img, base = (OFF_QR, V_QA) if which == "q" else (OFF_OR, V_OF)
+        out = []
+        for ks in range(4):
+            off = img + (self.cur ^ 1) * 4096
+            out.append(lambda ks=ks, off=off: self.g.ds_read(f"ds_read_b128 {v(base + 4 * ks, 4)}, {v(V_AQ + ks)} offset:{off}",
+                                                              regs("v", V_AQ + ks), regs("v", base + 4 * ks, 4)))
+        return out
+
+    # -- exponentials, dS, packs of tile n ---------------------------------------------------------------------------------
+    def soft_exp(self, u):
+        c, nl = self.T + (0 if u == 0 else 32), self.T + 16
+        out = []
+        for r in range(16):
+            out.append(lambda r=r: self.g.valu(f"v_fma_f32 {v(c + r)}, {v(c + r)}, {s(S_KEXP)}, {v(nl + r)}", regs("v", c + r) | regs("v", nl + r), regs("v", c + r)))
+            out.append(lambda r=r: self.g.valu(f"v_exp_f32_e32 {v(c + r)}, {v(c + r)}", regs("v", c + r), regs("v", c + r), trans=True))
+        return out
+
+    def soft_ds(self, u):
+        c, d = self.T + (0 if u == 0 else 32), V_DP + 16 * u
+        out = []
+        for r in range(16):
+            out.append(lambda r=r: self.g.valu(f"v_mul_f32_e32 {v(d + r)}, {v(c + r)}, {v(d + r)}", regs("v", c + r) | regs("v", d + r), regs("v", d + r)))
+        # packs: registers 8ss + 2j, 8ss + 2j + 1 -> 8ss + j (ascending j: a destination has been consumed by then)
+        for base in (d, c):                       # dS first: its store and its product come first
+            for ss in range(2):
+                for j in range(4):
+                    lo, hi, dst = base + 8 * ss + 2 * j, base + 8 * ss + 2 * j + 1, base + 8 * ss + j
+                    out.append(lambda lo=lo, hi=hi, dst=dst: self.g.valu(f"v_cvt_pk_bf16_f32 {v(dst)}, {v(lo)}, {v(hi)}",
+                                                                         regs("v", lo) | regs("v", hi), regs("v", dst)))
+        return out
+
+    # -- E chunk of tile n+2 -------------------------------------------------------------------------------------------------
+    def ldE_addr(self):
+        """pointer of chunk min(n + 2 - wk, nchunk - 1) of the fragment-ordered E copy -> S_EP"""
+        g = self.g
+        ops = [(f"s_add_u32 {s(S_ET)}, {s(S_N)}, 2", regs("s", S_N), regs("s", S_ET)),
+               (f"s_sub_u32 {s(S_ET)}, {s(S_ET)}, {s(S_WK)}", regs("s", S_ET) | regs("s", S_WK), regs("s", S_ET)),
+               (f"s_sub_u32 {s(S_ET + 1)}, {s(S_NCH)}, 1", regs("s", S_NCH), regs("s", S_ET + 1)),
+               (f"s_min_u32 {s(S_ET)}, {s(S_ET)}, {s(S_ET + 1)}", regs("s", S_ET, 2), regs("s", S_ET)),
+               (f"s_lshl_b32 {s(S_ET)}, {s(S_ET)}, 12", regs("s", S_ET), regs("s", S_ET)),
+               (f"s_add_u32 {s(S_EP)}, {s(S_EFA)}, {s(S_ET)}", regs("s", S_EFA) | regs("s", S_ET), regs("s", S_EP)),
+               (f"s_addc_u32 {s(S_EP + 1)}, {s(S_EFA + 1)}, 0", regs("s", S_EFA + 1), regs("s", S_EP + 1))]
+        return salu_items(g, ops)
+
+    def ld_E(self, tag):
+        g = self.g
+        out = []
+        for ks in range(4):
+            dst = A_E + 4 * (4 * self.slot_t2 + ks)
+            out.append(lambda ks=ks, dst=dst: g.vmem_load(f"global_load_dwordx4 {a(dst, 4)}, {v(V_L16)}, {s(S_EP, 2)} offset:{1024 * ks}", tag,
+                                                          regs("v", V_L16) | regs("s", S_EP, 2), regs("a", dst, 4)))
+        return out
+
+    # -- merge + skew of tile n+1 ------------------------------------------------------------------------------------------
+    def merge(self, u):
+        """sub-tile 0: lanes with key <= query take t0, the others t1 -> t0;  sub-tile 1: t1 / t2 -> t2"""
+        t0, t1, t2 = self.Tn, self.Tn + 16, self.Tn + 32
+        hi, lo, dst = (t0, t1, t0) if u == 0 else (t1, t2, t2)
+        return [lambda r=r: self.g.valu(f"v_cndmask_b32_e64 {v(dst + r)}, {v(lo + r)}, {v(hi + r)}, {s(S_MASK + 2 * r, 2)}",
+                                        regs("v", lo + r) | regs("v", hi + r) | regs("s", S_MASK + 2 * r, 2), regs("v", dst + r)) for r in range(16)]
+
+    def skew(self, u):
+        c = self.Tn + (0 if u == 0 else 32)
+        return [lambda r=r: self.g.emit("lds", f"ds_bpermute_b32 {v(c + r)}, {v(V_RD + r)}, {v(c + r)}", regs("v", V_RD + r) | regs("v", c + r), regs("v", c + r))
+                for r in range(16)]
+
+    # -- dS stores of tile n -----------------------------------------------------------------------------------------------
+    def st_addr(self):
+        """pointer of this step's dS tiles -> S_SP; then the offset of the next tile row: I += 1, offset += I << 11"""
+        g = self.g
+        ops = [(f"s_add_u32 {s(S_SP)}, {s(S_DSB)}, {s(S_DSOFF)}", regs("s", S_DSB) | regs("s", S_DSOFF), regs("s", S_SP)),
+               (f"s_addc_u32 {s(S_SP + 1)}, {s(S_DSB + 1)}, 0", regs("s", S_DSB + 1), regs("s", S_SP + 1)),
+               (f"s_add_u32 {s(S_I)}, {s(S_I)}, 1", regs("s", S_I), regs("s", S_I)),
+               (f"s_lshl_b32 {s(S_ST)}, {s(S_I)}, 11", regs("s", S_I), regs("s", S_ST)),
+               (f"s_add_u32 {s(S_DSOFF)}, {s(S_DSOFF)}, {s(S_ST)}", regs("s", S_DSOFF) | regs("s", S_ST), regs("s", S_DSOFF))]
+        return salu_items(g, ops)
+
+    def st_dS(self, tag):
+        g = self.g
+        out = []
+        for u in range(2):
+            for ss in range(2):
+                src = V_DP + 16 * u + 8 * ss
+                out.append(lambda u=u, ss=ss, src=src: g.vmem_store(
+                    f"global_store_dwordx4 {v(V_L16)}, {v(src, 4)}, {s(S_SP, 2)} offset:{2048 * u + 1024 * ss} nt", tag,
+                    regs("v", V_L16) | regs("v", src, 4) | regs("s", S_SP, 2)))
+        return out
+
+
+class Item:
+    """one filler (a function that emits one or a few instructions) with its scheduling constraints: it may be placed in the
+    shadow of MFMA `earliest` .. `deadline` (gap g = after MFMA g, before MFMA g+1), after every item in `deps`"""
+
+    def __init__(self, fn, cost, earliest=1, deadline=44, deps=(), pin=None, name=""):
+        self.fn, self.cost, self.earliest, self.deadline, self.deps, self.pin, self.name = fn, cost, earliest, deadline, list(deps), pin, name
+        self.gap = None
+
+
+COST = {"valu": 4, "trans": 8, "lds": 4, "lds128": 6, "salu": 3, "vmem": 8, "sync": 4}
+GAP_BUDGET = 22        # issue cycles of fillers an MFMA (32 cycles, 8 of them its own issue) is asked to hide
+
+
+def chain(items):
+    """items must keep their order"""
+    for x, y in zip(items, items[1:]):
+        y.deps.append(x)
+    return items
+
+
+def try_schedule(items, ngaps, budget):
+    for it in items:
+        it.gap = None
+    table = {g: [] for g in range(1, ngaps + 1)}
+    todo = list(items)
+    over = 0
+    for g in range(1, ngaps + 1):
+        used = 0
+        progress = True
+        while progress:
+            progress = False
+            ready = [it for it in todo if it.earliest <= g and all(d.gap is not None for d in it.deps) and (it.pin is None or it.pin == g)]
+            ready.sort(key=lambda it: (it.deadline, it.earliest))
+            for it in ready:
+                must = it.deadline <= g or it.pin == g
+                if must or used + it.cost <= budget:
+                    it.gap = g
+                    table[g].append(it)
+                    todo.remove(it)
+                    used += it.cost
+                    progress = True
+                    break
+        over = max(over, used - budget)
+    return table, todo, over
+
+
+def schedule(items, ngaps=44):
+    """earliest-deadline-first list scheduling with the smallest uniform per-gap issue budget that places every filler inside its
+    window (the fillers of a step cost more than 44 MFMA shadows hide: spread the excess evenly instead of piling it up)"""
+    budget = GAP_BUDGET
+    while True:
+        table, todo, over = try_schedule(items, ngaps, budget)
+        if not todo and over <= 8:
+            break
+        budget += 1
+        assert budget < 200, f"unschedulable: {[it.name for it in todo][:8]}"
+    late = [it for g in table for it in table[g] if g > it.deadline]
+    assert not late, f"fillers placed after their deadline: {[(it.name, it.gap, it.deadline) for it in late][:8]}"
+    return table, budget
+
+
+def body(g: Gen, b: int, do_cur: bool = True, listing=None):
+    st = Step(g, b)
+    prev_b = (b + 5) % 6
+    g.comment(f"==== iteration variant {b}: buffer {st.cur}, E slots t0/t1/t2 = {st.slot_t0}/{st.slot_t1}/{st.slot_t2}{'' if do_cur else '  (pipeline fill: tile n+1 part only)'} ====")
+    # ---- the MFMA sequence ----
+    none4 = [None] * 4
+    mf = (st.mfma_S(0) + st.mfma_S(1) + st.mfma_dP(0) + st.mfma_dP(1)) if do_cur else none4 * 4
+    mf += st.mfma_QE(0) + st.mfma_QE(1) + st.mfma_QE(2)
+    mf += (st.mfma_dVdK(0) + st.mfma_dVdK(1)) if do_cur else none4 * 4
+    # ---- the fillers ----
+    I = Item
+    items = []
+
+    def add(fns, cost, **kw):
+        out = [I(f, cost, name=kw.get("name", ""), **{k: v_ for k, v_ in kw.items() if k != "name"}) for f in fns]
+        items.extend(out)
+        return out
+
+    tile_n_reads = []
+    if do_cur:
+        nd0 = add(st.rd_nd(0), COST["lds128"], earliest=1, deadline=6, name="nd0")                     # dP0 = MFMA 9
+        nd1 = add(st.rd_nd(1), COST["lds128"], earliest=1, deadline=8, name="nd1")                     # dP1 = MFMA 13
+        nl = add(st.rd_nl(), COST["lds128"], earliest=1, deadline=5, name="nl")
+        tr = add(st.rd_tr(), COST["lds"], earliest=1, deadline=9, name="tr")
+        tile_n_reads = nd0 + nd1 + nl + tr
+    bar = add(st.barrier(f"dma{prev_b}"), COST["sync"], pin=10, deps=tile_n_reads, name="barrier")
+    dma_a = chain(add(st.dma_addr(), COST["salu"], earliest=1, deadline=10, name="dma_addr"))
+    dma = chain(add(st.dma(f"dma{b}"), COST["salu"] + COST["vmem"], earliest=10, deadline=16, deps=bar + dma_a[-1:], name="dma"))
+    rq = add(st.rd_rows("q"), COST["lds128"], earliest=10, deadline=13, deps=bar, name="rows_q")       # S of tile n = MFMAs 1-8
+    ro = add(st.rd_rows("o"), COST["lds128"], earliest=16, deadline=38, deps=bar, name="rows_o")       # dP of tile n = MFMAs 9-16
+    if do_cur:
+        cvds = []
+        for u, (e_c, e_dp, dl) in enumerate(((7, 15, 27), (11, 19, 35))):
+            ex = add(st.soft_exp(u), 0, earliest=e_c, deadline=dl - 4, name=f"exp{u}")
+            for r in range(16):
+                ex[2 * r].cost, ex[2 * r + 1].cost = COST["valu"], COST["trans"]
+                ex[2 * r + 1].deps.append(ex[2 * r])
+            sd = add(st.soft_ds(u), COST["valu"], earliest=max(e_c, e_dp), deadline=dl, name=f"ds{u}")
+            mul, cvd, cvc = sd[:16], sd[16:24], sd[24:32]
+            for r in range(16):
+                mul[r].deps.append(ex[2 * r + 1])
+            for k, (ss, j) in enumerate((ss, j) for ss in range(2) for j in range(4)):
+                cvd[k].deps += [mul[8 * ss + 2 * j], mul[8 * ss + 2 * j + 1], mul[8 * ss + j]] + ([cvd[k - 1]] if j else [])
+                cvc[k].deps += [ex[2 * (8 * ss + 2 * j) + 1], ex[2 * (8 * ss + 2 * j + 1) + 1], mul[8 * ss + j]] + ([cvc[k - 1]] if j else [])
+            cvds.append(cvd)
+        sa = chain(add(st.st_addr(), COST["salu"], earliest=1, deadline=30, name="st_addr"))
+        sts = chain(add(st.st_dS(f"st{b}"), COST["vmem"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
+        for k, it in enumerate(sts):
+            it.deps += cvds[k >> 1][4 * (k & 1): 4 * (k & 1) + 4]
+    ea = chain(add(st.ldE_addr(), COST["salu"], earliest=1, deadline=28, name="ldE_addr"))
+    le = chain(add(st.ld_E(f"e{b}"), COST["vmem"], earliest=28, deadline=40, deps=ea[-1:], name="ld_E"))   # t2 = MFMAs 25-28
+    m0 = add(st.merge(0), COST["valu"], earliest=27, deadline=38, name="merge0")                        # t0, t1 done after MFMA 24
+    m1 = add(st.merge(1), COST["valu"], earliest=31, deadline=42, name="merge1")
+    k0 = add(st.skew(0), COST["lds"], earliest=27, deadline=40, name="skew0")
+    k1 = add(st.skew(1), COST["lds"], earliest=31, deadline=44, name="skew1")
+    for r in range(16):
+        k0[r].deps.append(m0[r])
+        k1[r].deps.append(m1[r])
+    table, budget = schedule(items)
+    g.comment(f"per-gap issue budget {budget}")
+    for gi in range(1, 45):
+        m = mf[gi - 1]
+        if m is not None:
+            m()
+        if listing is not None:
+            listing.append((gi, len(g.out)))
+        for it in table[gi]:
+            it.fn()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# prologue / epilogue
+# ---------------------------------------------------------------------------------------------------------------------
+def prologue(g: Gen):
+    """%8 = LDS address of this wave's parameter block (written by the HIP code just before):
+         dwords 0..23: EfA, q_base, o_base, st_base, ds_col, kv_base (64-bit each) | n0 (= 4), nT, wk, I0, q_step, o_step, lds0, nchunk,
+                       w, d*2, 0, 0
+         + 256 + 256 k + 4 lane: lane table k = aq0..3, atr, ast, qoff0..1, ooff0..1, stoff, koff"""
+    g.comment("==== prologue ====")
+    g.drain()
+    T = V_T[0]                                   # 24 temporaries for the scalar block
+    g.valu(f"v_mbcnt_lo_u32_b32 {v(V_TMP)}, -1, 0", set(), regs("v", V_TMP))
+    g.valu(f"v_mbcnt_hi_u32_b32 {v(V_TMP)}, -1, {v(V_TMP)}", regs("v", V_TMP), regs("v", V_TMP))          # lane
+    g.valu(f"v_lshlrev_b32_e32 {v(V_L16)}, 4, {v(V_TMP)}", regs("v", V_TMP), regs("v", V_L16))
+    g.valu(f"v_mov_b32_e32 {v(V_TMP + 1)}, %8", set(), regs("v", V_TMP + 1))
+    for k in range(6):
+        g.ds_read(f"ds_read_b128 {v(T + 4 * k, 4)}, {v(V_TMP + 1)} offset:{16 * k}", regs("v", V_TMP + 1), regs("v", T + 4 * k, 4))
+    g.valu(f"v_lshl_add_u32 {v(V_TMP + 2)}, {v(V_TMP)}, 2, {v(V_TMP + 1)}", regs("v", V_TMP, 2), regs("v", V_TMP + 2))
+    lane_tab = [V_AQ, V_AQ + 1, V_AQ + 2, V_AQ + 3, V_ATR, V_AST, V_QOFF, V_QOFF + 1, V_OOFF, V_OOFF + 1, V_STOFF, V_KOFF]
+    for k, dst in enumerate(lane_tab):
+        g.ds_read(f"ds_read_b32 {v(dst)}, {v(V_TMP + 2)} offset:{256 + 256 * k}", regs("v", V_TMP + 2), regs("v", dst))
+    sc = [S_EFA, S_EFA + 1, S_QB, S_QB + 1, S_OB, S_OB + 1, S_STB, S_STB + 1, S_DSB, S_DSB + 1, S_KVB, S_KVB + 1,
+          S_N, S_NT, S_WK, S_I, S_QSTEP, S_OSTEP, S_LDS, S_NCH, S_W, S_DV]
+    g.raw("s_waitcnt lgkmcnt(0)")
+    g.lgkm = []
+    g.nop(1)
+    for k, dst in enumerate(sc):
+        g.valu(f"v_readfirstlane_b32 {s(dst)}, {v(T + k)}", regs("v", T + k), regs("s", dst))
+    g.nop(4)                                     # VALU write of an SGPR -> VMEM / SALU users
+    # constants and derived scalars
+    g.salu(f"s_mov_b32 {s(S_KEXP)}, 0x3e38aa3b", (), regs("s", S_KEXP))         # 0.125 * log2(e) (set below from the exact product)
+    g.salu(f"s_lshl_b32 {s(S_T)}, {s(S_W)}, 10", regs("s", S_W), regs("s", S_T))
+    g.salu(f"s_add_u32 {s(S_DQ)}, {s(S_LDS)}, {s(S_T)}", regs("s", S_LDS) | regs("s", S_T), regs("s", S_DQ))                  # lds0 + w * 1024
+    g.salu(f"s_lshl_b32 {s(S_T)}, {s(S_W)}, 8", regs("s", S_W), regs("s", S_T))
+    g.salu(f"s_add_u32 {s(S_DST)}, {s(S_LDS)}, {s(S_T)}", regs("s", S_LDS) | regs("s", S_T), regs("s", S_DST))
+    g.salu(f"s_add_u32 {s(S_DST)}, {s(S_DST)}, {OFF_ST}", regs("s", S_DST), regs("s", S_DST))                              # lds0 + OFF_ST + w * 256
+    # dS offset of tile row I = I0 + n0: I (I + 1) / 2 * 2048 = I (I + 1) << 10
+    g.salu(f"s_add_u32 {s(S_I)}, {s(S_I)}, {s(S_N)}", regs("s", S_I) | regs("s", S_N), regs("s", S_I))
+    g.salu(f"s_add_u32 {s(S_T)}, {s(S_I)}, 1", regs("s", S_I), regs("s", S_T))
+    g.salu(f"s_mul_i32 {s(S_T)}, {s(S_T)}, {s(S_I)}", regs("s", S_T) | regs("s", S_I), regs("s", S_T))
+    g.salu(f"s_lshl_b32 {s(S_DSOFF)}, {s(S_T)}, 10", regs("s", S_T), regs("s", S_DSOFF))
+    # masks: lanes whose key (lane & 31) <= query crow(r, hh) ; skew source lanes rd[r] = (32 hh + ((crow - bl) & 31)) * 4
+    BL, HH4, HH128, X = V_TMP + 3, V_TMP + 4, V_TMP + 5, V_TMP + 6
+    g.valu(f"v_and_b32_e32 {v(BL)}, 31, {v(V_TMP)}", regs("v", V_TMP), regs("v", BL))
+    g.valu(f"v_lshrrev_b32_e32 {v(HH4)}, 5, {v(V_TMP)}", regs("v", V_TMP), regs("v", HH4))
+    g.valu(f"v_lshlrev_b32_e32 {v(HH128)}, 7, {v(HH4)}", regs("v", HH4), regs("v", HH128))       # 32 hh * 4
+    g.valu(f"v_lshlrev_b32_e32 {v(HH4)}, 2, {v(HH4)}", regs("v", HH4), regs("v", HH4))           # 4 hh
+    for r in range(16):
+        g.valu(f"v_add_u32_e32 {v(X)}, {crow(r)}, {v(HH4)}", regs("v", HH4), regs("v", X))                             # crow(r, hh)
+        g.valu(f"v_cmp_le_u32_e64 {s(S_MASK + 2 * r, 2)}, {v(BL)}, {v(X)}", regs("v", BL) | regs("v", X), regs("s", S_MASK + 2 * r, 2))
+        g.valu(f"v_sub_u32_e32 {v(X)}, {v(X)}, {v(BL)}", regs("v", X) | regs("v", BL), regs("v", X))
+        g.valu(f"v_and_b32_e32 {v(X)}, 31, {v(X)}", regs("v", X), regs("v", X))
+        g.valu(f"v_lshl_add_u32 {v(V_RD + r)}, {v(X)}, 2, {v(HH128)}", regs("v", X) | regs("v", HH128), regs("v", V_RD + r))
+    # K / V row fragments of the wave's two key tiles
+    for u in range(2):
+        if u == 1:
+            g.salu(f"s_add_u32 {s(S_KVB)}, {s(S_KVB)}, {s(S_QSTEP)}", regs("s", S_KVB) | regs("s", S_QSTEP), regs("s", S_KVB))
+            g.salu(f"s_addc_u32 {s(S_KVB + 1)}, {s(S_KVB + 1)}, 0", regs("s", S_KVB + 1), regs("s", S_KVB + 1))
+        g.salu(f"s_add_u32 {s(S_T + 2)}, {s(S_KVB)}, {s(S_DV)}", regs("s", S_KVB) | regs("s", S_DV), regs("s", S_T + 2))
+        g.salu(f"s_addc_u32 {s(S_T + 3)}, {s(S_KVB + 1)}, 0", regs("s", S_KVB + 1), regs("s", S_T + 3))
+        for ks in range(4):
+            dk, dv_ = A_KF + 4 * (4 * u + ks), A_VF + 4 * (4 * u + ks)
+            g.vmem_load(f"global_load_dwordx4 {a(dk, 4)}, {v(V_KOFF)}, {s(S_KVB, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", S_KVB, 2), regs("a", dk, 4))
+            g.vmem_load(f"global_load_dwordx4 {a(dv_, 4)}, {v(V_KOFF)}, {s(S_T + 2, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", S_T + 2, 2), regs("a", dv_, 4))
+        g.raw("s_waitcnt vmcnt(0)")              # (S_T+2 is rewritten for the second tile)
+        g.vm_done = len(g.vm)
+    # E chunks of the first tile's products: chunk n0 - wk - k in slot (n0 - k) % 3, k = 0..2 (n0 = 4)
+    for k in range(3):
+        slot = (4 - k) % 3
+        g.salu(f"s_sub_u32 {s(S_T)}, {s(S_N)}, {s(S_WK)}", regs("s", S_N) | regs("s", S_WK), regs("s", S_T))
+        if k:
+            g.salu(f"s_sub_u32 {s(S_T)}, {s(S_T)}, {k}", regs("s", S_T), regs("s", S_T))
+        g.salu(f"s_lshl_b32 {s(S_T)}, {s(S_T)}, 12", regs("s", S_T), regs("s", S_T))
+        g.salu(f"s_add_u32 {s(S_T + 2)}, {s(S_EFA)}, {s(S_T)}", regs("s", S_EFA) | regs("s", S_T), regs("s", S_T + 2))
+        g.salu(f"s_addc_u32 {s(S_T + 3)}, {s(S_EFA + 1)}, 0", regs("s", S_EFA + 1), regs("s", S_T + 3))
+        for ks in range(4):
+            dst = A_E + 4 * (4 * slot + ks)
+            g.vmem_load(f"global_load_dwordx4 {a(dst, 4)}, {v(V_L16)}, {s(S_T + 2, 2)} offset:{1024 * ks}", "e0", regs("v", V_L16) | regs("s", S_T + 2, 2), regs("a", dst, 4))
+        g.raw("s_waitcnt vmcnt(0)")
+        g.vm_done = len(g.vm)
+    # tile n0 -> buffer 0 (the fill iteration then requests tile n0 + 1 into buffer 1): the DMA code of variant 5 with n - 2
+    g.raw("s_barrier")                           # the other wave has left whatever used the LDS buffers before
+    g.salu(f"s_sub_u32 {s(S_N)}, {s(S_N)}, 2", regs("s", S_N), regs("s", S_N))
+    st = Step(g, 4)                              # variant 4: n even -> DMA destination buffer 0
+    for f in st.dma_addr() + st.dma("dma_first"):
+        f()
+    g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))       # n = n0 - 1: the fill iteration
+    g.drain()
+    g.raw("s_barrier")
+
+
+def generate():
+    g = Gen()
+    prologue(g)
+    # pipeline fill = variant 5 (n = n0 - 1 = 3: buffer 1, E rotation 0) without the tile-n part
+    body(g, 5, do_cur=False)
+    g.drain()
+    g.nop(16)
+    g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))       # n = n0
+    pro_lines = list(g.out)
+    # the loop: two rounds to reach the loop-carried state of the wait / hazard trackers, the third is the one emitted
+    texts = []
+    for rnd in range(3):
+        g.out = []
+        for b in range(6):
+            g.out.append(f"L_dkv_b{b}_%=:")
+            body(g, b)
+            g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))
+            g.salu(f"s_cmp_ge_u32 {s(S_N)}, {s(S_NT)}", regs("s", S_N) | regs("s", S_NT), {"scc"})
+            g.raw(f"s_cbranch_scc1 L_dkv_end_%=")
+        g.raw("s_branch L_dkv_b0_%=")
+        texts.append(list(g.out))
+    assert texts[1] == texts[2], "the loop body is not a fixed point of the wait-count / hazard trackers"
+    loop_lines = texts[2]
+    g.out = []
+    g.out.append("L_dkv_end_%=:")
+    g.drain()
+    g.nop(16)                                    # the accumulators are read by compiler code behind the block
+    g.raw("s_barrier")
+    return pro_lines + loop_lines + g.out, g
+
+
+def clobbers():
+    c = [f"v{i}" for i in range(V_FIRST, V_LAST + 1)] + [f"a{i}" for i in range(A_FIRST, A_LAST + 1)]
+    c += [f"s{i}" for i in range(S_FIRST, S_LAST + 1)] + ["vcc", "scc", "m0", "memory"]
+    return c
+
+
+def main():
+    lines, g = generate()
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "rel_attn_dkv64_loop.inc")
+    with open(path, "w") as f:
+        f.write("// GENERATED by gen_dkv_asm.py -- do not edit.  The hand-scheduled main loop of rel_attn_dkv64_kernel (one asm statement):\n")
+        f.write("// operands %0..%7 = dk[0][0], dk[0][1], dv[0][0], dv[0][1], dk[1][0], dk[1][1], dv[1][0], dv[1][1] (\"+a\"), %8 = LDS address of the\n")
+        f.write("// wave's parameter block (\"s\").  Register map, schedule and hazard rules: gen_dkv_asm.py.\n")
+        f.write("#define MGX_DKV64_LOOP_ASM \\\n")
+        for ln in lines:
+            if ln.startswith(";"):
+                f.write(f"    /* {ln[1:].strip()} */ \\\n")
+            else:
+                f.write(f'    "{ln}\\n\\t" \\\n')
+        f.write('    ""\n')
+        f.write("#define MGX_DKV64_LOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+    n_loop = sum(1 for ln in lines if not ln.startswith(";") and not ln.endswith(":"))
+    print(f"wrote {path}: {n_loop} instructions, s_nop wait states inserted: {g.nops}; counts {g.stats}", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

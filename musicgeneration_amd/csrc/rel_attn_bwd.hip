@@ -1308,7 +1308,8 @@ extern "C" size_t mgx_rel_attn_bwd_workspace(int B, int L, int d) {
 
 // parts: 1 pre-pass (delta, E re-layout) | 4 dK/dV (stores the dS tiles) | 2 dQ from the stored tiles | 8 dE from the stored
 // tiles | 16 dE by recomputation | 32 dQ by recomputation (16, 32: independent of the stored tiles; cross-checks / A-B
-// timing).  Launch order inside one call: 1, 4, 2 (or 32), 8, 16.
+// timing) | 64 dK/dV by the 32-key kernel whatever the shape (instead of 4; cross-check of the 64-key kernel).  Launch order inside
+// one call: 1, 4 (or 64), 2 (or 32), 8, 16.
 extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                                       const uint16_t* ctx, const uint16_t* dctx, const float* lse, uint16_t* dqkv,
                                       float* dE, void* workspace, size_t ws_bytes, int B, int L, int d, int M,
@@ -1347,7 +1348,16 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
     const int bg = bwd_batch_group(B, L, d);
     MGX_REQUIRE((long)((L + 127) / 128) * (B / bg) <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: L/128 * batch groups too large");
     const dim3 gq(bg * heads, ((L + 127) / 128) * (B / bg));
-    if (parts & 4) {
+    MGX_REQUIRE(!((parts & 4) && (parts & 64)), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: parts 4 and 64 both write dk / dv and the dS tiles");
+#ifndef MGX_DKV64_DEFAULT
+#define MGX_DKV64_DEFAULT 1   // 0 (A/B builds): bit 2 launches the 32-key kernel for every shape
+#endif
+    // bit 2: the 64-keys-per-wave kernel with the hand-scheduled main loop (rel_attn_dkv64.hip) where the sequence is whole 128-key
+    // blocks, the 32-key kernel otherwise; bit 6: the 32-key kernel whatever the shape (cross-check: both give the same bits)
+    if ((parts & 4) && MGX_DKV64_DEFAULT && L % 128 == 0) {
+        const int rc64 = dkv64_launch(qkv, EfA, padbits, dctx, nlse2, ndelta, dqkv, dst, B, L, d, bg, stream);
+        if (rc64 != MGX_OK) return rc64;
+    } else if (parts & (4 | 64)) {
 #if MGX_EXPERIMENTS
         static const int dkv_lds = [] {     // experiment: MGX_DKV_LDS pads the dynamic LDS to lower the residency (timing only)
             const char* e = getenv("MGX_DKV_LDS");
@@ -1362,14 +1372,6 @@ extern "C" int mgx_rel_attn_bwd_parts(const uint16_t* qkv, const uint16_t* E, co
         MGX_REQUIRE(gk.y <= 65535, MGX_ERR_SHAPE, "mgx_rel_attn_bwd: too many key blocks for the grid");
         hipLaunchKernelGGL(rel_attn_dkv_kernel<true>, gk, dim3(64 * k2::KW), dkv_lds, s, qkv, EfA, padbits, dctx, nlse2, ndelta, dqkv, dst, L, d, bg);
     }
-#if MGX_EXPERIMENTS
-    if (parts & 64) {                                   // experiment builds: dK/dV with 64 keys per wave (tools/experiments/rel_attn_bwd64.hip)
-        MGX_REQUIRE(L % 128 == 0 && !(parts & 4), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: parts bit 6 needs L%%128==0 and excludes bit 2");
-        dkv64_launch(qkv, EfA, padbits, dctx, nlse2, ndelta, dqkv, dst, B, L, d, bg, stream);
-    }
-#else
-    MGX_REQUIRE(!(parts & 64), MGX_ERR_SHAPE, "mgx_rel_attn_bwd: parts bit 6 (64-key dK/dV) exists in experiment builds only");
-#endif
     if (parts & 2)
         hipLaunchKernelGGL(rel_attn_dq_lite_kernel, gq, dim3(256), k1l::LDS_BYTES, s, qkv, EfT, dst, dqkv, L, d, bg);
     if (parts & 32)

@@ -257,7 +257,7 @@ static inline void launch_er_frag(const uint16_t* Er, u32x4* EfA, u32x4* EfT, in
     hipLaunchKernelGGL(er_frag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Er, EfA, EfT, L);
 }
 
-// experiment builds only (tools/experiments/rel_attn_bwd64.hip): dK / dV with 64 keys per wave (L % 128 == 0)
+// rel_attn_dkv64.hip: dK / dV with 64 keys per wave and the generated asm main loop (L % 128 == 0)
 int dkv64_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, const uint16_t* dctx, const float* nlse2,
                  const float* ndelta, uint16_t* dqkv, uint16_t* dst, int B, int L, int d, int bg, void* stream);
 // experiment builds only (tools/experiments/rel_attn_fwd2.hip, rel_attn_fwd3.hip; MGX_EXPERIMENTS)

@@ -51,9 +51,8 @@ if a.parts & 4:
         timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 32, dqkv, ws), 5, "dq_rec")     # recompute (cross-check kernel)
 if a.parts & 8:
     for _ in range(a.rounds):
-        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 6, "dkv")
-        if a.L % 128 == 0 and os.environ.get("MGX_LIB_PATH", "").endswith("_exp.so"):        # experiment build only
-            timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 64, dqkv, ws), 5.5, "dkv64")
+        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4, dqkv, ws), 5.5 if a.L % 128 == 0 else 6, "dkv")     # 64-key asm kernel where L % 128 == 0
+        timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 64, dqkv, ws), 6, "dkv32")                              # the 32-key kernel
 if a.parts & 16: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 8, dqkv, ws), 1, "de_tiles")
 if a.parts & 32: timed(lambda: ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 16, dqkv, ws), 6, "de_rec")
 if a.parts & 64:

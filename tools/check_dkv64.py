@@ -1,13 +1,12 @@
-"""Parity of the experimental 64-keys-per-wave dK/dV kernel (tools/experiments/rel_attn_bwd64.hip) with the product's 32-key
-kernel: dk, dv and every stored dS tile must be bit-identical (same arithmetic per tile).  GPU box:
-    python -m musicgeneration_amd._build --variant exp --experiments          (here)
-    MGX_LIB_PATH=musicgeneration_amd/libmgx_exp.so python tools/experiments/check_dkv64.py"""
+"""Parity of the 64-keys-per-wave dK/dV kernel with the generated asm main loop (csrc/rel_attn_dkv64.hip, parts bit 2 where
+L % 128 == 0) with the 32-key kernel (parts bit 6): dk, dv and every stored dS tile must be bit-identical (same arithmetic per
+tile, same accumulation order).  GPU box:   python tools/check_dkv64.py     (also localises differing tiles on a small case)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from musicgeneration_amd import ops
 dev = torch.device("cuda")
-for (B, L, d) in ((2, 256, 128), (1, 1024, 64), (3, 512, 192)):
+for (B, L, d) in ((1, 256, 64), (2, 256, 128), (1, 1024, 64), (3, 512, 192), (2, 2048, 128), (1, 640, 64), (1, 896, 64)):
     g = torch.Generator().manual_seed(L)
     qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(dev)
     E = (torch.randn(L, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
@@ -19,8 +18,8 @@ for (B, L, d) in ((2, 256, 128), (1, 1024, 64), (3, 512, 192)):
         ws1 = torch.zeros(n, dtype=torch.uint8, device=dev); ws2 = torch.zeros(n, dtype=torch.uint8, device=dev)
         dE = torch.zeros(L, 64, device=dev)
         dq1 = torch.zeros_like(qkv); dq2 = torch.zeros_like(qkv)
-        ops.rel_attn_bwd(qkv, E, bits, ctx, dctx, lse, dE, 1 | 4, dq1, ws1)
-        ops.rel_attn_bwd(qkv, E, bits, ctx, dctx, lse, dE, 1 | 64, dq2, ws2)
+        ops.rel_attn_bwd(qkv, E, bits, ctx, dctx, lse, dE, 1 | 64, dq1, ws1)      # 32-key kernel
+        ops.rel_attn_bwd(qkv, E, bits, ctx, dctx, lse, dE, 1 | 4, dq2, ws2)       # 64-key kernel, asm main loop
         torch.cuda.synchronize()
         same_kv = torch.equal(dq1[..., d:], dq2[..., d:])
         same_ws = torch.equal(ws1, ws2)
@@ -28,7 +27,7 @@ for (B, L, d) in ((2, 256, 128), (1, 1024, 64), (3, 512, 192)):
               " max|diff|", (dq1[..., d:].float() - dq2[..., d:].float()).abs().max().item())
 
 # localise: which dS tiles differ (B=1, L=256, d=64: 8x8 tile grid, causal half packed by rows)
-B, L, d = 1, 256, 64
+B, L, d = 1, 512, 64
 g = torch.Generator().manual_seed(1)
 qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(dev)
 E = (torch.randn(L, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
@@ -37,8 +36,8 @@ ctx, lse = ops.rel_attn_fwd(qkv, E, None)
 n = ops._lib.load().mgx_rel_attn_bwd_workspace(B, L, d)
 ws1 = torch.zeros(n, dtype=torch.uint8, device=dev); ws2 = torch.zeros(n, dtype=torch.uint8, device=dev)
 dE = torch.zeros(L, 64, device=dev); dq1 = torch.zeros_like(qkv); dq2 = torch.zeros_like(qkv)
-ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1 | 4, dq1, ws1)
-ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1 | 64, dq2, ws2)
+ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1 | 64, dq1, ws1)
+ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1 | 4, dq2, ws2)
 torch.cuda.synchronize()
 nt = L // 32
 off = n - nt * (nt + 1) // 2 * 2048
