@@ -31,8 +31,7 @@ EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip"]      # --experim
 # row sums into v_pk_add_f32 (slower than two v_add_f32 beside MFMAs).
 _W64 = ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]
 EXTRA_FLAGS = {"rel_attn_fwd2.hip": _W64,
-               # the 64-key dK/dV kernel (HIP steps): accumulators in AGPRs through inline-asm MFMAs, every other MFMA the builtin in VGPR form
-               "rel_attn_dkv64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+               }
 
 
 def _hipcc() -> str:
@@ -58,9 +57,18 @@ def _stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _generate() -> None:
+    """the hand-scheduled dK/dV main loop is generated code: csrc/gen_dkv_asm.py -> csrc/rel_attn_dkv64_loop.inc (tracked, so the
+    schedule can be read and diffed) and ..._loop_stamp.inc (diagnostic builds; not tracked).  Regenerated on every build."""
+    r = subprocess.run([sys.executable, os.path.join(CSRC, "gen_dkv_asm.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("gen_dkv_asm.py failed:\n" + r.stdout)
+
+
 def _compile_and_link(lib: str, objdir: str, defines, verbose: bool, experiments: bool = False) -> None:
     hipcc = _hipcc()
     os.makedirs(objdir, exist_ok=True)
+    _generate()
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
               "-I" + CSRC, "-Wno-unused-value", "-Wno-unused-result"] + list(defines)
     objs, procs = [], []

@@ -3,10 +3,12 @@
 
     python musicgeneration_amd/csrc/gen_dkv_asm.py            -> musicgeneration_amd/csrc/rel_attn_dkv64_loop.inc
 
-The kernel's prologue, its diagonal (masked) steps and its epilogue stay HIP; the steady-state steps -- every query tile
-t >= 4 of an unpadded key block -- are ONE `asm volatile` block emitted by this script: a fixed register map, every MFMA
-followed by the VALU / LDS / VMEM instructions assigned to its shadow, counted waits, and the hazards hipcc does not pad
-inside an asm statement checked (and padded) here.  What a step computes, and the layouts, are those of rel_attn_bwd.hip
+The kernel's address set-up and its epilogue (the dk / dv stores) stay HIP; the whole sweep over the query tiles is ONE
+`asm volatile` block emitted by this script: a fixed register map, every MFMA followed by the VALU / LDS / VMEM instructions
+assigned to its shadow, counted waits, and the hazards hipcc does not pad inside an asm statement checked (and padded) here.
+Two loops of six body variants each: "masked" bodies for the steps of the diagonal block (a sub-tile not started / on its
+diagonal) and for key blocks with padded keys, and the branch-free main bodies a wave switches to once both its sub-tiles are
+full (query tile n >= wk + 2).  What a step computes, and the layouts, are those of rel_attn_bwd.hip
 (dkv_kernel) / tools/experiments/rel_attn_bwd64.hip; results are bit-identical to both.
 
 Structure of one iteration n (query tile n against the wave's key tiles J, J+1 = sub-tiles 0, 1), 44 MFMAs:
@@ -35,6 +37,7 @@ V_QOFF = 23          # ..24  DMA source offsets of q (two 1 KB pieces)
 V_OOFF = 25          # ..26  ... of dO
 V_STOFF = 27         # ... of the statistics
 V_KOFF = 28          # K / V fragment offset (prologue only)
+V_NEGINF = 29        # -inf in every lane (masked bodies)
 V_TMP = 238          # ..245 temporaries (prologue)
 V_RD = 30            # ..45  ds_bpermute source-lane addresses of the skew
 V_QA = 46            # ..61  q row fragments (4 x 4)
@@ -58,7 +61,18 @@ S_DV = 101           # d * 2 (byte offset of V behind K)
 S_FIRST, S_LAST = 36, 101
 S_ET, S_EP, S_SP = 32, 34, 30   # E-load temporaries (2), E chunk pointer (2), dS store pointer (2): s30..s35
 S_ST = 29
-S_FIRST = 29
+S_FIRST = 14
+S_STAMP = 10         # ..13 (stamp builds): s_memtime pair, previous stamp, difference
+S_PADM = 14          # ..17: lanes whose key is padded, sub-tile 0 / 1
+S_FULL = 18          # ..21 (masked bodies): all ones where sub-tile u is below its diagonal (no causal mask), else 0
+S_KILL = 22          # ..25 (masked bodies): lanes to mask whatever the row: padded keys; everything while sub-tile u has not started
+S_TM = 26            # ..27 (masked bodies): keep-mask of one accumulator register
+S_PADANY = 28        # != 0: a key of this wave is padded (every step runs the masked body)
+V_STAMP = 246        # ..253 (stamp builds): cycle sums
+STAMP = False
+ST_CACHE = os.environ.get("MGX_DKV64_ST", "nt")          # experiment: cache policy of the dS stores (nt | plain | sc1 | sc0sc1)
+ST_PINS = [int(x) for x in os.environ.get("MGX_DKV64_STPIN", "").split(",") if x]      # experiment: the MFMA shadows of the four dS stores
+PEEL = 0             # timing experiments (results wrong): 1 no dS stores | 2 no E loads | 4 no DMA | 8 no skew | 16 no exp | 32 no merge | 64 no stats reads | 128 no tr reads
 
 OFF_QR, OFF_OR, OFF_ST = 0, 8192, 16384
 ST_BYTES = 512
@@ -142,6 +156,17 @@ class Gen:
         idx = max((i for i in range(len(self.vm)) if self.vm[i][0] == tag), default=-1)
         if idx >= self.vm_done:
             self.wait_vm_index(idx)
+
+    def stamp(self, k):
+        """diagnostic builds: add the cycles since the previous stamp to sum k (v246 + k; every lane holds the same value).  Reading
+        the clock waits for lgkmcnt(0): a stamped build is slower, read its SHARES"""
+        self.raw(f"s_memtime {s(S_STAMP, 2)}")
+        self.raw("s_waitcnt lgkmcnt(0)")
+        self.lgkm = []
+        self.raw(f"s_sub_u32 {s(S_STAMP + 3)}, {s(S_STAMP)}, {s(S_STAMP + 2)}")
+        self.raw(f"s_mov_b32 {s(S_STAMP + 2)}, {s(S_STAMP)}")
+        if k is not None:
+            self.raw(f"v_add_u32_e32 {v(V_STAMP + k)}, {s(S_STAMP + 3)}, {v(V_STAMP + k)}")
 
     def drain(self):
         self.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -250,6 +275,9 @@ class Gen:
 # ---------------------------------------------------------------------------------------------------------------------
 # pieces of a step
 # ---------------------------------------------------------------------------------------------------------------------
+ST_SUFFIX = {"nt": " nt", "plain": "", "sc1": " sc1", "sc0sc1": " sc0 sc1"}[ST_CACHE]
+
+
 def crow(r, hh=0):
     return (r & 3) + 8 * (r >> 2) + 4 * hh
 
@@ -270,11 +298,11 @@ def salu_items(g, ops):
 
 
 class Step:
-    """instruction groups of iteration n in variant `b` (n = 4 + b mod 6)"""
+    """instruction groups of iteration n in variant `b` = n mod 6"""
 
     def __init__(self, g: Gen, b: int):
         self.g = g
-        n = 4 + b
+        n = b
         self.cur = n & 1                       # LDS buffer of tile n; tile n+1 in cur ^ 1; DMA of tile n+2 -> cur
         self.T = V_T[n & 1]                    # c0 / nl / c1 of tile n
         self.Tn = V_T[(n + 1) & 1]             # chunk products of tile n+1
@@ -423,14 +451,64 @@ class Step:
                                                                          regs("v", lo) | regs("v", hi), regs("v", dst)))
         return out
 
+    # -- masked bodies: causal / padding / not-started masks of tile n ---------------------------------------------------------
+    def mask_setup(self):
+        """per sub-tile u (dq_u = n - wk - u): FULL_u = dq_u > 0 ? ~0 : 0;  KILL_u = PADM_u | (dq_u < 0 ? ~0 : 0)"""
+        g = self.g
+        ops = []
+        for u in range(2):
+            ops += [(f"s_sub_u32 {s(S_TM)}, {s(S_N)}, {s(S_WK)}", regs("s", S_N) | regs("s", S_WK), regs("s", S_TM))]
+            if u:
+                ops += [(f"s_sub_u32 {s(S_TM)}, {s(S_TM)}, 1", regs("s", S_TM), regs("s", S_TM))]
+            ops += [(f"s_cmp_gt_i32 {s(S_TM)}, 0", regs("s", S_TM), {"scc"}),
+                    (f"s_cselect_b64 {s(S_FULL + 2 * u, 2)}, -1, 0", {"scc"}, regs("s", S_FULL + 2 * u, 2)),
+                    (f"s_cmp_lt_i32 {s(S_TM)}, 0", regs("s", S_TM), {"scc"}),
+                    (f"s_cselect_b64 {s(S_KILL + 2 * u, 2)}, -1, 0", {"scc"}, regs("s", S_KILL + 2 * u, 2)),
+                    (f"s_or_b64 {s(S_KILL + 2 * u, 2)}, {s(S_KILL + 2 * u, 2)}, {s(S_PADM + 2 * u, 2)}", regs("s", S_KILL + 2 * u, 2) | regs("s", S_PADM + 2 * u, 2),
+                     regs("s", S_KILL + 2 * u, 2))]
+        return [lambda: [g.salu(*o) for o in ops]]          # ONE item: the compare / select pairs pass through SCC, S_TM is a temporary
+
+    def mask_apply(self, u):
+        """c_u[r] = keep ? c_u[r] : -inf, keep = (lanes with key <= query of register r | FULL_u) & ~KILL_u"""
+        g = self.g
+        c = self.T + (0 if u == 0 else 32)
+        out = []
+        for r in range(16):
+            def f(r=r):
+                g.salu(f"s_or_b64 {s(S_TM, 2)}, {s(S_MASK + 2 * r, 2)}, {s(S_FULL + 2 * u, 2)}", regs("s", S_MASK + 2 * r, 2) | regs("s", S_FULL + 2 * u, 2), regs("s", S_TM, 2))
+                g.salu(f"s_andn2_b64 {s(S_TM, 2)}, {s(S_TM, 2)}, {s(S_KILL + 2 * u, 2)}", regs("s", S_TM, 2) | regs("s", S_KILL + 2 * u, 2), regs("s", S_TM, 2))
+                g.valu(f"v_cndmask_b32_e64 {v(c + r)}, {v(V_NEGINF)}, {v(c + r)}, {s(S_TM, 2)}", regs("v", V_NEGINF) | regs("v", c + r) | regs("s", S_TM, 2), regs("v", c + r))
+            out.append(f)
+        return out
+
+    def st_dS_masked(self, tag):
+        """the dS stores of sub-tile u exist only for key tile <= query tile (dq_u >= 0): EXEC = 0 otherwise -- a store with no active
+        lane writes nothing and still counts in vmcnt, so the counted waits hold.  One item per sub-tile: nothing else may run under the
+        cleared EXEC"""
+        g = self.g
+        out = []
+        for u in range(2):
+            def f(u=u):
+                g.salu(f"s_sub_u32 {s(S_TM)}, {s(S_N)}, {s(S_WK)}", regs("s", S_N) | regs("s", S_WK), regs("s", S_TM))
+                g.salu(f"s_cmp_ge_i32 {s(S_TM)}, {u}", regs("s", S_TM), {"scc"})
+                g.salu(f"s_cselect_b64 exec, -1, 0", {"scc"}, {"exec"})
+                for ss in range(2):
+                    src = V_DP + 16 * u + 8 * ss
+                    g.vmem_store(f"global_store_dwordx4 {v(V_L16)}, {v(src, 4)}, {s(S_SP, 2)} offset:{2048 * u + 1024 * ss}{ST_SUFFIX}", tag,
+                                 regs("v", V_L16) | regs("v", src, 4) | regs("s", S_SP, 2))
+                g.salu("s_mov_b64 exec, -1", (), {"exec"})
+            out.append(f)
+        return out
+
     # -- E chunk of tile n+2 -------------------------------------------------------------------------------------------------
     def ldE_addr(self):
-        """pointer of chunk min(n + 2 - wk, nchunk - 1) of the fragment-ordered E copy -> S_EP"""
+        """pointer of chunk clamp(n + 2 - wk, 0, nchunk - 1) of the fragment-ordered E copy -> S_EP"""
         g = self.g
         ops = [(f"s_add_u32 {s(S_ET)}, {s(S_N)}, 2", regs("s", S_N), regs("s", S_ET)),
                (f"s_sub_u32 {s(S_ET)}, {s(S_ET)}, {s(S_WK)}", regs("s", S_ET) | regs("s", S_WK), regs("s", S_ET)),
                (f"s_sub_u32 {s(S_ET + 1)}, {s(S_NCH)}, 1", regs("s", S_NCH), regs("s", S_ET + 1)),
-               (f"s_min_u32 {s(S_ET)}, {s(S_ET)}, {s(S_ET + 1)}", regs("s", S_ET, 2), regs("s", S_ET)),
+               (f"s_min_i32 {s(S_ET)}, {s(S_ET)}, {s(S_ET + 1)}", regs("s", S_ET, 2), regs("s", S_ET)),
+               (f"s_max_i32 {s(S_ET)}, {s(S_ET)}, 0", regs("s", S_ET), regs("s", S_ET)),        # (wave 1's first steps: chunk < 0, product unused)
                (f"s_lshl_b32 {s(S_ET)}, {s(S_ET)}, 12", regs("s", S_ET), regs("s", S_ET)),
                (f"s_add_u32 {s(S_EP)}, {s(S_EFA)}, {s(S_ET)}", regs("s", S_EFA) | regs("s", S_ET), regs("s", S_EP)),
                (f"s_addc_u32 {s(S_EP + 1)}, {s(S_EFA + 1)}, 0", regs("s", S_EFA + 1), regs("s", S_EP + 1))]
@@ -476,9 +554,12 @@ class Step:
             for ss in range(2):
                 src = V_DP + 16 * u + 8 * ss
                 out.append(lambda u=u, ss=ss, src=src: g.vmem_store(
-                    f"global_store_dwordx4 {v(V_L16)}, {v(src, 4)}, {s(S_SP, 2)} offset:{2048 * u + 1024 * ss} nt", tag,
+                    f"global_store_dwordx4 {v(V_L16)}, {v(src, 4)}, {s(S_SP, 2)} offset:{2048 * u + 1024 * ss}{ST_SUFFIX}", tag,
                     regs("v", V_L16) | regs("v", src, 4) | regs("s", S_SP, 2)))
         return out
+
+
+STAMP_GAPS = {10: 0, 16: 1, 28: 2, 36: 3, 44: 4}      # stamp after the shadow of MFMA g -> sum index
 
 
 class Item:
@@ -542,10 +623,10 @@ def schedule(items, ngaps=44):
     return table, budget
 
 
-def body(g: Gen, b: int, do_cur: bool = True, listing=None):
+def body(g: Gen, b: int, do_cur: bool = True, masked: bool = False, listing=None):
     st = Step(g, b)
     prev_b = (b + 5) % 6
-    g.comment(f"==== iteration variant {b}: buffer {st.cur}, E slots t0/t1/t2 = {st.slot_t0}/{st.slot_t1}/{st.slot_t2}{'' if do_cur else '  (pipeline fill: tile n+1 part only)'} ====")
+    g.comment(f"==== {'masked' if masked else 'main'} body {b}: buffer {st.cur}, E slots t0/t1/t2 = {st.slot_t0}/{st.slot_t1}/{st.slot_t2}{'' if do_cur else '  (pipeline fill: tile n+1 part only)'} ====")
     # ---- the MFMA sequence ----
     none4 = [None] * 4
     mf = (st.mfma_S(0) + st.mfma_S(1) + st.mfma_dP(0) + st.mfma_dP(1)) if do_cur else none4 * 4
@@ -574,11 +655,17 @@ def body(g: Gen, b: int, do_cur: bool = True, listing=None):
     ro = add(st.rd_rows("o"), COST["lds128"], earliest=16, deadline=38, deps=bar, name="rows_o")       # dP of tile n = MFMAs 9-16
     if do_cur:
         cvds = []
+        if masked:
+            ms = add(st.mask_setup(), 12 * COST["salu"], earliest=1, deadline=6, name="mask_setup")
         for u, (e_c, e_dp, dl) in enumerate(((7, 15, 27), (11, 19, 35))):
             ex = add(st.soft_exp(u), 0, earliest=e_c, deadline=dl - 4, name=f"exp{u}")
+            if masked:
+                mk = add(st.mask_apply(u), 2 * COST["salu"] + COST["valu"], earliest=e_c, deadline=dl - 5, deps=ms, name=f"mask{u}")
             for r in range(16):
                 ex[2 * r].cost, ex[2 * r + 1].cost = COST["valu"], COST["trans"]
                 ex[2 * r + 1].deps.append(ex[2 * r])
+                if masked:
+                    ex[2 * r].deps.append(mk[r])
             sd = add(st.soft_ds(u), COST["valu"], earliest=max(e_c, e_dp), deadline=dl, name=f"ds{u}")
             mul, cvd, cvc = sd[:16], sd[16:24], sd[24:32]
             for r in range(16):
@@ -588,9 +675,16 @@ def body(g: Gen, b: int, do_cur: bool = True, listing=None):
                 cvc[k].deps += [ex[2 * (8 * ss + 2 * j) + 1], ex[2 * (8 * ss + 2 * j + 1) + 1], mul[8 * ss + j]] + ([cvc[k - 1]] if j else [])
             cvds.append(cvd)
         sa = chain(add(st.st_addr(), COST["salu"], earliest=1, deadline=30, name="st_addr"))
-        sts = chain(add(st.st_dS(f"st{b}"), COST["vmem"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
-        for k, it in enumerate(sts):
-            it.deps += cvds[k >> 1][4 * (k & 1): 4 * (k & 1) + 4]
+        if masked:
+            sts = chain(add(st.st_dS_masked(f"st{b}"), 2 * COST["vmem"] + 4 * COST["salu"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
+            for u, it in enumerate(sts):
+                it.deps += cvds[u]
+        else:
+            sts = chain(add(st.st_dS(f"st{b}"), COST["vmem"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
+            for k, it in enumerate(sts):
+                it.deps += cvds[k >> 1][4 * (k & 1): 4 * (k & 1) + 4]
+                if ST_PINS:
+                    it.pin = ST_PINS[k]
     ea = chain(add(st.ldE_addr(), COST["salu"], earliest=1, deadline=28, name="ldE_addr"))
     le = chain(add(st.ld_E(f"e{b}"), COST["vmem"], earliest=28, deadline=40, deps=ea[-1:], name="ld_E"))   # t2 = MFMAs 25-28
     m0 = add(st.merge(0), COST["valu"], earliest=27, deadline=38, name="merge0")                        # t0, t1 done after MFMA 24
@@ -600,6 +694,19 @@ def body(g: Gen, b: int, do_cur: bool = True, listing=None):
     for r in range(16):
         k0[r].deps.append(m0[r])
         k1[r].deps.append(m1[r])
+    if PEEL and not masked and do_cur:
+        drop = set()
+        for bit, names in ((1, ("st_dS",)), (2, ("ld_E",)), (4, ("dma",)), (8, ("skew0", "skew1")), (32, ("merge0", "merge1")),
+                           (64, ("nd0", "nd1", "nl")), (128, ("tr",))):
+            if PEEL & bit:
+                drop |= set(names)
+        for it in items:
+            if it.name in drop:
+                it.fn = lambda: None
+        if PEEL & 16:
+            for it in items:
+                if it.name.startswith("exp") and it.cost == COST["trans"]:
+                    it.fn = lambda: None
     table, budget = schedule(items)
     g.comment(f"per-gap issue budget {budget}")
     for gi in range(1, 45):
@@ -610,6 +717,8 @@ def body(g: Gen, b: int, do_cur: bool = True, listing=None):
             listing.append((gi, len(g.out)))
         for it in table[gi]:
             it.fn()
+        if STAMP and do_cur and not masked and gi in STAMP_GAPS:
+            g.stamp(STAMP_GAPS[gi])
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -617,8 +726,8 @@ def body(g: Gen, b: int, do_cur: bool = True, listing=None):
 # ---------------------------------------------------------------------------------------------------------------------
 def prologue(g: Gen):
     """%8 = LDS address of this wave's parameter block (written by the HIP code just before):
-         dwords 0..23: EfA, q_base, o_base, st_base, ds_col, kv_base (64-bit each) | n0 (= 4), nT, wk, I0, q_step, o_step, lds0, nchunk,
-                       w, d*2, 0, 0
+         dwords 0..23: EfA, q_base, o_base, st_base, ds_col, kv_base (64-bit each) | 0, nT, wk, I0, q_step, o_step, lds0, nchunk,
+                       w, d*2, pad word of key tile 0, of key tile 1
          + 256 + 256 k + 4 lane: lane table k = aq0..3, atr, ast, qoff0..1, ooff0..1, stoff, koff"""
     g.comment("==== prologue ====")
     g.drain()
@@ -633,117 +742,166 @@ def prologue(g: Gen):
     lane_tab = [V_AQ, V_AQ + 1, V_AQ + 2, V_AQ + 3, V_ATR, V_AST, V_QOFF, V_QOFF + 1, V_OOFF, V_OOFF + 1, V_STOFF, V_KOFF]
     for k, dst in enumerate(lane_tab):
         g.ds_read(f"ds_read_b32 {v(dst)}, {v(V_TMP + 2)} offset:{256 + 256 * k}", regs("v", V_TMP + 2), regs("v", dst))
+    S_PW = S_TM                                  # the two pad words (temporaries until the masks exist)
     sc = [S_EFA, S_EFA + 1, S_QB, S_QB + 1, S_OB, S_OB + 1, S_STB, S_STB + 1, S_DSB, S_DSB + 1, S_KVB, S_KVB + 1,
-          S_N, S_NT, S_WK, S_I, S_QSTEP, S_OSTEP, S_LDS, S_NCH, S_W, S_DV]
+          S_N, S_NT, S_WK, S_I, S_QSTEP, S_OSTEP, S_LDS, S_NCH, S_W, S_DV, S_PW, S_PW + 1]
     g.raw("s_waitcnt lgkmcnt(0)")
     g.lgkm = []
     g.nop(1)
     for k, dst in enumerate(sc):
         g.valu(f"v_readfirstlane_b32 {s(dst)}, {v(T + k)}", regs("v", T + k), regs("s", dst))
     g.nop(4)                                     # VALU write of an SGPR -> VMEM / SALU users
-    # constants and derived scalars
-    g.salu(f"s_mov_b32 {s(S_KEXP)}, 0x3e38aa3b", (), regs("s", S_KEXP))         # 0.125 * log2(e) (set below from the exact product)
+    # derived scalars
     g.salu(f"s_lshl_b32 {s(S_T)}, {s(S_W)}, 10", regs("s", S_W), regs("s", S_T))
     g.salu(f"s_add_u32 {s(S_DQ)}, {s(S_LDS)}, {s(S_T)}", regs("s", S_LDS) | regs("s", S_T), regs("s", S_DQ))                  # lds0 + w * 1024
     g.salu(f"s_lshl_b32 {s(S_T)}, {s(S_W)}, 8", regs("s", S_W), regs("s", S_T))
     g.salu(f"s_add_u32 {s(S_DST)}, {s(S_LDS)}, {s(S_T)}", regs("s", S_LDS) | regs("s", S_T), regs("s", S_DST))
     g.salu(f"s_add_u32 {s(S_DST)}, {s(S_DST)}, {OFF_ST}", regs("s", S_DST), regs("s", S_DST))                              # lds0 + OFF_ST + w * 256
-    # dS offset of tile row I = I0 + n0: I (I + 1) / 2 * 2048 = I (I + 1) << 10
-    g.salu(f"s_add_u32 {s(S_I)}, {s(S_I)}, {s(S_N)}", regs("s", S_I) | regs("s", S_N), regs("s", S_I))
-    g.salu(f"s_add_u32 {s(S_T)}, {s(S_I)}, 1", regs("s", S_I), regs("s", S_T))
-    g.salu(f"s_mul_i32 {s(S_T)}, {s(S_T)}, {s(S_I)}", regs("s", S_T) | regs("s", S_I), regs("s", S_T))
+    # every global request of the prologue goes out now (distinct pointer pairs: no wait in between): query tile 0 -> buffer 0,
+    # the K / V row fragments of the wave's two key tiles, E chunk 0 into the three slots (the first step's products use chunks
+    # <= 0: chunk 0 or, for a sub-tile that has not started, anything)
+    for i in range(2):
+        for img, ptr, voff in ((OFF_QR, S_QB, V_QOFF + i), (OFF_OR, S_OB, V_OOFF + i)):
+            g.salu(f"s_add_u32 m0, {s(S_DQ)}, {img + 2048 * i}", regs("s", S_DQ), {"m0"})
+            g.vmem_dma(f"global_load_lds_dwordx4 {v(voff)}, {s(ptr, 2)}", "dma_first", regs("v", voff) | regs("s", ptr, 2) | {"m0"})
+    g.salu(f"s_add_u32 m0, {s(S_DST)}, 0", regs("s", S_DST), {"m0"})
+    g.vmem_dma(f"global_load_lds_dword {v(V_STOFF)}, {s(S_STB, 2)}", "dma_first", regs("v", V_STOFF) | regs("s", S_STB, 2) | {"m0"})
+    P_V0, P_K1, P_V1 = S_T + 2, S_T + 4, S_T + 6
+    g.salu(f"s_add_u32 {s(P_V0)}, {s(S_KVB)}, {s(S_DV)}", regs("s", S_KVB) | regs("s", S_DV), regs("s", P_V0))
+    g.salu(f"s_addc_u32 {s(P_V0 + 1)}, {s(S_KVB + 1)}, 0", regs("s", S_KVB + 1), regs("s", P_V0 + 1))
+    g.salu(f"s_add_u32 {s(P_K1)}, {s(S_KVB)}, {s(S_QSTEP)}", regs("s", S_KVB) | regs("s", S_QSTEP), regs("s", P_K1))
+    g.salu(f"s_addc_u32 {s(P_K1 + 1)}, {s(S_KVB + 1)}, 0", regs("s", S_KVB + 1), regs("s", P_K1 + 1))
+    g.salu(f"s_add_u32 {s(P_V1)}, {s(P_K1)}, {s(S_DV)}", regs("s", P_K1) | regs("s", S_DV), regs("s", P_V1))
+    g.salu(f"s_addc_u32 {s(P_V1 + 1)}, {s(P_K1 + 1)}, 0", regs("s", P_K1 + 1), regs("s", P_V1 + 1))
+    for u, (pk, pv) in enumerate(((S_KVB, P_V0), (P_K1, P_V1))):
+        for ks in range(4):
+            dk, dv_ = A_KF + 4 * (4 * u + ks), A_VF + 4 * (4 * u + ks)
+            g.vmem_load(f"global_load_dwordx4 {a(dk, 4)}, {v(V_KOFF)}, {s(pk, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", pk, 2), regs("a", dk, 4))
+            g.vmem_load(f"global_load_dwordx4 {a(dv_, 4)}, {v(V_KOFF)}, {s(pv, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", pv, 2), regs("a", dv_, 4))
+    for slot in range(3):
+        for ks in range(4):
+            dst = A_E + 4 * (4 * slot + ks)
+            g.vmem_load(f"global_load_dwordx4 {a(dst, 4)}, {v(V_L16)}, {s(S_EFA, 2)} offset:{1024 * ks}", "e0", regs("v", V_L16) | regs("s", S_EFA, 2), regs("a", dst, 4))
+    # ... and the lane-dependent constants are formed while they are in flight
+    g.salu(f"s_mov_b32 {s(S_KEXP)}, 0x3e38aa3b", (), regs("s", S_KEXP))         # 0.125 * log2(e) = 0x3fb8aa3b / 8, exact
+    g.salu(f"s_add_u32 {s(S_T)}, {s(S_I)}, 1", regs("s", S_I), regs("s", S_T))                                              # dS offset of tile row I = I0:
+    g.salu(f"s_mul_i32 {s(S_T)}, {s(S_T)}, {s(S_I)}", regs("s", S_T) | regs("s", S_I), regs("s", S_T))                      #   I (I + 1) / 2 * 2048
     g.salu(f"s_lshl_b32 {s(S_DSOFF)}, {s(S_T)}, 10", regs("s", S_T), regs("s", S_DSOFF))
+    g.salu(f"s_or_b32 {s(S_PADANY)}, {s(S_PW)}, {s(S_PW + 1)}", regs("s", S_PW, 2), regs("s", S_PADANY))
+    g.valu(f"v_mov_b32_e32 {v(V_NEGINF)}, 0xff800000", set(), regs("v", V_NEGINF))
     # masks: lanes whose key (lane & 31) <= query crow(r, hh) ; skew source lanes rd[r] = (32 hh + ((crow - bl) & 31)) * 4
     BL, HH4, HH128, X = V_TMP + 3, V_TMP + 4, V_TMP + 5, V_TMP + 6
     g.valu(f"v_and_b32_e32 {v(BL)}, 31, {v(V_TMP)}", regs("v", V_TMP), regs("v", BL))
     g.valu(f"v_lshrrev_b32_e32 {v(HH4)}, 5, {v(V_TMP)}", regs("v", V_TMP), regs("v", HH4))
     g.valu(f"v_lshlrev_b32_e32 {v(HH128)}, 7, {v(HH4)}", regs("v", HH4), regs("v", HH128))       # 32 hh * 4
     g.valu(f"v_lshlrev_b32_e32 {v(HH4)}, 2, {v(HH4)}", regs("v", HH4), regs("v", HH4))           # 4 hh
+    for u in range(2):                           # lanes whose key is padded: bit (lane & 31) of the key tile's pad word
+        g.valu(f"v_lshrrev_b32_e64 {v(X)}, {v(BL)}, {s(S_PW + u)}", regs("v", BL) | regs("s", S_PW + u), regs("v", X))
+        g.valu(f"v_and_b32_e32 {v(X)}, 1, {v(X)}", regs("v", X), regs("v", X))
+        g.valu(f"v_cmp_ne_u32_e64 {s(S_PADM + 2 * u, 2)}, 0, {v(X)}", regs("v", X), regs("s", S_PADM + 2 * u, 2))
     for r in range(16):
         g.valu(f"v_add_u32_e32 {v(X)}, {crow(r)}, {v(HH4)}", regs("v", HH4), regs("v", X))                             # crow(r, hh)
         g.valu(f"v_cmp_le_u32_e64 {s(S_MASK + 2 * r, 2)}, {v(BL)}, {v(X)}", regs("v", BL) | regs("v", X), regs("s", S_MASK + 2 * r, 2))
         g.valu(f"v_sub_u32_e32 {v(X)}, {v(X)}, {v(BL)}", regs("v", X) | regs("v", BL), regs("v", X))
         g.valu(f"v_and_b32_e32 {v(X)}, 31, {v(X)}", regs("v", X), regs("v", X))
         g.valu(f"v_lshl_add_u32 {v(V_RD + r)}, {v(X)}, 2, {v(HH128)}", regs("v", X) | regs("v", HH128), regs("v", V_RD + r))
-    # K / V row fragments of the wave's two key tiles
-    for u in range(2):
-        if u == 1:
-            g.salu(f"s_add_u32 {s(S_KVB)}, {s(S_KVB)}, {s(S_QSTEP)}", regs("s", S_KVB) | regs("s", S_QSTEP), regs("s", S_KVB))
-            g.salu(f"s_addc_u32 {s(S_KVB + 1)}, {s(S_KVB + 1)}, 0", regs("s", S_KVB + 1), regs("s", S_KVB + 1))
-        g.salu(f"s_add_u32 {s(S_T + 2)}, {s(S_KVB)}, {s(S_DV)}", regs("s", S_KVB) | regs("s", S_DV), regs("s", S_T + 2))
-        g.salu(f"s_addc_u32 {s(S_T + 3)}, {s(S_KVB + 1)}, 0", regs("s", S_KVB + 1), regs("s", S_T + 3))
-        for ks in range(4):
-            dk, dv_ = A_KF + 4 * (4 * u + ks), A_VF + 4 * (4 * u + ks)
-            g.vmem_load(f"global_load_dwordx4 {a(dk, 4)}, {v(V_KOFF)}, {s(S_KVB, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", S_KVB, 2), regs("a", dk, 4))
-            g.vmem_load(f"global_load_dwordx4 {a(dv_, 4)}, {v(V_KOFF)}, {s(S_T + 2, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", S_T + 2, 2), regs("a", dv_, 4))
-        g.raw("s_waitcnt vmcnt(0)")              # (S_T+2 is rewritten for the second tile)
-        g.vm_done = len(g.vm)
-    # E chunks of the first tile's products: chunk n0 - wk - k in slot (n0 - k) % 3, k = 0..2 (n0 = 4)
-    for k in range(3):
-        slot = (4 - k) % 3
-        g.salu(f"s_sub_u32 {s(S_T)}, {s(S_N)}, {s(S_WK)}", regs("s", S_N) | regs("s", S_WK), regs("s", S_T))
-        if k:
-            g.salu(f"s_sub_u32 {s(S_T)}, {s(S_T)}, {k}", regs("s", S_T), regs("s", S_T))
-        g.salu(f"s_lshl_b32 {s(S_T)}, {s(S_T)}, 12", regs("s", S_T), regs("s", S_T))
-        g.salu(f"s_add_u32 {s(S_T + 2)}, {s(S_EFA)}, {s(S_T)}", regs("s", S_EFA) | regs("s", S_T), regs("s", S_T + 2))
-        g.salu(f"s_addc_u32 {s(S_T + 3)}, {s(S_EFA + 1)}, 0", regs("s", S_EFA + 1), regs("s", S_T + 3))
-        for ks in range(4):
-            dst = A_E + 4 * (4 * slot + ks)
-            g.vmem_load(f"global_load_dwordx4 {a(dst, 4)}, {v(V_L16)}, {s(S_T + 2, 2)} offset:{1024 * ks}", "e0", regs("v", V_L16) | regs("s", S_T + 2, 2), regs("a", dst, 4))
-        g.raw("s_waitcnt vmcnt(0)")
-        g.vm_done = len(g.vm)
-    # tile n0 -> buffer 0 (the fill iteration then requests tile n0 + 1 into buffer 1): the DMA code of variant 5 with n - 2
-    g.raw("s_barrier")                           # the other wave has left whatever used the LDS buffers before
-    g.salu(f"s_sub_u32 {s(S_N)}, {s(S_N)}, 2", regs("s", S_N), regs("s", S_N))
-    st = Step(g, 4)                              # variant 4: n even -> DMA destination buffer 0
-    for f in st.dma_addr() + st.dma("dma_first"):
-        f()
-    g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))       # n = n0 - 1: the fill iteration
+    g.salu(f"s_mov_b32 {s(S_N)}, -1", (), regs("s", S_N))                            # the fill iteration: "tile -1"
     g.drain()
     g.raw("s_barrier")
+
+
+def loop_tail(g: Gen, b: int, masked: bool):
+    nb = (b + 1) % 6
+    g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))
+    g.salu(f"s_cmp_ge_u32 {s(S_N)}, {s(S_NT)}", regs("s", S_N) | regs("s", S_NT), {"scc"})
+    g.raw("s_cbranch_scc1 L_dkv_end_%=")
+    if not masked:
+        if b == 5:
+            g.raw("s_branch L_dkv_u0_%=")
+        return
+    # a wave stays in the masked bodies while one of its keys is padded or a sub-tile is not below its diagonal yet (n - wk < 2)
+    g.salu(f"s_cmp_lg_u32 {s(S_PADANY)}, 0", regs("s", S_PADANY), {"scc"})
+    g.raw(f"s_cbranch_scc1 L_dkv_m{nb}_%=")
+    g.salu(f"s_sub_u32 {s(S_TM)}, {s(S_N)}, {s(S_WK)}", regs("s", S_N) | regs("s", S_WK), regs("s", S_TM))
+    g.salu(f"s_cmp_lt_i32 {s(S_TM)}, 2", regs("s", S_TM), {"scc"})
+    g.raw(f"s_cbranch_scc1 L_dkv_m{nb}_%=")
+    # switch to the main bodies: their counted waits assume the main loop's own history, so start them from a drained state
+    g.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    g.raw("s_nop 7")
+    g.raw("s_nop 7")
+    if STAMP:
+        g.stamp(None)
+    g.raw(f"s_branch L_dkv_u{nb}_%=")
+
+
+def fixed_point_loop(g: Gen, masked: bool):
+    """three rounds over the six bodies: the second reaches the loop-carried state of the wait / hazard trackers, the third is emitted"""
+    texts = []
+    for rnd in range(3):
+        g.out = []
+        for b in range(6):
+            g.out.append(f"L_dkv_{'m' if masked else 'u'}{b}_%=:")
+            body(g, b, masked=masked)
+            if STAMP and not masked:
+                g.raw(f"v_add_u32_e32 {v(V_STAMP + 7)}, 1, {v(V_STAMP + 7)}")
+            loop_tail(g, b, masked)
+        texts.append(list(g.out))
+    assert texts[1] == texts[2], "the loop body is not a fixed point of the wait-count / hazard trackers"
+    return texts[2]
 
 
 def generate():
     g = Gen()
     prologue(g)
-    # pipeline fill = variant 5 (n = n0 - 1 = 3: buffer 1, E rotation 0) without the tile-n part
+    # pipeline fill = variant 5 (n = -1: buffer 1, E rotation of n = 5) without the tile-n part
     body(g, 5, do_cur=False)
     g.drain()
     g.nop(16)
-    g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))       # n = n0
+    g.salu(f"s_mov_b32 {s(S_N)}, 0", (), regs("s", S_N))
+    if STAMP:
+        for k in range(8):
+            g.raw(f"v_mov_b32_e32 {v(V_STAMP + k)}, 0")
     pro_lines = list(g.out)
-    # the loop: two rounds to reach the loop-carried state of the wait / hazard trackers, the third is the one emitted
-    texts = []
-    for rnd in range(3):
-        g.out = []
-        for b in range(6):
-            g.out.append(f"L_dkv_b{b}_%=:")
-            body(g, b)
-            g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))
-            g.salu(f"s_cmp_ge_u32 {s(S_N)}, {s(S_NT)}", regs("s", S_N) | regs("s", S_NT), {"scc"})
-            g.raw(f"s_cbranch_scc1 L_dkv_end_%=")
-        g.raw("s_branch L_dkv_b0_%=")
-        texts.append(list(g.out))
-    assert texts[1] == texts[2], "the loop body is not a fixed point of the wait-count / hazard trackers"
-    loop_lines = texts[2]
+    m_lines = fixed_point_loop(g, masked=True)       # entered at n = 0 (dq0 = -wk <= 0: always a masked step)
+    g.drain()                                        # (tracker state only: the main loop is entered through the drains of loop_tail)
+    u_lines = fixed_point_loop(g, masked=False)
     g.out = []
     g.out.append("L_dkv_end_%=:")
     g.drain()
+    if STAMP:                                    # sums -> parameter block + 3584 (+ 4 k); v246.. hold the same value in every lane
+        g.raw(f"v_mov_b32_e32 {v(V_TMP)}, %8")
+        for k in range(8):
+            g.raw(f"ds_write_b32 {v(V_TMP)}, {v(V_STAMP + k)} offset:{3584 + 4 * k}")
+        g.raw("s_waitcnt lgkmcnt(0)")
     g.nop(16)                                    # the accumulators are read by compiler code behind the block
     g.raw("s_barrier")
-    return pro_lines + loop_lines + g.out, g
+    return pro_lines + m_lines + u_lines + g.out, g
 
 
 def clobbers():
     c = [f"v{i}" for i in range(V_FIRST, V_LAST + 1)] + [f"a{i}" for i in range(A_FIRST, A_LAST + 1)]
-    c += [f"s{i}" for i in range(S_FIRST, S_LAST + 1)] + ["vcc", "scc", "m0", "memory"]
+    c += [f"s{i}" for i in range(S_FIRST, S_LAST + 1)] + ["vcc", "scc", "m0", "memory"]       # (EXEC is restored to all ones by every item that clears it)
+    if STAMP:
+        c += [f"v{i}" for i in range(V_STAMP, V_STAMP + 8)] + [f"s{i}" for i in range(S_STAMP, S_STAMP + 4)]
     return c
 
 
 def main():
-    lines, g = generate()
+    global STAMP, PEEL
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "rel_attn_dkv64_loop.inc")
+    if not (ST_PINS or ST_CACHE != "nt"):
+        for STAMP in (False, True):
+            write(here)
+    STAMP = False
+    PEEL = int(os.environ.get("MGX_DKV64_PEEL", "0"))
+    if PEEL or ST_PINS or ST_CACHE != "nt":          # experiment builds: a loop of their own, never the tracked one
+        PEEL = PEEL or 1 << 20
+        write(here)
+
+
+def write(here):
+    lines, g = generate()
+    path = os.path.join(here, "rel_attn_dkv64_loop_peel.inc" if PEEL else "rel_attn_dkv64_loop_stamp.inc" if STAMP else "rel_attn_dkv64_loop.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by gen_dkv_asm.py -- do not edit.  The hand-scheduled main loop of rel_attn_dkv64_kernel (one asm statement):\n")
         f.write("// operands %0..%7 = dk[0][0], dk[0][1], dv[0][0], dv[0][1], dk[1][0], dk[1][1], dv[1][0], dv[1][1] (\"+a\"), %8 = LDS address of the\n")
