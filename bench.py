@@ -311,12 +311,13 @@ def pmc_traffic(kernel, B, L, d):
     FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
     Only reported when this run has a shape the counters were collected on (cfg2 at the per-GPU batch in the file name)."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(prof, f) for f in (f"r04_traffic_cfg2_b{B}.json", f"r03_traffic_cfg2_b{B}.json", f"r02_traffic_cfg2_b{B}.json", f"r01_traffic_cfg2_b{B}.json")
+    path = next((os.path.join(prof, f) for f in (f"r05_traffic_cfg2_b{B}.json", f"r04_traffic_cfg2_b{B}.json", f"r03_traffic_cfg2_b{B}.json", f"r02_traffic_cfg2_b{B}.json", f"r01_traffic_cfg2_b{B}.json")
                  if os.path.exists(os.path.join(prof, f))), None)
     if path is None or (L, d) != (2048, 512):
         return {"traffic": None}
     k = json.load(open(path))["kernels"]
-    match = [n for n in k if kernel in n]
+    sym = "rel_attn_dkv64_kernel" if (kernel == "rel_attn_dkv_kernel" and L % 128 == 0) else kernel      # the symbol this shape launches
+    match = [n for n in k if sym in n]
     if not match:
         return {"traffic": None}
     heads = d // 64
@@ -514,7 +515,8 @@ def main():
         # (half-empty) chunk product of de_tiles
         credited = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dkv_kernel": 3.0, "rel_attn_dq_lite_kernel": 2.0,
                     "rel_attn_de_tiles_kernel": 1.0}
-        executed = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dkv_kernel": 6.0, "rel_attn_dq_lite_kernel": 2.0,
+        # (the 64-key dK/dV kernel runs three Q.Er^T chunk products per pair of key tiles instead of four: 5.5 units; the 32-key one 6)
+        executed = {"rel_attn_fwd_kernel": 3.0, "rel_attn_dkv_kernel": 5.5 if L % 128 == 0 else 6.0, "rel_attn_dq_lite_kernel": 2.0,
                     "rel_attn_de_tiles_kernel": 1.25}
         per_kernel = {k: {"ms": kt[k], "credited_tflops": attn_flops_per_launch(B, L, d, credited[k]) / (kt[k] * 1e-3) / 1e12,
                           "executed_tflops": attn_flops_per_launch(B, L, d, executed[k]) / (kt[k] * 1e-3) / 1e12}
@@ -523,7 +525,8 @@ def main():
         # algorithmic share of the products it computes (no credit for recomputing S/P/dP or for the second Q.Er^T
         # chunk); executed units count every MFMA product it runs.  The op it belongs to (ONE C-ABI call,
         # mgx_rel_attn_bwd = pre-pass + dK/dV + dQ + dE kernels, 6 credited units) is reported beside it.
-        kernel_symbol = {"rel_attn_fwd_kernel": "rel_attn_fwd_kernel<false>", "rel_attn_dkv_kernel": "rel_attn_dkv_kernel<true>",
+        kernel_symbol = {"rel_attn_fwd_kernel": "rel_attn_fwd_kernel<false>",
+                         "rel_attn_dkv_kernel": "rel_attn_dkv64_kernel" if L % 128 == 0 else "rel_attn_dkv_kernel<true>",
                          "rel_attn_dq_lite_kernel": "rel_attn_dq_lite_kernel", "rel_attn_de_tiles_kernel": "rel_attn_de_tiles_kernel"}
         dom_k = max(credited, key=lambda k: kt[k])
         dom_ms = kt[dom_k]
@@ -538,17 +541,17 @@ def main():
                            "algorithmic_flops_per_launch": attn_flops_per_launch(B, L, d, credited[dom_k]),
                            "executed_tflops": exe, "executed_frac": exe / PEAK_BF16_TFLOPS,
                            "op": {"name": "mgx_rel_attn_bwd (pre-pass + dkv + dq_lite + de_tiles kernels)", "launch_ms": bwd_ms,
-                                  "credited_units": 6.0, "executed_units": 9.25,
+                                  "credited_units": 6.0, "executed_units": executed["rel_attn_dkv_kernel"] + 3.25,
                                   "achieved": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12,
                                   "frac": attn_flops_per_launch(B, L, d, 6.0) / (bwd_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}}
         out["roofline"].update(pmc_traffic(dom_k, B, L, d))
         # MFMA-busy of the attention kernels from the committed PMC passes of this shape (tools/pmc_attn.sh: SQ_VALU_MFMA_BUSY_CYCLES
         # / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)); like `traffic`, a committed measurement of this command, not of this run
-        pmc_path = os.path.join(ROOT, "profiles", f"r04_pmc_attn_b{B}.json")
-        if (L, d) == (2048, 512) and os.path.exists(pmc_path):
+        pmc_path = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"r0{r_}_pmc_attn_b{B}.json") for r_ in (5, 4)) if os.path.exists(p_)), "")
+        if (L, d) == (2048, 512) and pmc_path:
             pk = json.load(open(pmc_path))["kernels"]
             for k in per_kernel:
-                m = [v for n, v in pk.items() if k in n]
+                m = [v for n, v in pk.items() if kernel_symbol[k].split("<")[0] in n]
                 if m:
                     per_kernel[k]["mfma_busy_pmc"] = m[0]["mfma_busy_frac"]
             tw = sum(per_kernel[k]["ms"] * per_kernel[k].get("mfma_busy_pmc", 0.0) for k in per_kernel) / sum(per_kernel[k]["ms"] for k in per_kernel)
@@ -559,7 +562,7 @@ def main():
         out["attention_all_kernels"] = {
             "ms_per_layer": sum(kt.values()),
             "achieved_tflops": attn_flops_per_launch(B, L, d, 9.0) / (sum(kt.values()) * 1e-3) / 1e12,
-            "executed_tflops": attn_flops_per_launch(B, L, d, 12.25) / (sum(kt.values()) * 1e-3) / 1e12}
+            "executed_tflops": attn_flops_per_launch(B, L, d, sum(executed.values())) / (sum(kt.values()) * 1e-3) / 1e12}
     if rank == 0 and world == 1 and not args.no_cfg4 and args.workload == "cfg2":
         del mt, opt, sch, ring, last
         torch.cuda.empty_cache()

@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows; 16: mgx_smooth_ce_bwd takes a device-side scale, mgx_pad_bitmap a flag, mgx_set_deterministic */
-#define MGX_ABI_VERSION 16
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows; 16: mgx_smooth_ce_bwd takes a device-side scale, mgx_pad_bitmap a flag, mgx_set_deterministic; 17: mgx_rel_attn_bwd_parts bit 6 */
+#define MGX_ABI_VERSION 17
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -122,7 +122,9 @@ int mgx_rel_attn_bwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* pad
                      int B, int L, int d, int M, void* stream);
 /* same, running only the selected sub-kernels, in this order inside one call:
  *   bit0 (1)  pre-pass: delta = rowsum(dctx*ctx), E re-layout
- *   bit2 (4)  dK + dV; stores every dS tile in the workspace
+ *   bit2 (4)  dK + dV; stores every dS tile in the workspace (L % 128 == 0: the 64-keys-per-wave kernel whose sweep is a generated,
+ *             hand-scheduled gfx950 asm block, csrc/rel_attn_dkv64.hip; any other L: the 32-key HIP kernel)
+ *   bit6 (64) dK + dV by the 32-key HIP kernel whatever the shape (instead of bit2: cross-check, the two give the same bits)
  *   bit1 (2)  dQ from the dS tiles a bit2 run (this call or an earlier one) left in the SAME workspace
  *   bit5 (32) dQ by full recomputation instead (independent of the stored tiles: cross-check; not together with bit1)
  *   bit3 (8)  dE from the stored dS tiles

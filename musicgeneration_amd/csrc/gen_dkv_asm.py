@@ -228,6 +228,12 @@ class Gen:
             for r in reads:
                 self.store_r[r] = at
 
+    def prewait(self, touched):
+        """wait now for every outstanding load that writes a register of `touched` (the operands of a whole MFMA chain): one
+        s_waitcnt pair instead of a descending ladder in front of every MFMA of the chain"""
+        self._wait_lgkm(set(touched))
+        self._wait_vm(set(touched))
+
     # ---- instructions ----------------------------------------------------------------------------------------------
     def mfma(self, d, a_, b_, c=None, dn=16):
         """d (+)= a_ * b_; registers given as (prefix, index)"""
@@ -709,8 +715,14 @@ def body(g: Gen, b: int, do_cur: bool = True, masked: bool = False, listing=None
                     it.fn = lambda: None
     table, budget = schedule(items)
     g.comment(f"per-gap issue budget {budget}")
+    chains = {17: regs("v", V_QA, 16) | regs("a", A_E + 16 * st.slot_t0, 16)}      # MFMA index -> registers its chain of four reads
+    if do_cur:
+        chains[9] = regs("v", V_OF, 16) | regs("v", V_DP, 16)
+        chains[29] = regs("v", V_TR, 32)
     for gi in range(1, 45):
         m = mf[gi - 1]
+        if gi in chains:
+            g.prewait(chains[gi])
         if m is not None:
             m()
         if listing is not None:
@@ -757,15 +769,9 @@ def prologue(g: Gen):
     g.salu(f"s_lshl_b32 {s(S_T)}, {s(S_W)}, 8", regs("s", S_W), regs("s", S_T))
     g.salu(f"s_add_u32 {s(S_DST)}, {s(S_LDS)}, {s(S_T)}", regs("s", S_LDS) | regs("s", S_T), regs("s", S_DST))
     g.salu(f"s_add_u32 {s(S_DST)}, {s(S_DST)}, {OFF_ST}", regs("s", S_DST), regs("s", S_DST))                              # lds0 + OFF_ST + w * 256
-    # every global request of the prologue goes out now (distinct pointer pairs: no wait in between): query tile 0 -> buffer 0,
-    # the K / V row fragments of the wave's two key tiles, E chunk 0 into the three slots (the first step's products use chunks
-    # <= 0: chunk 0 or, for a sub-tile that has not started, anything)
-    for i in range(2):
-        for img, ptr, voff in ((OFF_QR, S_QB, V_QOFF + i), (OFF_OR, S_OB, V_OOFF + i)):
-            g.salu(f"s_add_u32 m0, {s(S_DQ)}, {img + 2048 * i}", regs("s", S_DQ), {"m0"})
-            g.vmem_dma(f"global_load_lds_dwordx4 {v(voff)}, {s(ptr, 2)}", "dma_first", regs("v", voff) | regs("s", ptr, 2) | {"m0"})
-    g.salu(f"s_add_u32 m0, {s(S_DST)}, 0", regs("s", S_DST), {"m0"})
-    g.vmem_dma(f"global_load_lds_dword {v(V_STOFF)}, {s(S_STB, 2)}", "dma_first", regs("v", V_STOFF) | regs("s", S_STB, 2) | {"m0"})
+    # every global request of the prologue goes out now (distinct pointer pairs: no wait in between): the K / V row fragments of the
+    # wave's two key tiles (HBM: the longest latency), query tile 0 -> buffer 0, E chunk 0 into the slot of the first step's hi chunk
+    # (its other two products use chunks < 0: sub-tiles that have not started or lanes beyond the diagonal, masked whatever they hold)
     P_V0, P_K1, P_V1 = S_T + 2, S_T + 4, S_T + 6
     g.salu(f"s_add_u32 {s(P_V0)}, {s(S_KVB)}, {s(S_DV)}", regs("s", S_KVB) | regs("s", S_DV), regs("s", P_V0))
     g.salu(f"s_addc_u32 {s(P_V0 + 1)}, {s(S_KVB + 1)}, 0", regs("s", S_KVB + 1), regs("s", P_V0 + 1))
@@ -778,10 +784,15 @@ def prologue(g: Gen):
             dk, dv_ = A_KF + 4 * (4 * u + ks), A_VF + 4 * (4 * u + ks)
             g.vmem_load(f"global_load_dwordx4 {a(dk, 4)}, {v(V_KOFF)}, {s(pk, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", pk, 2), regs("a", dk, 4))
             g.vmem_load(f"global_load_dwordx4 {a(dv_, 4)}, {v(V_KOFF)}, {s(pv, 2)} offset:{32 * ks}", "kv", regs("v", V_KOFF) | regs("s", pv, 2), regs("a", dv_, 4))
-    for slot in range(3):
-        for ks in range(4):
-            dst = A_E + 4 * (4 * slot + ks)
-            g.vmem_load(f"global_load_dwordx4 {a(dst, 4)}, {v(V_L16)}, {s(S_EFA, 2)} offset:{1024 * ks}", "e0", regs("v", V_L16) | regs("s", S_EFA, 2), regs("a", dst, 4))
+    for i in range(2):
+        for img, ptr, voff in ((OFF_QR, S_QB, V_QOFF + i), (OFF_OR, S_OB, V_OOFF + i)):
+            g.salu(f"s_add_u32 m0, {s(S_DQ)}, {img + 2048 * i}", regs("s", S_DQ), {"m0"})
+            g.vmem_dma(f"global_load_lds_dwordx4 {v(voff)}, {s(ptr, 2)}", "dma_first", regs("v", voff) | regs("s", ptr, 2) | {"m0"})
+    g.salu(f"s_add_u32 m0, {s(S_DST)}, 0", regs("s", S_DST), {"m0"})
+    g.vmem_dma(f"global_load_lds_dword {v(V_STOFF)}, {s(S_STB, 2)}", "dma_first", regs("v", V_STOFF) | regs("s", S_STB, 2) | {"m0"})
+    for ks in range(4):
+        dst = A_E + 4 * (4 * 0 + ks)             # slot 0 = the hi-chunk slot of the fill iteration (n = -1: (n + 1) % 3)
+        g.vmem_load(f"global_load_dwordx4 {a(dst, 4)}, {v(V_L16)}, {s(S_EFA, 2)} offset:{1024 * ks}", "e0", regs("v", V_L16) | regs("s", S_EFA, 2), regs("a", dst, 4))
     # ... and the lane-dependent constants are formed while they are in flight
     g.salu(f"s_mov_b32 {s(S_KEXP)}, 0x3e38aa3b", (), regs("s", S_KEXP))         # 0.125 * log2(e) = 0x3fb8aa3b / 8, exact
     g.salu(f"s_add_u32 {s(S_T)}, {s(S_I)}, 1", regs("s", S_I), regs("s", S_T))                                              # dS offset of tile row I = I0:
@@ -806,7 +817,9 @@ def prologue(g: Gen):
         g.valu(f"v_and_b32_e32 {v(X)}, 31, {v(X)}", regs("v", X), regs("v", X))
         g.valu(f"v_lshl_add_u32 {v(V_RD + r)}, {v(X)}, 2, {v(HH128)}", regs("v", X) | regs("v", HH128), regs("v", V_RD + r))
     g.salu(f"s_mov_b32 {s(S_N)}, -1", (), regs("s", S_N))                            # the fill iteration: "tile -1"
-    g.drain()
+    g.raw("s_waitcnt lgkmcnt(0)")
+    g.lgkm = []
+    g.wait_vm_tag("dma_first")                   # tile 0 has landed; the K / V and E fragments may still be in flight (first used by MFMAs)
     g.raw("s_barrier")
 
 

@@ -142,7 +142,7 @@ def _side_streams(dev):
 def rel_attn_bwd(qkv, E, padbits, ctx, dctx, lse, dE, parts=15, dqkv=None, workspace=None, concurrent=None) -> torch.Tensor:
     """-> dqkv bf16 [B,L,3d]; dE f32 [M,64] accumulated in place.  parts selects sub-kernels (bench, cross-checks):
     1 pre-pass | 4 dK/dV (stores its dS tiles in the workspace) | 2 dQ from those tiles | 8 dE from those tiles |
-    16 dE by recomputation | 32 dQ by recomputation (instead of 2).
+    16 dE by recomputation | 32 dQ by recomputation (instead of 2) | 64 dK/dV by the 32-key kernel (instead of 4: cross-check).
     concurrent (opt-in, MGX_CONCURRENT_BWD=1): after dK/dV, the two HBM-bound readers of the dS tiles (dQ, dE) run on two
     streams.  Default is one stream, which keeps per-kernel profiles comparable."""
     _need_cuda(qkv, E, padbits, ctx, dctx, lse, dE)

@@ -588,3 +588,53 @@ def test_deterministic_mode_keeps_a_nan_a_nan():
     assert torch.isnan(gw[5]).all() and torch.isnan(gb[5])
     assert torch.isfinite(gw[:5]).all() and torch.isfinite(gw[6:]).all() and torch.isfinite(gb[:5]).all() and torch.isfinite(gb[6:]).all()
     assert torch.isnan(stats[0])                                            # the loss sum
+
+
+@pytest.mark.parametrize("B,L,d", [(2, 256, 128), (1, 1024, 64), (3, 512, 192), (2, 2048, 128), (1, 640, 64)])
+def test_dkv64_matches_the_32_key_kernel_bitwise(B, L, d):
+    """The 64-keys-per-wave dK/dV kernel whose whole sweep is the generated, hand-scheduled asm block (rel_attn_dkv64.hip,
+    gen_dkv_asm.py; parts bit 2 where L % 128 == 0) against the HIP 32-key kernel (parts bit 6): the same arithmetic per tile in the
+    same accumulation order, so dk, dv and every stored dS tile -- the whole workspace -- must be equal BIT FOR BIT, without and with
+    padded keys (the masked bodies then run for every step of the padded key blocks).  L = 640: five key blocks, sweeps of 4..20 tiles
+    (every exit point of the six-body loops)."""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(L + d)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    E = (torch.randn(L, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dctx = torch.randn(B, L, d, generator=g).to(torch.bfloat16).to(dev)
+    tok = torch.zeros(B, L, dtype=torch.int32)
+    tok[0, L - 37:] = 5                                   # trailing pads in batch row 0: its last two key blocks take the masked bodies
+    tok[B - 1, L - 150:] = 5
+    n = ops._lib.load().mgx_rel_attn_bwd_workspace(B, L, d)
+    for bits in (None, ops.pad_bitmap(tok.to(dev), 5)):
+        ctx, lse = ops.rel_attn_fwd(qkv, E, bits)
+        ws1 = torch.zeros(n, dtype=torch.uint8, device=dev)
+        ws2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+        dE = torch.zeros(L, 64, device=dev)
+        dq1, dq2 = torch.zeros_like(qkv), torch.zeros_like(qkv)
+        ops.rel_attn_bwd(qkv, E, bits, ctx, dctx, lse, dE, 1 | 64, dq1, ws1)          # 32-key kernel
+        ops.rel_attn_bwd(qkv, E, bits, ctx, dctx, lse, dE, 1 | 4, dq2, ws2)           # 64-key kernel, asm sweep
+        torch.cuda.synchronize()
+        assert torch.isfinite(dq2.float()).all()
+        assert torch.equal(dq1[..., d:], dq2[..., d:]), "dk / dv"
+        assert torch.equal(ws1, ws2), "dS tiles"
+
+
+def test_dkv_falls_back_to_the_32_key_kernel_when_the_sequence_is_not_whole_key_blocks():
+    """L % 128 != 0: parts bit 2 runs the 32-key kernel (the 64-key kernel needs whole 128-key blocks) -- same bits as bit 6"""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    B, L, d = 2, 352, 64
+    g = torch.Generator().manual_seed(3)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    E = (torch.randn(L, 64, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dctx = torch.randn(B, L, d, generator=g).to(torch.bfloat16).to(dev)
+    ctx, lse = ops.rel_attn_fwd(qkv, E, None)
+    dE = torch.zeros(L, 64, device=dev)
+    a = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1 | 4)
+    b = ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 1 | 64)
+    torch.cuda.synchronize()
+    assert torch.equal(a[..., d:], b[..., d:])
+    with pytest.raises(Exception):
+        ops.rel_attn_bwd(qkv, E, None, ctx, dctx, lse, dE, 4 | 64)                   # both write dk / dv
