@@ -22,7 +22,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgx.so")
-SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_bwd.hip", "rel_attn_dkv64.hip", "linear.hip", "decode.hip", "gru_train.hip"]
+SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_fwd64.hip", "rel_attn_bwd.hip", "rel_attn_dkv64.hip", "linear.hip", "decode.hip", "gru_train.hip"]
 EXPERIMENT_DIR = os.path.join(ROOT, "tools", "experiments")
 EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip"]      # --experiments builds only
 # per-file flags.  The 64-rows-per-wave attention kernels run one wave per SIMD with the whole 512-entry register file:
@@ -60,9 +60,10 @@ def _stale(lib: str = LIB) -> bool:
 def _generate() -> None:
     """the hand-scheduled dK/dV main loop is generated code: csrc/gen_dkv_asm.py -> csrc/rel_attn_dkv64_loop.inc (tracked, so the
     schedule can be read and diffed) and ..._loop_stamp.inc (diagnostic builds; not tracked).  Regenerated on every build."""
-    r = subprocess.run([sys.executable, os.path.join(CSRC, "gen_dkv_asm.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("gen_dkv_asm.py failed:\n" + r.stdout)
+    for gen in ("gen_dkv_asm.py", "gen_fwd_asm.py"):
+        r = subprocess.run([sys.executable, os.path.join(CSRC, gen)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(gen + " failed:\n" + r.stdout)
 
 
 def _compile_and_link(lib: str, objdir: str, defines, verbose: bool, experiments: bool = False) -> None:

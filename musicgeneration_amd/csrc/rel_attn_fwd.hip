@@ -386,15 +386,19 @@ static int fwd_common_checks(const char* who, const void* ws, size_t ws_bytes, i
     return MGX_OK;
 }
 
-extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
-                                float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
-    MGX_REQUIRE(qkv && E && ctx && lse, MGX_ERR_NULL, "mgx_rel_attn_fwd: NULL pointer");
-    if (int rc = fwd_common_checks("mgx_rel_attn_fwd", workspace, ws_bytes, B, L, d, M)) return rc;
+#ifndef MGX_FWD64_DEFAULT
+#define MGX_FWD64_DEFAULT 1   // 0 (A/B builds): mgx_rel_attn_fwd launches the 32-row kernel for every shape
+#endif
+// rows64: the 64-rows-per-wave kernel whose sweep is the generated asm block (rel_attn_fwd64.hip) where the shape allows it
+static int rel_attn_fwd_impl(const char* who, bool rows64, const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
+                             float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
+    MGX_REQUIRE(qkv && E && ctx && lse, MGX_ERR_NULL, "%s: NULL pointer", who);
+    if (int rc = fwd_common_checks(who, workspace, ws_bytes, B, L, d, M)) return rc;
     set_fwd_attrs();
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
 #if MGX_EXPERIMENTS
     // experiment builds only (`_build.py --variant NAME --experiments`, tools/experiments/): for L % 256 == 0, MGX_ATTN_FWD64 = 2
-    // selects the ping-pong kernel (rel_attn_fwd3.hip), 1 the 64-rows-per-wave kernel (rel_attn_fwd2.hip); both measured slower
+    // selects the ping-pong kernel (rel_attn_fwd3.hip), 1 the 64-rows-per-wave HIP kernel (rel_attn_fwd2.hip); both measured slower
     if (L % 256 == 0) {
         const int mode = env_digit("MGX_ATTN_FWD64", 0);
         if (mode == 2) return fwdpp_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
@@ -402,6 +406,12 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
     }
 #endif
     const int bg = batch_group(B, L, d);
+    if (rows64 && L % 128 == 0 && L <= 8192) {            // (its pad-word table holds 256 key tiles)
+        const int rc = fwd64a_launch(qkv, workspace, padbits, ctx, lse, B, L, d, bg, stream);
+        if (rc != MGX_OK) return rc;
+        MGX_CHECK_LAUNCH(who);
+        return MGX_OK;
+    }
     dim3 grid(bg * (d / 64), ((L + 127) / 128) * (B / bg));
 #if MGX_EXPERIMENTS
     static const int occ_lds = [] {        // experiment: MGX_FWD_LDS pads the dynamic LDS to lower the residency (timing only)
@@ -415,8 +425,19 @@ extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const ui
 #endif
     hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), occ_lds, (hipStream_t)stream, qkv,
                        (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d, bg);
-    MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");
+    MGX_CHECK_LAUNCH(who);
     return MGX_OK;
+}
+
+extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
+                                float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
+    return rel_attn_fwd_impl("mgx_rel_attn_fwd", MGX_FWD64_DEFAULT != 0, qkv, E, padbits, ctx, lse, workspace, ws_bytes, B, L, d, M, stream);
+}
+
+// the same through the 32-rows-per-wave HIP kernel whatever the shape: cross-check of the 64-row kernel (same bits)
+extern "C" int mgx_rel_attn_fwd_rows32(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
+                                       float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
+    return rel_attn_fwd_impl("mgx_rel_attn_fwd_rows32", false, qkv, E, padbits, ctx, lse, workspace, ws_bytes, B, L, d, M, stream);
 }
 
 extern "C" int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const float* lse,
