@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows; 16: mgx_smooth_ce_bwd takes a device-side scale, mgx_pad_bitmap a flag, mgx_set_deterministic; 17: mgx_rel_attn_bwd_parts bit 6; 18: mgx_rel_attn_fwd_rows32 */
-#define MGX_ABI_VERSION 18
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows; 16: mgx_smooth_ce_bwd takes a device-side scale, mgx_pad_bitmap a flag, mgx_set_deterministic; 17: mgx_rel_attn_bwd_parts bit 6 */
+#define MGX_ABI_VERSION 17
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -99,12 +99,6 @@ size_t mgx_rel_attn_fwd_workspace(int L);
 int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
                      uint16_t* ctx, float* lse, void* workspace, size_t ws_bytes,
                      int B, int L, int d, int M, void* stream);
-/* Two kernels stand behind mgx_rel_attn_fwd and give the same bits: for L % 128 == 0 (L <= 8192) the 64-rows-per-wave kernel whose
- * sweep over the key tiles is a generated, hand-scheduled gfx950 asm block (csrc/rel_attn_fwd64.hip, gen_fwd_asm.py), otherwise the
- * 32-rows-per-wave HIP kernel.  mgx_rel_attn_fwd_rows32 (ABI 18) runs the HIP kernel whatever the shape: the cross-check.  */
-int mgx_rel_attn_fwd_rows32(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits,
-                            uint16_t* ctx, float* lse, void* workspace, size_t ws_bytes,
-                            int B, int L, int d, int M, void* stream);
 /* The reference's SAMPLING call Decoder(x, mask=None) (network.py:60-62): every query attends to every key j < Lk (no look-ahead, no
  * padding mask), the relative term is what _qe_masking + _skewing leave of it: q_i.E[M-1-(i-j)] for j <= i, 0 for j > i.  Lk <= L =
  * real length of the window; rows / keys Lk..L-1 only pad it to a multiple of 32.  Inference only.                          */

@@ -22,9 +22,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmgx.so")
-SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_fwd64.hip", "rel_attn_bwd.hip", "rel_attn_dkv64.hip", "linear.hip", "decode.hip", "gru_train.hip"]
+SOURCES = ["api.cpp", "rowwise_ops.hip", "rel_attn_fwd.hip", "rel_attn_bwd.hip", "rel_attn_dkv64.hip", "linear.hip", "decode.hip", "gru_train.hip"]
 EXPERIMENT_DIR = os.path.join(ROOT, "tools", "experiments")
-EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip"]      # --experiments builds only
+EXPERIMENT_SOURCES = ["rel_attn_fwd2.hip", "rel_attn_fwd3.hip", "rel_attn_fwd64.hip"]      # --experiments builds only
 # per-file flags.  The 64-rows-per-wave attention kernels run one wave per SIMD with the whole 512-entry register file:
 # MFMA results that VALU code reads (scores) must stay in arch VGPRs (with more than 256 registers available hipcc otherwise
 # gives every MFMA an AGPR destination and copies each result out), and the SLP vectoriser must not pair the two blocks'
@@ -57,11 +57,12 @@ def _stale(lib: str = LIB) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _generate() -> None:
+def _generate(experiments: bool = False) -> None:
     """the hand-scheduled dK/dV main loop is generated code: csrc/gen_dkv_asm.py -> csrc/rel_attn_dkv64_loop.inc (tracked, so the
     schedule can be read and diffed) and ..._loop_stamp.inc (diagnostic builds; not tracked).  Regenerated on every build."""
-    for gen in ("gen_dkv_asm.py", "gen_fwd_asm.py"):
-        r = subprocess.run([sys.executable, os.path.join(CSRC, gen)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    gens = [os.path.join(CSRC, "gen_dkv_asm.py")] + ([os.path.join(EXPERIMENT_DIR, "gen_fwd_asm.py")] if experiments else [])
+    for gen in gens:
+        r = subprocess.run([sys.executable, gen], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(gen + " failed:\n" + r.stdout)
 
@@ -69,7 +70,7 @@ def _generate() -> None:
 def _compile_and_link(lib: str, objdir: str, defines, verbose: bool, experiments: bool = False) -> None:
     hipcc = _hipcc()
     os.makedirs(objdir, exist_ok=True)
-    _generate()
+    _generate(experiments)
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
               "-I" + CSRC, "-Wno-unused-value", "-Wno-unused-result"] + list(defines)
     objs, procs = [], []

@@ -13,7 +13,7 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 # the ABI the SIGNATURES table below was written for (MGX_ABI_VERSION of include/mgx.h).  A left-over
 # libmgx.so of another ABI still exports the same names: calling it with this table would shift arguments.
-EXPECTED_ABI = 18
+EXPECTED_ABI = 17
 
 # name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
 SIGNATURES = {
@@ -26,7 +26,6 @@ SIGNATURES = {
     "mgx_pad_bitmap": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mgx_rel_attn_fwd_workspace": [_i],                  # returns size_t
     "mgx_rel_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
-    "mgx_rel_attn_fwd_rows32": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_fwd_nomask": [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp],
     "mgx_rel_attn_bwd_workspace": [_i, _i, _i],          # returns size_t

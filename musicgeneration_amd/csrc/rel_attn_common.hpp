@@ -260,7 +260,7 @@ static inline void launch_er_frag(const uint16_t* Er, u32x4* EfA, u32x4* EfT, in
 // rel_attn_dkv64.hip: dK / dV with 64 keys per wave and the generated asm main loop (L % 128 == 0)
 int dkv64_launch(const uint16_t* qkv, const void* EfA, const uint32_t* padbits, const uint16_t* dctx, const float* nlse2,
                  const float* ndelta, uint16_t* dqkv, uint16_t* dst, int B, int L, int d, int bg, void* stream);
-// rel_attn_fwd64.hip: forward with 64 query rows per wave and the generated asm sweep (L % 128 == 0, L <= 8192)
+// experiment builds only (tools/experiments/rel_attn_fwd64.hip): forward with 64 query rows per wave and a generated asm sweep
 int fwd64a_launch(const uint16_t* qkv, const void* Ef, const uint32_t* padbits, uint16_t* ctx, float* lse, int B, int L, int d, int bg,
                   void* stream);
 // experiment builds only (tools/experiments/rel_attn_fwd2.hip, rel_attn_fwd3.hip; MGX_EXPERIMENTS)

@@ -200,24 +200,27 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
     // ---- softmax of one tile against the lazy reference, then O^T += V^T P^T ------------------------
     // P^T goes straight into the bf16 operand fragments of the O^T product (k order kappa, see acc_to_frag)
     auto exp_tile = [&](const f32x16& c, float mneg, bf16x8 (&pf)[2]) {
-        float lsum = 0.f;
+        // the tile's partial row sum is formed as four interleaved chains s_j = p[j] + p[j+4] + p[j+8] + p[j+12], then (s0 + s1) + (s2 + s3):
+        // the order the hand-scheduled 64-row kernel (rel_attn_fwd64.hip) uses -- a single chain of 15 dependent adds stalls a lone
+        // wave -- so the two kernels give the same bits
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ar = __builtin_fmaf(c[r], LOG2E, mneg);
+            p[r] = (MGX_FWD_PEEL & 4) ? ar * 1e-9f : __builtin_amdgcn_exp2f(ar);
+        }
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             u32x4 wv;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float a0 = __builtin_fmaf(c[8 * ss + 2 * jj], LOG2E, mneg), a1 = __builtin_fmaf(c[8 * ss + 2 * jj + 1], LOG2E, mneg);
-                const float p0 = (MGX_FWD_PEEL & 4) ? a0 * 1e-9f : __builtin_amdgcn_exp2f(a0);
-                const float p1 = (MGX_FWD_PEEL & 4) ? a1 * 1e-9f : __builtin_amdgcn_exp2f(a1);
-                if (!(MGX_FWD_PEEL & 32)) {
-                    lsum += p0;
-                    lsum += p1;
-                }
-                wv[jj] = pack_bf16x2(p0, p1);
-            }
+            for (int jj = 0; jj < 4; ++jj) wv[jj] = pack_bf16x2(p[8 * ss + 2 * jj], p[8 * ss + 2 * jj + 1]);
             pf[ss] = __builtin_bit_cast(bf16x8, wv);
         }
-        return lsum;
+        if (MGX_FWD_PEEL & 32) return 0.f;
+        float sj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sj[j] = ((p[j] + p[j + 4]) + p[j + 8]) + p[j + 12];
+        return (sj[0] + sj[1]) + (sj[2] + sj[3]);
     };
     auto softmax_pv = [&](const f32x16& c, int cur) {
         bf16x8 pf[2];
@@ -386,32 +389,24 @@ static int fwd_common_checks(const char* who, const void* ws, size_t ws_bytes, i
     return MGX_OK;
 }
 
-#ifndef MGX_FWD64_DEFAULT
-#define MGX_FWD64_DEFAULT 1   // 0 (A/B builds): mgx_rel_attn_fwd launches the 32-row kernel for every shape
-#endif
-// rows64: the 64-rows-per-wave kernel whose sweep is the generated asm block (rel_attn_fwd64.hip) where the shape allows it
-static int rel_attn_fwd_impl(const char* who, bool rows64, const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
-                             float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
-    MGX_REQUIRE(qkv && E && ctx && lse, MGX_ERR_NULL, "%s: NULL pointer", who);
-    if (int rc = fwd_common_checks(who, workspace, ws_bytes, B, L, d, M)) return rc;
+extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
+                                float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
+    MGX_REQUIRE(qkv && E && ctx && lse, MGX_ERR_NULL, "mgx_rel_attn_fwd: NULL pointer");
+    if (int rc = fwd_common_checks("mgx_rel_attn_fwd", workspace, ws_bytes, B, L, d, M)) return rc;
     set_fwd_attrs();
     launch_er_frag(E + (size_t)(M - L) * 64, (u32x4*)workspace, nullptr, L, (hipStream_t)stream);
+    const int bg = batch_group(B, L, d);
 #if MGX_EXPERIMENTS
-    // experiment builds only (`_build.py --variant NAME --experiments`, tools/experiments/): for L % 256 == 0, MGX_ATTN_FWD64 = 2
-    // selects the ping-pong kernel (rel_attn_fwd3.hip), 1 the 64-rows-per-wave HIP kernel (rel_attn_fwd2.hip); both measured slower
-    if (L % 256 == 0) {
+    // experiment builds only (`_build.py --variant NAME --experiments`, tools/experiments/), all measured slower: MGX_ATTN_FWD64 = 3 the
+    // 64-rows-per-wave kernel with the generated asm sweep (rel_attn_fwd64.hip; L % 128 == 0, L <= 8192), 2 the ping-pong kernel
+    // (rel_attn_fwd3.hip), 1 the 64-rows-per-wave HIP kernel (rel_attn_fwd2.hip) (both L % 256 == 0)
+    {
         const int mode = env_digit("MGX_ATTN_FWD64", 0);
-        if (mode == 2) return fwdpp_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
-        if (mode == 1) return fwd64_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
+        if (mode == 3 && L % 128 == 0 && L <= 8192) return fwd64a_launch(qkv, workspace, padbits, ctx, lse, B, L, d, bg, stream);
+        if (mode == 2 && L % 256 == 0) return fwdpp_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
+        if (mode == 1 && L % 256 == 0) return fwd64_launch(qkv, workspace, padbits, ctx, lse, B, L, d, stream);
     }
 #endif
-    const int bg = batch_group(B, L, d);
-    if (rows64 && L % 128 == 0 && L <= 8192) {            // (its pad-word table holds 256 key tiles)
-        const int rc = fwd64a_launch(qkv, workspace, padbits, ctx, lse, B, L, d, bg, stream);
-        if (rc != MGX_OK) return rc;
-        MGX_CHECK_LAUNCH(who);
-        return MGX_OK;
-    }
     dim3 grid(bg * (d / 64), ((L + 127) / 128) * (B / bg));
 #if MGX_EXPERIMENTS
     static const int occ_lds = [] {        // experiment: MGX_FWD_LDS pads the dynamic LDS to lower the residency (timing only)
@@ -425,19 +420,8 @@ static int rel_attn_fwd_impl(const char* who, bool rows64, const uint16_t* qkv, 
 #endif
     hipLaunchKernelGGL(rel_attn_fwd_kernel<false>, grid, dim3(256), occ_lds, (hipStream_t)stream, qkv,
                        (const u32x4*)workspace, padbits, ctx, lse, (const float*)nullptr, (float*)nullptr, L, d, bg);
-    MGX_CHECK_LAUNCH(who);
+    MGX_CHECK_LAUNCH("mgx_rel_attn_fwd");
     return MGX_OK;
-}
-
-extern "C" int mgx_rel_attn_fwd(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
-                                float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
-    return rel_attn_fwd_impl("mgx_rel_attn_fwd", MGX_FWD64_DEFAULT != 0, qkv, E, padbits, ctx, lse, workspace, ws_bytes, B, L, d, M, stream);
-}
-
-// the same through the 32-rows-per-wave HIP kernel whatever the shape: cross-check of the 64-row kernel (same bits)
-extern "C" int mgx_rel_attn_fwd_rows32(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, uint16_t* ctx,
-                                       float* lse, void* workspace, size_t ws_bytes, int B, int L, int d, int M, void* stream) {
-    return rel_attn_fwd_impl("mgx_rel_attn_fwd_rows32", false, qkv, E, padbits, ctx, lse, workspace, ws_bytes, B, L, d, M, stream);
 }
 
 extern "C" int mgx_rel_attn_weights(const uint16_t* qkv, const uint16_t* E, const uint32_t* padbits, const float* lse,

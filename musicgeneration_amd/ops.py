@@ -85,9 +85,8 @@ def embed_bwd(tok, dout, dtable, p_drop=0.0, seed=0):
                                     stream_ptr()), "mgx_embed_bwd")
 
 
-def rel_attn_fwd(qkv, E, padbits, M=None, rows32: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
-    """qkv bf16 [B,L,3d], E bf16 [M,64], padbits int32 [B,L/32] or None -> (ctx bf16 [B,L,d], lse f32 [B,h,L]).
-    rows32: the 32-rows-per-wave HIP kernel whatever the shape (cross-check of the 64-row asm kernel: same bits)"""
+def rel_attn_fwd(qkv, E, padbits, M=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """qkv bf16 [B,L,3d], E bf16 [M,64], padbits int32 [B,L/32] or None -> (ctx bf16 [B,L,d], lse f32 [B,h,L])"""
     _need_cuda(qkv, E, padbits)
     B, L, d3 = qkv.shape
     d = d3 // 3
@@ -96,8 +95,8 @@ def rel_attn_fwd(qkv, E, padbits, M=None, rows32: bool = False) -> Tuple[torch.T
     lse = torch.empty(B, d // 64, L, dtype=torch.float32, device=qkv.device)
     lib = _lib.load()
     ws = torch.empty(lib.mgx_rel_attn_fwd_workspace(L), dtype=torch.uint8, device=qkv.device)
-    fn = lib.mgx_rel_attn_fwd_rows32 if rows32 else lib.mgx_rel_attn_fwd
-    check(fn(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(lse), ptr(ws), ws.numel(), B, L, d, M, stream_ptr()), "mgx_rel_attn_fwd")
+    check(lib.mgx_rel_attn_fwd(ptr(qkv), ptr(E), ptr(padbits), ptr(ctx), ptr(lse), ptr(ws), ws.numel(), B, L, d, M,
+                               stream_ptr()), "mgx_rel_attn_fwd")
     return ctx, lse
 
 

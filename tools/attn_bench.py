@@ -39,9 +39,9 @@ def timed(fn, units, name):
     print(f"{name:8s} {ms:8.3f} ms   executed {units*unit/ms/1e9:8.1f} TF/s ({units} units)")
 if a.parts & 1:
     for _ in range(a.rounds):          # interleaved rounds in one process (A/B)
-        timed(lambda: ops.rel_attn_fwd(qkv, E, None), 3, "fwd")                       # 64-row asm kernel where L % 128 == 0
-        timed(lambda: ops.rel_attn_fwd(qkv, E, None, rows32=True), 3, "fwd32")        # the 32-row HIP kernel
+        timed(with_env("MGX_ATTN_FWD64", "0", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd32")
         if not a.fwd_variants: continue
+        timed(with_env("MGX_ATTN_FWD64", "3", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd64asm")
         timed(with_env("MGX_ATTN_FWD64", "1", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwd64")
         timed(with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None)), 3, "fwdpp")
         timed(with_env("MGX_ATTN_PP_RIGID", "1", with_env("MGX_ATTN_FWD64", "2", lambda: ops.rel_attn_fwd(qkv, E, None))), 3, "fwdpp_r")

@@ -1,10 +1,22 @@
-"""Parity of the 64-rows-per-wave forward kernel with the generated asm sweep (csrc/rel_attn_fwd64.hip; mgx_rel_attn_fwd where
-L % 128 == 0) with the 32-row HIP kernel (mgx_rel_attn_fwd_rows32): ctx and lse must be bit-identical, without and with padded keys,
-and on inputs that force the lazy-softmax redo late in the sweep.  GPU box:   python tools/check_fwd64.py"""
+"""Parity of the experimental 64-rows-per-wave forward kernel with the generated asm sweep (tools/experiments/rel_attn_fwd64.hip,
+MGX_ATTN_FWD64=3 in an experiment build) with the product's 32-row HIP kernel: ctx and lse must be bit-identical, without and with
+padded keys, and on inputs that force the lazy-softmax redo late in the sweep.
+    python -m musicgeneration_amd._build --variant exp --experiments          (here)
+    MGX_LIB_PATH=musicgeneration_amd/libmgx_exp.so python tools/experiments/check_fwd64.py        (GPU box)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from musicgeneration_amd import ops
+
+
+def fwd(q, E, bits, rows64):
+    os.environ["MGX_ATTN_FWD64"] = "3" if rows64 else "0"
+    try:
+        return ops.rel_attn_fwd(q, E, bits)
+    finally:
+        os.environ.pop("MGX_ATTN_FWD64", None)
+
+
 dev = torch.device("cuda")
 ok = True
 for (B, L, d) in ((1, 128, 64), (1, 256, 64), (2, 256, 128), (1, 1024, 64), (3, 512, 192), (2, 2048, 128), (1, 640, 64)):
@@ -19,8 +31,8 @@ for (B, L, d) in ((1, 128, 64), (1, 256, 64), (2, 256, 128), (1, 1024, 64), (3, 
             q[B - 1, L - 70, :64] = 3.0; q[B - 1, 40, d:d + 64] = 5.0
         q = q.to(dev)
         bits = ops.pad_bitmap(tok.to(dev), 5) if case == "pad" else None
-        c1, l1 = ops.rel_attn_fwd(q, E, bits, rows32=True)
-        c2, l2 = ops.rel_attn_fwd(q, E, bits)
+        c1, l1 = fwd(q, E, bits, False)
+        c2, l2 = fwd(q, E, bits, True)
         torch.cuda.synchronize()
         e1, e2 = torch.equal(c1, c2), torch.equal(l1, l2)
         ok &= e1 and e2

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled gfx950 sweep of the 64-rows-per-wave forward attention kernel (rel_attn_fwd64.hip).
+EXPERIMENT (round 5): correct -- ctx and lse bit-identical to the product's 32-row HIP kernel, padding and lazy-softmax redo
+included (check_fwd64.py) -- and NOT faster: 0.603 ms against 0.559 at cfg2 / batch 64 on one box (main body 1,870 stamped cycles
+per pair of tiles = the HIP kernel's 890 per tile; 11 % of a wave's time in the latency-exposed prologue + pipeline fill, which
+three workgroups per CU hide for the HIP kernel and one wave per SIMD cannot).  Built only by `_build.py --experiments`
+(MGX_ATTN_FWD64=3 selects it); kept with its stamp tool as the record of that measurement.
 
-    python musicgeneration_amd/csrc/gen_fwd_asm.py            -> musicgeneration_amd/csrc/rel_attn_fwd64_loop.inc
+    python tools/experiments/gen_fwd_asm.py            -> tools/experiments/rel_attn_fwd64_loop.inc
 
 Math, LDS images and the rotated fp32 band are those of rel_attn_fwd.hip (the 32-rows-per-wave HIP kernel, which stays the kernel
 for L % 128 != 0, the no-mask inference call and the weights output); results are bit-identical to it.  A wave owns TWO query
@@ -25,7 +30,7 @@ from __future__ import annotations
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "musicgeneration_amd", "csrc"))
 from asm_sched import COST, Gen, Item, a, chain, crow, regs, s, salu_items, schedule, v  # noqa: E402
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -45,7 +50,8 @@ V_QE = 64            # ..95  chunk products qeA | qeB
 V_S = (96, 128)      # two sets: sA | sB (scores of tile t in set t & 1)
 V_P = (160, 192)     # two sets: pA | pB (exponentials; the bf16 operand fragments are packed in place)
 V_MNEG, V_M, V_L, V_LSUM = 224, 226, 228, 230      # (+ X): -m log2e | m | l | partial row sum of the tile
-V_TMP = 232          # ..245 temporaries (prologue, redo)
+V_TMP = 232          # ..233, 242..245 temporaries (prologue, redo, pad)
+V_SUMT = 234         # ..241 the four partial chains of a tile's row sum (A | B)
 V_FIRST, V_LAST = 16, 245
 
 A_O = 128            # O^T accumulators: oA0 | oA1 | oB0 | oB1
@@ -151,11 +157,23 @@ class Step:
         return out
 
     def sum_items(self, t, X):
-        p, ls = self.pset(t, X), V_LSUM + X
-        out = [lambda: self.g.valu(f"v_add_f32_e32 {v(ls)}, {v(p)}, {v(p + 1)}", regs("v", p, 2), regs("v", ls))]
-        for r in range(2, 16):
-            out.append(lambda r=r: self.g.valu(f"v_add_f32_e32 {v(ls)}, {v(ls)}, {v(p + r)}", regs("v", ls) | regs("v", p + r), regs("v", ls)))
-        return out
+        """partial row sum of the tile, in the order of rel_attn_fwd.hip (exp_tile): four interleaved chains c_j = p[j] + p[j+4] + p[j+8] +
+        p[j+12] (independent: a single chain of 15 dependent adds stalls a lone wave), then (c0 + c1) + (c2 + c3).  Returns (items, deps):
+        deps[k] = the elements item k reads"""
+        p, ls, c = self.pset(t, X), V_LSUM + X, V_SUMT + 4 * X
+        out, need = [], []
+        for j in range(4):
+            out.append(lambda j=j: self.g.valu(f"v_add_f32_e32 {v(c + j)}, {v(p + j)}, {v(p + j + 4)}", regs("v", p + j) | regs("v", p + j + 4), regs("v", c + j)))
+            need.append((j, j + 4))
+        for k in (8, 12):
+            for j in range(4):
+                out.append(lambda j=j, k=k: self.g.valu(f"v_add_f32_e32 {v(c + j)}, {v(c + j)}, {v(p + j + k)}", regs("v", c + j) | regs("v", p + j + k), regs("v", c + j)))
+                need.append((j + k,))
+        out.append(lambda: self.g.valu(f"v_add_f32_e32 {v(c)}, {v(c)}, {v(c + 1)}", regs("v", c, 2), regs("v", c)))
+        out.append(lambda: self.g.valu(f"v_add_f32_e32 {v(c + 2)}, {v(c + 2)}, {v(c + 3)}", regs("v", c + 2, 2), regs("v", c + 2)))
+        out.append(lambda: self.g.valu(f"v_add_f32_e32 {v(ls)}, {v(c)}, {v(c + 2)}", regs("v", c) | regs("v", c + 2), regs("v", ls)))
+        need += [(), (), ()]
+        return out, need
 
     def check_item(self, t, X, site):
         """!(lsum <= L_SAFE) in any lane -> redo the tile against its true maximum (out of line), then l += lsum"""
@@ -244,7 +262,7 @@ class Step:
     def padword_items(self):
         """pad word of key tile min(t1, 255) from the LDS table -> S_PW (0 when the batch row has no padded key)"""
         g = self.g
-        T = V_TMP + 12
+        T = 242
 
         def rd():
             g.salu(f"s_add_u32 {s(S_TM)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_TM))
@@ -277,7 +295,7 @@ class Step:
         """padded keys of tile t1 (pad word != 0): s[r] = min(s[r], -1e9) in the lane half whose key is padded (the reference's additive
         mask; future keys stay -inf).  Key of register r in half hh: crow(r, 0) + 4 hh.  ONE item with its own skip branch."""
         g = self.g
-        T = V_TMP + 12
+        T = 244
 
         def f():
             g.salu(f"s_cmp_eq_u32 {s(S_PW)}, 0", regs("s", S_PW), {"scc"})
@@ -326,10 +344,14 @@ def body(g: Gen, b: int, n_min: int = 0, masked: bool = False, site_base: int = 
             if k & 1:
                 it.deps.append(exB[k - 1])
         for X in range(2):
-            sm = chain(add(st.sum_items(st.t0, X), COST["valu"], earliest=1, deadline=8 + 4 * X, name=f"sum{X}"))
+            fns, need = st.sum_items(st.t0, X)
+            sm = add(fns, COST["valu"], earliest=1, deadline=8 + 4 * X, name=f"sum{X}")
+            for k in range(4, 15):                          # program order inside each chain / the final tree
+                sm[k].deps.append(sm[k - 4] if k < 12 else sm[8 + 2 * (k - 12)] if k < 14 else sm[12])
+            sm[12].deps.append(sm[9]); sm[13].deps += [sm[10], sm[11]]; sm[14].deps.append(sm[13])
             if X == 1:
-                for r in range(8, 16):
-                    sm[r - 1].deps.append(exB[2 * (r - 8) + 1])      # link r - 1 adds element r
+                for k, els in enumerate(need):
+                    sm[k].deps += [exB[2 * (r - 8) + 1] for r in els if r >= 8]
             ck = add(st.check_item(st.t0, X, site_base + 2 * b + X), 3 * COST["valu"], earliest=3, deadline=9 + 4 * X, deps=sm[-1:], name=f"check{X}")
             pk = add(st.pack_items(st.t0, X), COST["valu"], earliest=3, deadline=14 + 2 * X, deps=ck, name=f"pack{X}")
             chk[X] = ck[0]
@@ -386,8 +408,8 @@ def body(g: Gen, b: int, n_min: int = 0, masked: bool = False, site_base: int = 
             m()
         for it in table[gi]:
             it.fn()
-        if STAMP and not masked and n_min == 0 and gi in (8, 16, 24):
-            g.stamp({8: 0, 16: 1, 24: 2}[gi])
+        if STAMP and n_min == 0 and gi in (8, 16, 24):
+            g.stamp({8: 0, 16: 1, 24: 2}[gi] + (3 if masked else 0))
 
 
 def redo_block(X: int, par: int, nsites: int):
@@ -396,7 +418,7 @@ def redo_block(X: int, par: int, nsites: int):
     softmax_pv).  Own tracker: everything it touches is complete at the call sites (see body), it waits for its own LDS operation."""
     g = Gen()
     sr, p = V_S[par] + 16 * X, V_P[par] + 16 * X
-    T, T2, AL = V_TMP, V_TMP + 1, V_TMP + 2
+    T, T2, AL = V_TMP, V_TMP + 1, 245
     g.out.append(f"L_fwd_redo{X}{par}_%=:")
     g.nop(4)
     g.valu(f"v_max_f32_e32 {v(T)}, {v(sr)}, {v(sr + 1)}", regs("v", sr, 2), regs("v", T))
@@ -415,11 +437,16 @@ def redo_block(X: int, par: int, nsites: int):
     for r in range(16):
         g.valu(f"v_fma_f32 {v(p + r)}, {v(sr + r)}, {s(S_LOG2E)}, {v(V_MNEG + X)}", regs("v", sr + r) | regs("v", V_MNEG + X), regs("v", p + r))
         g.valu(f"v_exp_f32_e32 {v(p + r)}, {v(p + r)}", regs("v", p + r), regs("v", p + r), trans=True)
-    ls = V_LSUM + X
+    ls, c = V_LSUM + X, V_SUMT + 4 * X
     g.nop(2)
-    g.valu(f"v_add_f32_e32 {v(ls)}, {v(p)}, {v(p + 1)}", regs("v", p, 2), regs("v", ls))
-    for r in range(2, 16):
-        g.valu(f"v_add_f32_e32 {v(ls)}, {v(ls)}, {v(p + r)}", regs("v", ls) | regs("v", p + r), regs("v", ls))
+    for j in range(4):
+        g.valu(f"v_add_f32_e32 {v(c + j)}, {v(p + j)}, {v(p + j + 4)}", regs("v", p + j) | regs("v", p + j + 4), regs("v", c + j))
+    for k in (8, 12):
+        for j in range(4):
+            g.valu(f"v_add_f32_e32 {v(c + j)}, {v(c + j)}, {v(p + j + k)}", regs("v", c + j) | regs("v", p + j + k), regs("v", c + j))
+    g.valu(f"v_add_f32_e32 {v(c)}, {v(c)}, {v(c + 1)}", regs("v", c, 2), regs("v", c))
+    g.valu(f"v_add_f32_e32 {v(c + 2)}, {v(c + 2)}, {v(c + 3)}", regs("v", c + 2, 2), regs("v", c + 2))
+    g.valu(f"v_add_f32_e32 {v(ls)}, {v(c)}, {v(c + 2)}", regs("v", c) | regs("v", c + 2), regs("v", ls))
     g.valu(f"v_mul_f32_e32 {v(V_L + X)}, {v(V_L + X)}, {v(AL)}", regs("v", V_L + X) | regs("v", AL), regs("v", V_L + X))
     for k in range(32):
         ar = A_O + 32 * X + k
@@ -529,6 +556,8 @@ def fixed_point_loop(g: Gen, masked: bool):
         for b in range(6):
             g.out.append(f"L_fwd_{'m' if masked else 'u'}{b}_%=:")
             body(g, b, masked=masked, site_base=12 if masked else 0)
+            if STAMP:
+                g.raw(f"v_add_u32_e32 {v(246 + (6 if masked else 7))}, 1, {v(246 + (6 if masked else 7))}")      # iterations: [6] masked, [7] main
             loop_tail(g, b, masked)
         texts.append(list(g.out))
     assert texts[1] == texts[2], "the loop body is not a fixed point of the wait-count / hazard trackers"
@@ -542,9 +571,13 @@ def generate():
     # pipeline fill: n = -3 (QE of tile -1: the diagonal chunks), -2 (QE of tile 0, DMA of tile 0), -1 (QE 1, S 0, DMA 1)
     for n in (-3, -2, -1):
         body(g, n % 6, n_min=-n, masked=True, site_base=24 + 12 * (n + 3))      # masked: tile 0 may be a diagonal tile (first query block)
-        g.drain()
-        g.nop(16)
         g.salu(f"s_add_u32 {s(S_N)}, {s(S_N)}, 1", regs("s", S_N), regs("s", S_N))
+    g.drain()
+    g.nop(16)
+    if STAMP:
+        for k in range(8):
+            g.raw(f"v_mov_b32_e32 {v(246 + k)}, 0")
+        g.stamp(None)
     # n = 0: main bodies if tile 1 is strictly below the wave's first diagonal and no key of the batch row is padded
     g.salu(f"s_cmp_lg_u32 {s(S_PADANY)}, 0", regs("s", S_PADANY), {"scc"})
     g.raw("s_cbranch_scc1 L_fwd_m0_%=")
@@ -569,6 +602,14 @@ def generate():
     g.raw(f"v_mov_b32_e32 %5, {v(V_L)}")
     g.raw(f"v_mov_b32_e32 %6, {v(V_M + 1)}")
     g.raw(f"v_mov_b32_e32 %7, {v(V_L + 1)}")
+    if STAMP:                                    # sums -> LDS: OFF_PAD + 512 + 64 w + 4 k (the pad table of a short sequence ends before that)
+        g.raw(f"s_lshl_b32 {s(S_TM)}, {s(S_W)}, 6")
+        g.raw(f"s_add_u32 {s(S_TM)}, {s(S_TM)}, {OFF_PAD + 512}")
+        g.raw(f"s_add_u32 {s(S_TM)}, {s(S_TM)}, {s(S_LDS)}")
+        g.raw(f"v_mov_b32_e32 {v(V_TMP)}, {s(S_TM)}")
+        for k in range(8):
+            g.raw(f"ds_write_b32 {v(V_TMP)}, {v(246 + k)} offset:{4 * k}")
+        g.raw("s_waitcnt lgkmcnt(0)")
     g.nop(16)
     g.raw("s_barrier")
     g.raw("s_branch L_fwd_done_%=")
@@ -590,7 +631,7 @@ def clobbers():
 
 def write(here):
     lines, g = generate()
-    path = os.path.join(here, "rel_attn_fwd64_loop.inc")
+    path = os.path.join(here, "rel_attn_fwd64_loop_stamp.inc" if STAMP else "rel_attn_fwd64_loop.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by gen_fwd_asm.py -- do not edit.  The hand-scheduled sweep of rel_attn_fwd64_kernel (one asm statement):\n")
         f.write("// operands %0..%3 = oA0, oA1, oB0, oB1 (\"=&a\"), %4..%7 = m_A, l_A, m_B, l_B (\"=&v\"), %8..%15 = the scaled q fragments of tiles A, B\n")
@@ -608,4 +649,5 @@ def write(here):
 
 
 if __name__ == "__main__":
-    write(os.path.dirname(os.path.abspath(__file__)))
+    for STAMP in (False, True):
+        write(os.path.dirname(os.path.abspath(__file__)))
