@@ -237,7 +237,7 @@ class Item:
         self.gap = None
 
 
-COST = {"valu": 4, "trans": 8, "lds": 4, "lds128": 6, "salu": 3, "vmem": 8, "sync": 4}
+COST = {"valu": 4, "trans": 8, "lds": 4, "lds128": 8, "salu": 3, "vmem": 8, "store": 24, "sync": 4}
 GAP_BUDGET = 22        # issue cycles of fillers an MFMA (32 cycles, 8 of them its own issue) is asked to hide
 
 

@@ -77,7 +77,7 @@ ST_CACHE = os.environ.get("MGX_DKV64_ST", "nt")          # experiment: cache pol
 ST_PINS = [int(x) for x in os.environ.get("MGX_DKV64_STPIN", "").split(",") if x]      # experiment: the MFMA shadows of the four dS stores
 PEEL = 0             # timing experiments (results wrong): 1 no dS stores | 2 no E loads | 4 no DMA | 8 no skew | 16 no exp | 32 no merge | 64 no stats reads | 128 no tr reads
 
-OFF_QR, OFF_OR, OFF_ST = 0, 8192, 16384
+OFF_QR, OFF_OR, OFF_ST = 0, 12288, 24576      # three LDS buffers per image: query tile t in buffer t % 3
 ST_BYTES = 512
 
 
@@ -95,7 +95,7 @@ class Step:
     def __init__(self, g: Gen, b: int):
         self.g = g
         n = b
-        self.cur = n & 1                       # LDS buffer of tile n; tile n+1 in cur ^ 1; DMA of tile n+2 -> cur
+        self.cur, self.nxt, self.dst = n % 3, (n + 1) % 3, (n + 2) % 3      # LDS buffers of tile n, of tile n+1, and of the DMA of tile n+2
         self.T = V_T[n & 1]                    # c0 / nl / c1 of tile n
         self.Tn = V_T[(n + 1) & 1]             # chunk products of tile n+1
         self.slot_t0 = (n + 1) % 3             # E slots of the products of tile n+1
@@ -149,7 +149,7 @@ class Step:
     def rd_nd(self, u, nxt=False):
         """-delta of the accumulator rows: initial value of dp_u (nxt: of tile n+1, from the other buffer)"""
         out = []
-        buf = self.cur ^ 1 if nxt else self.cur
+        buf = self.nxt if nxt else self.cur
         for g4 in range(4):
             dst = V_DP + 16 * u + 4 * g4
             off = buf * ST_BYTES + 128 + 32 * g4         # (V_AST includes OFF_ST)
@@ -170,8 +170,6 @@ class Step:
         g = self.g
 
         def f():
-            g.raw("s_waitcnt lgkmcnt(0)")                # every LDS read of tile n has returned
-            g.lgkm = []
             g.wait_vm_tag(dma_tag)                         # this wave's pieces of tile n+1 have landed
             g.raw("s_barrier")
         return [f]
@@ -194,28 +192,28 @@ class Step:
         return salu_items(g, ops)
 
     def dma(self, tag):
-        """tile min(n + 2, nT - 1) -> buffer cur (pointers from dma_addr)"""
+        """tile min(n + 2, nT - 1) -> buffer (n + 2) % 3 (pointers from dma_addr)"""
         g = self.g
         out = []
         for i in range(2):
             for img, ptr, voff in ((OFF_QR, S_T + 2, V_QOFF + i), (OFF_OR, S_T + 4, V_OOFF + i)):
                 def piece(i=i, img=img, ptr=ptr, voff=voff):
-                    g.salu(f"s_add_u32 m0, {s(S_DQ)}, {img + self.cur * 4096 + 2048 * i}", regs("s", S_DQ), {"m0"})
+                    g.salu(f"s_add_u32 m0, {s(S_DQ)}, {img + self.dst * 4096 + 2048 * i}", regs("s", S_DQ), {"m0"})
                     g.vmem_dma(f"global_load_lds_dwordx4 {v(voff)}, {s(ptr, 2)}", tag, regs("v", voff) | regs("s", ptr, 2) | {"m0"})
                 out.append(piece)
 
         def stat():
-            g.salu(f"s_add_u32 m0, {s(S_DST)}, {self.cur * ST_BYTES}", regs("s", S_DST), {"m0"})
+            g.salu(f"s_add_u32 m0, {s(S_DST)}, {self.dst * ST_BYTES}", regs("s", S_DST), {"m0"})
             g.vmem_dma(f"global_load_lds_dword {v(V_STOFF)}, {s(S_T + 6, 2)}", tag, regs("v", V_STOFF) | regs("s", S_T + 6, 2) | {"m0"})
         out.append(stat)
         return out
 
     def rd_rows(self, which):
-        """row fragments of tile n+1 (buffer cur ^ 1): q -> V_QA, dO -> V_OF"""
+        """row fragments of tile n+1: q -> V_QA, dO -> V_OF"""
         img, base = (OFF_QR, V_QA) if which == "q" else (OFF_OR, V_OF)
         out = []
         for ks in range(4):
-            off = img + (self.cur ^ 1) * 4096
+            off = img + self.nxt * 4096
             out.append(lambda ks=ks, off=off: self.g.ds_read(f"ds_read_b128 {v(base + 4 * ks, 4)}, {v(V_AQ + ks)} offset:{off}",
                                                               regs("v", V_AQ + ks), regs("v", base + 4 * ks, 4)))
         return out
@@ -372,18 +370,19 @@ def body(g: Gen, b: int, do_cur: bool = True, masked: bool = False, listing=None
         items.extend(out)
         return out
 
-    tile_n_reads = []
+    # Three LDS buffers: the barrier at the top of iteration n tells every wave that (a) all pieces of tile n+1 have landed (each wave
+    # waited for its own, requested a whole iteration ago) and (b) everybody has left iteration n-1, so the buffer of tile n-1 is free
+    # for the DMA of tile n+2.  No LDS read of the iteration is tied to a position by the barrier: the scheduler spreads them.
+    bar = add(st.barrier(f"dma{prev_b}"), COST["sync"], pin=1, name="barrier")
+    dma_a = chain(add(st.dma_addr(), COST["salu"], earliest=1, deadline=4, name="dma_addr"))
+    dma = chain(add(st.dma(f"dma{b}"), COST["salu"] + COST["vmem"], earliest=1, deadline=12, deps=bar + dma_a[-1:], name="dma"))
     if do_cur:
-        nd0 = add(st.rd_nd(0), COST["lds128"], earliest=1, deadline=6, name="nd0")                     # dP0 = MFMA 9
-        nd1 = add(st.rd_nd(1), COST["lds128"], earliest=1, deadline=8, name="nd1")                     # dP1 = MFMA 13
-        nl = add(st.rd_nl(), COST["lds128"], earliest=1, deadline=5, name="nl")
-        tr = add(st.rd_tr(), COST["lds"], earliest=1, deadline=9, name="tr")
-        tile_n_reads = nd0 + nd1 + nl + tr
-    bar = add(st.barrier(f"dma{prev_b}"), COST["sync"], pin=10, deps=tile_n_reads, name="barrier")
-    dma_a = chain(add(st.dma_addr(), COST["salu"], earliest=1, deadline=10, name="dma_addr"))
-    dma = chain(add(st.dma(f"dma{b}"), COST["salu"] + COST["vmem"], earliest=10, deadline=16, deps=bar + dma_a[-1:], name="dma"))
-    rq = add(st.rd_rows("q"), COST["lds128"], earliest=10, deadline=13, deps=bar, name="rows_q")       # S of tile n = MFMAs 1-8
-    ro = add(st.rd_rows("o"), COST["lds128"], earliest=16, deadline=38, deps=bar, name="rows_o")       # dP of tile n = MFMAs 9-16
+        nd0 = add(st.rd_nd(0), COST["lds128"], earliest=1, deadline=7, name="nd0")                     # dP0 = MFMA 9
+        nd1 = add(st.rd_nd(1), COST["lds128"], earliest=1, deadline=11, name="nd1")                    # dP1 = MFMA 13
+        nl = add(st.rd_nl(), COST["lds128"], earliest=1, deadline=6, name="nl")
+        tr = add(st.rd_tr(), COST["lds"], earliest=1, deadline=26, name="tr")                          # dV / dK = MFMAs 29..
+    rq = add(st.rd_rows("q"), COST["lds128"], earliest=9, deadline=14, deps=bar, name="rows_q")        # S of tile n = MFMAs 1-8; QE of tile n+1 = 17..
+    ro = add(st.rd_rows("o"), COST["lds128"], earliest=16, deadline=40, deps=bar, name="rows_o")       # dP of tile n = MFMAs 9-16
     if do_cur:
         cvds = []
         if masked:
@@ -407,11 +406,11 @@ def body(g: Gen, b: int, do_cur: bool = True, masked: bool = False, listing=None
             cvds.append(cvd)
         sa = chain(add(st.st_addr(), COST["salu"], earliest=1, deadline=30, name="st_addr"))
         if masked:
-            sts = chain(add(st.st_dS_masked(f"st{b}"), 2 * COST["vmem"] + 4 * COST["salu"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
+            sts = chain(add(st.st_dS_masked(f"st{b}"), 2 * COST["store"] + 4 * COST["salu"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
             for u, it in enumerate(sts):
                 it.deps += cvds[u]
         else:
-            sts = chain(add(st.st_dS(f"st{b}"), COST["vmem"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
+            sts = chain(add(st.st_dS(f"st{b}"), COST["store"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
             for k, it in enumerate(sts):
                 it.deps += cvds[k >> 1][4 * (k & 1): 4 * (k & 1) + 4]
                 if ST_PINS:
