@@ -58,9 +58,10 @@ def _stale(lib: str = LIB) -> bool:
 
 
 def _generate(experiments: bool = False) -> None:
-    """the hand-scheduled dK/dV main loop is generated code: csrc/gen_dkv_asm.py -> csrc/rel_attn_dkv64_loop.inc (tracked, so the
-    schedule can be read and diffed) and ..._loop_stamp.inc (diagnostic builds; not tracked).  Regenerated on every build."""
-    gens = [os.path.join(CSRC, "gen_dkv_asm.py")] + ([os.path.join(EXPERIMENT_DIR, "gen_fwd_asm.py")] if experiments else [])
+    """the hand-scheduled main loops are generated code: csrc/gen_dkv_asm.py -> csrc/rel_attn_dkv64_loop.inc (tracked, so the
+    schedule can be read and diffed) and ..._loop_stamp.inc (diagnostic builds; not tracked); csrc/gen_gemm_asm.py ->
+    csrc/linear_dw_ring4_loop.inc.  Regenerated on every build."""
+    gens = [os.path.join(CSRC, "gen_dkv_asm.py"), os.path.join(CSRC, "gen_gemm_asm.py")] + ([os.path.join(EXPERIMENT_DIR, "gen_fwd_asm.py")] if experiments else [])
     for gen in gens:
         r = subprocess.run([sys.executable, gen], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:

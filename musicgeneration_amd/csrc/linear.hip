@@ -1229,6 +1229,143 @@ __global__ __launch_bounds__(512, 1) void linear_dw_ring_kernel(const DwRing g, 
     }
 }
 
+// ---- the same unit with FOUR waves, one per SIMD, each holding a 128 x 128 output tile = 16 accumulator tiles = all 256 AGPRs ----
+// The eight-wave kernel above reads 6 operand fragments from LDS for 8 MFMAs per k-step and wave: 96 KB of transposing reads + 32 KB
+// of DMA writes per stage and workgroup against 1024 MFMA cycles per SIMD -- the LDS (128 B/clk) is as busy as the MFMA pipe, and the
+// kernel sat at ~49 % MFMA-busy.  128 x 128 wave tiles read 8 fragments for 16 MFMAs: 64 + 32 KB per stage.  hipcc cannot keep 256
+// accumulators in place for one wave (rounds 3-4: it shuffles them between the register files), so the main loop is one generated asm
+// statement that owns them (gen_gemm_asm.py -> linear_dw_ring4_loop.inc; parameters through an LDS block as in rel_attn_dkv64.hip);
+// unit decoding, the parameter block and the epilogue stay HIP.  Same images, same stage order, same MFMA operand order as the
+// eight-wave kernel: the partial tiles are bit-identical to its.
+#include "linear_dw_ring4_loop.inc"
+#ifdef MGX_DW4_TIMES
+// diagnostic builds: s_memrealtime (100 MHz) at a unit's start, loop start, loop end and end, per workgroup (tools/dw4_times.py)
+__device__ unsigned long long mgx_dw4_times_buf[8 * 1024];     // [workgroup][4 real-time stamps, 4 shader-clock stamps]
+extern "C" int mgx_debug_dw4_times(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx_dw4_times_buf), sizeof(unsigned long long) * n);
+}
+#define DW4_TIME(k) do { if (tid == 0) { mgx_dw4_times_buf[8 * blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime(); \
+                                        mgx_dw4_times_buf[8 * blockIdx.x + 4 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define DW4_TIME(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(256, 1) void linear_dw_ring4_kernel(const DwRing g, int M, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    DW4_TIME(0);
+    const int tiles_all = g.first_tile[g.n];
+    const int u = xcd_remap(blockIdx.x, gridDim.x);          // unit order: see linear_dw_ring_kernel
+    const int sp = u / tiles_all, t = u - sp * tiles_all;
+    const int unit = t * g.splits + sp;
+    int p = 0;
+    while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
+    const int N = g.N[p], K = g.K[p];
+    const int ntk = K >> 8, tl = t - g.first_tile[p];
+    const int n0 = (tl / ntk) << 8, k0 = (tl % ntk) << 8;
+    const int total = M >> 5;
+    const int s0 = sp * g.steps_per_split;
+    const int G = min(total, s0 + g.steps_per_split) - s0;   // >= 1 (host)
+    char* patch = smem + RG_NST * RG_STAGE + w * RG_PATCH;
+    // bias gradient gb[n] += sum_m dY[m][n]: the 2 ntk waves that hold the same dY fragments (wn = 0, 1 of every k-tile of the tile row)
+    // share the sums -- one fragment each when there are four or more of them, two each when there are two (gen_gemm_asm.py:
+    // BIAS_VARIANTS; 32 v_dot2c per stage in one wave of a workgroup slowed the whole workgroup by a fifth)
+    int bias_mode = 0, bias_mask = 0;
+    if (g.gb[p] != nullptr) {
+        const int j = 2 * (k0 >> 8) + wn;
+        if (ntk >= 2) { if (j < 4) { bias_mode = 4 + j; bias_mask = 1 << j; } }
+        else { bias_mode = 2 + j; bias_mask = 3 << (2 * j); }
+    }
+    bias_mode = __builtin_amdgcn_readfirstlane(bias_mode);
+    bias_mask = __builtin_amdgcn_readfirstlane(bias_mask);
+
+    // ---- parameter block (layout: gen_gemm_asm.py, prologue), in the wave's epilogue patch ----
+    {
+        uint32_t* lt = (uint32_t*)(patch + 256) + lane;
+        // DMA: this wave fetches pieces q = 4 w + j of both images = rows 8 j .. 8 j + 7 of 64-column sub-tile w
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 8 * j + (lane >> 3);
+            const int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+            lt[64 * j] = (uint32_t)(((size_t)r * N + 64 * w + chunk * 8) * 2);
+            lt[64 * (4 + j)] = (uint32_t)(((size_t)r * K + 64 * w + chunk * 8) * 2);
+        }
+        const int i15 = lane & 15, gq = lane >> 4, rq = i15 >> 2;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int chunk = 4 * ct + 2 * (gq & 1) + ((i15 & 3) >> 1);
+            const uint32_t in_tile = (8 * hh + rq) * 128 + ((chunk ^ (((rq >> 1) & 1) << 2)) << 4) + 8 * (i15 & 1);
+            lt[64 * (8 + ct)] = lds_addr_of(smem) + 2 * wm * TILE_BYTES + in_tile;
+            lt[64 * (10 + ct)] = lds_addr_of(smem) + 16384 + 2 * wn * TILE_BYTES + in_tile;
+        }
+        if (lane == 0) {
+            uint64_t* p64 = (uint64_t*)patch;
+            p64[0] = (uint64_t)(uintptr_t)(g.dY[p] + (size_t)(s0 * 32) * N + n0);
+            p64[1] = (uint64_t)(uintptr_t)(g.X[p] + (size_t)(s0 * 32) * K + k0);
+            uint32_t* p32 = (uint32_t*)patch;
+            p32[4] = (uint32_t)(32 * N * 2);                 // bytes per stage
+            p32[5] = (uint32_t)(32 * K * 2);
+            p32[6] = (uint32_t)G;
+            p32[7] = lds_addr_of(smem);
+            p32[8] = (uint32_t)w;
+            p32[9] = (uint32_t)bias_mode;
+            p32[10] = p32[11] = 0u;
+        }
+    }
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = zero16();
+    float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t pba = __builtin_amdgcn_readfirstlane(lds_addr_of(patch));
+    DW4_TIME(1);
+    asm volatile(MGX_DW4_LOOP_ASM
+                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+                   "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
+                   "+a"(acc[3][2]), "+a"(acc[3][3]), "+v"(gsum[0]), "+v"(gsum[1]), "+v"(gsum[2]), "+v"(gsum[3])
+                 : "s"(pba)
+                 : MGX_DW4_LOOP_CLOBBERS);
+    DW4_TIME(2);
+
+    // ---- epilogue: fp32 partial tile -> workspace, row-major [n][k], 128-byte row segments per 8 lanes ----
+    float* wsu = ws + (size_t)unit * 65536;
+    const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                *(f32x4*)(patch + l31 * 128 + (((2 * g4 + hh) ^ (l31 & 7)) << 4)) =
+                    f32x4{acc[rt][ct][4 * g4], acc[rt][ct][4 * g4 + 1], acc[rt][ct][4 * g4 + 2], acc[rt][ct][4 * g4 + 3]};
+            wave_lds_fence();
+            f32x4 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rr + 8 * i;
+                o[i] = *(const f32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(f32x4*)(wsu + (size_t)(128 * wm + 32 * rt + rr + 8 * i) * 256 + 128 * wn + 32 * ct + 4 * ch) = o[i];
+            wave_lds_fence();
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if ((bias_mask >> i) & 1) {
+            const float v = gsum[i] + __shfl_xor(gsum[i], 32, 64);
+            if (hh == 0) {
+                if (g.detb[p]) det_add(g.detb[p] + n0 + 128 * wm + 32 * i + l31, v);
+                else atomicAdd(g.gb[p] + n0 + 128 * wm + 32 * i + l31, v);
+            }
+        }
+    }
+    DW4_TIME(3);
+}
+
 // gW tile += sum over the M-splits of its partial tiles (fp32, 16 bytes per thread, fully coalesced)
 __global__ __launch_bounds__(256) void dw_fixup_kernel(const DwRing g, const float* __restrict__ ws) {
     const int t = blockIdx.y;
@@ -1461,6 +1598,7 @@ static void set_attrs() {
     hipFuncSetAttribute((const void*)linear_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_dw_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+    hipFuncSetAttribute((const void*)linear_dw_ring4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1685,8 +1823,14 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int coun
             for (int i = 0; i < count; ++i)
                 if (problems[i].gb) { rg.detb[i] = det + o; o += (size_t)problems[i].N; }
         }
-        hipLaunchKernelGGL(linear_dw_ring_kernel, dim3(tiles * rg.splits), dim3(512), RG_LDS, (hipStream_t)stream, rg, M,
-                           (float*)workspace);
+        static int four = -1;                              // 0: the eight-wave HIP kernel (A/B, experiment builds)
+        if (four < 0) four = gemm_knob("MGX_DW_RING4", 1);
+        if (four)
+            hipLaunchKernelGGL(linear_dw_ring4_kernel, dim3(tiles * rg.splits), dim3(256), RG_LDS, (hipStream_t)stream, rg, M,
+                               (float*)workspace);
+        else
+            hipLaunchKernelGGL(linear_dw_ring_kernel, dim3(tiles * rg.splits), dim3(512), RG_LDS, (hipStream_t)stream, rg, M,
+                               (float*)workspace);
         hipLaunchKernelGGL(dw_fixup_kernel, dim3(64, tiles), dim3(256), 0, (hipStream_t)stream, rg, (const float*)workspace);
         if (det)
             for (int i = 0; i < count; ++i)

@@ -140,3 +140,48 @@ def test_dw_ring_against_fp64_reference(M, shapes):
         if gb is not None:
             errb = (gb.double() - rb).abs().max().item() / rb.abs().max().item()
             assert errb < 1e-5, f"gb {tuple(gb.shape)}: relative error {errb:.2e}"
+
+
+CHILD_DW = r'''
+import sys, os, torch, numpy as np
+sys.path.insert(0, sys.argv[1])
+from musicgeneration_amd import ops
+dev = "cuda:0"
+out = {}
+g = torch.Generator(device="cpu").manual_seed(13)
+for i, (M, shapes) in enumerate([(4096 + 32 * 5, [(768, 256, True), (256, 256, False), (512, 256, True), (256, 512, True)]),
+                                 (4096, [(256, 256, True)]),
+                                 (32768, [(1536, 512, True), (512, 512, True), (256, 512, True), (512, 256, True)]),
+                                 (8192, [(2304, 768, True), (768, 768, True)])]):
+    probs = []
+    for (N, K, has_b) in shapes:
+        probs.append(((torch.randn(M, N, generator=g) * 0.5).to(dev).bfloat16(), (torch.randn(M, K, generator=g) * 0.5).to(dev).bfloat16(),
+                      torch.randn(N, K, generator=g).to(dev), torch.randn(N, generator=g).to(dev) if has_b else None))
+    ops.linear_dw_grouped(probs)
+    torch.cuda.synchronize()
+    for j, (dy, x, gw, gb) in enumerate(probs):
+        out[f"gw{i}_{j}"] = gw.cpu().numpy()
+        if gb is not None:
+            out[f"gb{i}_{j}"] = gb.cpu().numpy()
+            out[f"gbref{i}_{j}"] = dy.double().sum(0).cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+
+
+def test_dw_ring4_matches_the_eight_wave_kernel_bitwise(tmp_path):
+    """the generated-asm four-wave weight-gradient kernel (linear_dw_ring4_kernel, the product path) against the eight-wave HIP ring
+    kernel it replaced (MGX_DW_RING4=0, experiment builds only): same images, same stage order, same MFMA operand order -> the weight
+    gradients are bit-identical; the bias gradients are summed by different waves in a different order -> close, not identical"""
+    res = {}
+    for four in (0, 1):
+        path = str(tmp_path / f"dw{four}.npz")
+        env = dict(os.environ, MGX_DW_RING4=str(four), MGX_LIB_PATH=_variant_lib())
+        r = subprocess.run([sys.executable, "-c", CHILD_DW, ROOT, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res[four] = np.load(path)
+    for k in res[0].files:
+        if k.startswith("gw"):
+            assert np.array_equal(res[0][k], res[1][k]), f"{k}: the four-wave kernel's weight gradient differs"
+        elif k.startswith("gb") and not k.startswith("gbref"):
+            scale = np.abs(res[0]["gbref" + k[2:]]).max()
+            assert np.abs(res[0][k] - res[1][k]).max() < 1e-5 * scale, f"{k}: bias gradient"
