@@ -227,7 +227,11 @@ typedef struct mgx_dw_problem {
     int N, K;
 } mgx_dw_problem;
 /* workspace: caller scratch >= mgx_linear_dw_grouped_workspace(problems, count, M) bytes, 16-byte aligned (fp32 partial
- * tiles of the M-splits; 0 when the group runs on the tiled kernel, NULL is accepted then).                             */
+ * tiles of the M-splits; 0 when the group runs on the tiled kernel, NULL is accepted then).  With M >= 4096, M % 32 == 0,
+ * the weights whose N x K fills its 256 x 256 tiles to 60 % or more (N, K % 8 == 0; a ragged last tile row / column is
+ * allowed: the vocabulary projection 448 x 512) take the split-then-fix-up path -- one fp32 partial tile per (tile, M-split)
+ * in the workspace, added into gW in split order by a second pass, no fp32 atomics on gW; a group of ONE weight is the way
+ * to send a single large weight gradient (mgx_linear_dw's shapes) down that path.                                         */
 size_t mgx_linear_dw_grouped_workspace(const mgx_dw_problem* problems, int count, int M);
 int mgx_linear_dw_grouped(const mgx_dw_problem* problems, int count, int M, void* workspace, size_t ws_bytes,
                           void* stream);

@@ -180,12 +180,14 @@ class Gen:
             same = all(r in self.mfma_d for r in dr)
             self.emit("mfma_acc_same" if same else "mfma", f"v_mfma_f32_32x32x16_bf16 {dt}, {at}, {bt}, {dt}", ar | br | dr, dr)
 
-    def mfma_op(self, opnd, a_, b_):
-        """accumulator given as an asm operand (%N, compiler-allocated AGPRs): never touched by anything else in the block"""
+    def mfma_op(self, opnd, a_, b_, c0=False, cv=None):
+        """accumulator given as an asm operand (%N, compiler-allocated AGPRs): never touched by anything else in the block; c0: C = 0;
+        cv: C = the 16 VGPRs from cv on (D = C + A B written to the operand)"""
         ar, br = regs(a_[0], a_[1], 4), regs(b_[0], b_[1], 4)
         at = f"{a_[0]}[{a_[1]}:{a_[1] + 3}]"
         bt = f"{b_[0]}[{b_[1]}:{b_[1] + 3}]"
-        self.emit("mfma", f"v_mfma_f32_32x32x16_bf16 {opnd}, {at}, {bt}, {opnd}", ar | br, set())
+        ct = f"v[{cv}:{cv + 15}]" if cv is not None else ("0" if c0 else opnd)
+        self.emit("mfma", f"v_mfma_f32_32x32x16_bf16 {opnd}, {at}, {bt}, {ct}", ar | br | (regs("v", cv, 16) if cv is not None else set()), set())
 
     def valu(self, text, reads, writes, trans=False):
         self.emit("trans" if trans else "valu", text, reads, writes)

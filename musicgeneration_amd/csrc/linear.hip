@@ -699,6 +699,210 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
 }
 
 // =================================================================================================
+// The same ring with FOUR waves, one per SIMD, each holding a 128 x 128 block of the tile = 16 accumulator tiles = all 256 AGPRs
+// (round 5).  Per 16-column k-step a wave reads 8 operand fragments for 16 MFMAs instead of 6 for 8: two thirds of the LDS bytes per
+// MFMA.  hipcc cannot keep 256 accumulators in place (rounds 3-4), so one TILE's stages are one generated asm statement that owns them
+// (gen_gemm_asm.py: ring_tile -> linear_ring4_loop.inc); what stays HIP is the tile loop, the wave's parameter block in LDS (source
+// pointers of this and the next tile, the ring's state between two statements) and the epilogue.  The DMA ring runs on across the
+// statement's end: the first three stages of the next tile are in flight during the epilogue, whose 32 global stores per wave
+// (MGX_RING4_EPI_STORES) the statement's first counted waits allow for.  Same images, same MFMA operand order as the eight-wave kernel:
+// bit-identical results.  Stages of 64 reduction columns in two 64 KB slots, so that every DMA instruction fetches whole 128-byte lines
+// (gen_gemm_asm.py).  LDS: 2 x 64 KB stages + 4 x 4 KB patches + 4 x 4 KB parameter blocks (bias at + 512) = 160 KB.
+// =================================================================================================
+#include "linear_ring4_loop.inc"
+#ifdef MGX_DW4_TIMES
+extern __device__ unsigned long long mgx_dw4_times_buf[8 * 1024];
+#endif
+template <bool FWD, int PRE>
+MGX_DEV void store_wave_block4(uint16_t* __restrict__ C, const uint16_t* __restrict__ relu_y, const uint16_t* __restrict__ addend,
+                               f32x16 (&acc)[4][4], const char* bias_lds, int act, int mb, int nb, int N, int lane, char* patch) {
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int rr = lane >> 3, ch = lane & 7;
+    char* wr = patch + l31 * 128 + 8 * hh;
+    const int sw = l31 & 7;
+    const bool relu = FWD && act == 1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                   // 64 columns at a time: the patch holds 32 rows x 64 columns
+        // byte offsets from the (uniform) matrix bases in 32 bits (host: the matrix is smaller than 4 GB): sixteen 64-bit row pointers
+        // per operand cost 64 registers and spilled
+        const uint32_t off0 = (uint32_t)(((size_t)(mb + rr) * N + nb + 64 * half + ch * 8) * 2), rowb = (uint32_t)N * 16u;   // 8 rows
+        u32x4 pre[4][4];
+        if constexpr (!FWD && PRE != 0) {
+            // all sixteen rows of the half-block at once, waited for once (store_wave_block)
+            const char* pbase = (const char*)(PRE == 2 ? addend : relu_y);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pre[rt][i] = *(const u32x4*)(pbase + (off0 + (uint32_t)(4 * rt + i) * rowb));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 b[2][4];                                       // bias of the lane's columns (parameter block + 512: the statement's DMA)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) b[ct][g4] = FWD ? *(const f32x4*)(bias_lds + (64 * half + 32 * ct + 8 * g4 + 4 * hh) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            // (packed one 32-row slice at a time: the accumulators stay where they are -- AGPRs -- until they are read here.  ReLU as a
+            //  straight-line variant: on the runtime flag hipcc computed both and selected, 4 more instructions per 4 values)
+            auto park = [&](auto relu_tag) {
+                constexpr bool RELU = decltype(relu_tag)::value;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const f32x16& a = acc[rt][2 * half + ct];
+                        uint32_t p0 = pack_bf16x2(a[4 * g4 + 0] + b[ct][g4].x, a[4 * g4 + 1] + b[ct][g4].y);
+                        uint32_t p1 = pack_bf16x2(a[4 * g4 + 2] + b[ct][g4].z, a[4 * g4 + 3] + b[ct][g4].w);
+                        if (RELU) { p0 = relu_bf16x2(p0); p1 = relu_bf16x2(p1); }
+                        *(u32x2*)(wr + (((4 * ct + g4) ^ sw) << 4)) = u32x2{p0, p1};
+                    }
+            };
+            if (relu) park(std::true_type{}); else park(std::false_type{});
+            wave_lds_fence();
+            u32x4 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rr + 8 * i;
+                o[i] = *(const u32x4*)(patch + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+            if constexpr (!FWD && PRE != 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float f[8], a[8];
+                    unpack8(o[i], f);
+                    unpack8(pre[rt][i], a);
+                    if (PRE == 1) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) f[k] = (a[k] > 0.f) ? f[k] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) f[k] += a[k];
+                    }
+                    o[i] = pack8(f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)((char*)C + (off0 + (uint32_t)(4 * rt + i) * rowb)) = o[i];
+            wave_lds_fence();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <bool BTRANS, int PRE>      // PRE (dX): 0 plain, 1 ReLU-backward mask, 2 residual addend -- ONE epilogue per kernel: with the three behind
+                                     // runtime branches hipcc moved accumulator tiles between AGPR tuples after the statement and spilled
+__global__ __launch_bounds__(256, 1) void linear_ring4_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                             const float* __restrict__ bias, const uint16_t* __restrict__ relu_y,
+                                                             const uint16_t* __restrict__ addend, uint16_t* __restrict__ C, int M, int NO,
+                                                             int R, int act) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int ntn = NO / 256, ntm = M / 256, ntiles = ntm * ntn;           // whole tiles (host)
+    const int nd = R / 64;                                   // 64-column stages per tile: even, >= 4 (host)
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    char* patch = smem + 2 * 65536 + w * RG_PATCH;
+    char* pb = smem + 2 * 65536 + 4 * RG_PATCH + w * 4096;
+    auto tile_origin = [&](int i, int& m0, int& n0) {        // i-th tile of this workgroup (past the last one: the last one again)
+        const int t = min(xcd_remap((int)blockIdx.x + min(i, my_tiles - 1) * (int)gridDim.x, ntiles), ntiles - 1);
+        m0 = (t / ntn) * 256; n0 = (t % ntn) * 256;
+    };
+    auto a_base = [&](int m0) { return (uint64_t)(uintptr_t)(A + (size_t)m0 * R); };
+    auto b_base = [&](int n0) { return (uint64_t)(uintptr_t)(BTRANS ? B + n0 : B + (size_t)n0 * R); };
+    // ---- the lane's table (layout: gen_gemm_asm.py, ring_tile): DMA source offsets of the wave's pieces 0 and 1, fragment addresses ----
+    {
+        uint32_t* lt = (uint32_t*)(pb + 1024) + lane;
+        // image R (128-byte rows): piece p = rows 8 p .. 8 p + 7; the wave fetches pieces 8 w + j; physical chunk lane & 7 of row
+        // r holds logical chunk (lane & 7) ^ ((r >> 1) & 7)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 64 * w + 8 * j + (lane >> 3);
+            const uint32_t offR = (uint32_t)(((size_t)row * R + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2);
+            lt[64 * j] = offR;
+            if (!BTRANS) lt[64 * (2 + j)] = offR;
+        }
+        if (BTRANS) {                                        // image T: piece 0 of the wave = rows 0 .. 7 of 64-column sub-tile w
+            const int r = lane >> 3;
+            const int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
+            lt[64 * 2] = (uint32_t)(((size_t)r * NO + 64 * w + chunk * 8) * 2);
+            lt[64 * 3] = 0u;
+        }
+        lt[64 * 4] = lds_addr_of(smem) + imgR_off(128 * wm + l31, hh);
+        if (!BTRANS) { lt[64 * 5] = lds_addr_of(smem) + 32768 + imgR_off(128 * wn + l31, hh); lt[64 * 6] = 0u; }
+        else {
+            const int i15 = lane & 15, gq = lane >> 4, rq = i15 >> 2;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int chunk = 4 * ct + 2 * (gq & 1) + ((i15 & 3) >> 1);
+                lt[64 * (5 + ct)] = lds_addr_of(smem) + 32768 + 2 * wn * TILE_BYTES + (8 * hh + rq) * 128 +
+                                    ((chunk ^ (((rq >> 1) & 1) << 2)) << 4) + 8 * (i15 & 1);
+            }
+        }
+    }
+    if (!BTRANS) {                                           // no bias: the epilogue adds these zeros (the statement's bias DMA fetches nothing)
+        float* bl = (float*)(pb + 512);
+        bl[lane] = 0.f;
+        bl[64 + lane] = 0.f;
+    }
+    const uint32_t pba = __builtin_amdgcn_readfirstlane(lds_addr_of(pb));
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        int m0, n0, m1, n1;
+        tile_origin(ti, m0, n0);
+        tile_origin(ti + 1, m1, n1);
+        if (lane == 0) {
+            uint64_t* p64 = (uint64_t*)pb;
+            uint32_t* p32 = (uint32_t*)pb;
+            if (ti == 0) {
+                p64[0] = a_base(m0); p64[1] = b_base(n0);
+                p32[11] = p32[19] = (uint32_t)nd;            // requests of A / of B left in the tile that operand's pointer stands in
+            }
+            p64[2] = a_base(m1); p64[3] = b_base(n1);
+            p32[8] = 128u;                                   // bytes per stage: 64 columns of A
+            p32[9] = BTRANS ? (uint32_t)(64 * NO * 2) : 128u;
+            p32[10] = (uint32_t)nd;
+            p32[12] = lds_addr_of(smem);
+            p32[13] = (uint32_t)w;
+            p32[14] = ti == 0 ? 1u : 0u;
+            p32[15] = (uint32_t)(8 * R * 2);                 // 8 rows of A
+            p64[8] = (uint64_t)(uintptr_t)(bias ? bias + n0 + 128 * wn : nullptr);      // this tile's bias (0: none -- the zeros below stay)
+            p32[18] = BTRANS ? (uint32_t)(8 * NO * 2) : (uint32_t)(8 * R * 2);      // 8 rows of B
+        }
+        f32x16 acc[4][4];
+#ifdef MGX_DW4_TIMES
+        const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
+#define MGX_RING4_OPERANDS                                                                                                                  \
+    : "=a"(acc[0][0]), "=a"(acc[0][1]), "=a"(acc[0][2]), "=a"(acc[0][3]), "=a"(acc[1][0]), "=a"(acc[1][1]), "=a"(acc[1][2]),                \
+      "=a"(acc[1][3]), "=a"(acc[2][0]), "=a"(acc[2][1]), "=a"(acc[2][2]), "=a"(acc[2][3]), "=a"(acc[3][0]), "=a"(acc[3][1]),                \
+      "=a"(acc[3][2]), "=a"(acc[3][3])                                                                                                      \
+    : "s"(pba)                                                                                                                              \
+    : MGX_RING4_CLOBBERS
+        if constexpr (BTRANS) asm volatile(MGX_RING4_NN_ASM MGX_RING4_OPERANDS);
+        else asm volatile(MGX_RING4_NT_ASM MGX_RING4_OPERANDS);
+#undef MGX_RING4_OPERANDS
+#ifdef MGX_DW4_TIMES
+        const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
+        store_wave_block4<!BTRANS, PRE>(C, relu_y, addend, acc, pb + 512, act, m0 + 128 * wm, n0 + 128 * wn, NO, lane, patch);
+#ifdef MGX_DW4_TIMES
+        if (tid == 0) {          // per workgroup: [0] statement cycles, [1] epilogue cycles (summed over its tiles), [2] tiles, [3] real time
+            const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+            unsigned long long* rec = mgx_dw4_times_buf + 8 * blockIdx.x;
+            if (ti == 0) { rec[0] = rec[1] = rec[2] = 0; rec[3] = __builtin_amdgcn_s_memrealtime(); }
+            rec[0] += tq1 - tq0; rec[1] += tq2 - tq1; rec[2] += 1;
+            rec[4] = __builtin_amdgcn_s_memrealtime() - rec[3];
+        }
+#endif
+    }
+    wait_vmcnt<0>();                                         // the requests past the last tile land before the workgroup's LDS is released
+}
+
+// =================================================================================================
 // dX = dY W   (NN; optional epilogue: dX *= (relu_y > 0), the backward of a fused ReLU; then dX += addend)
 //   tile: 128 rows m x 128 cols k', reduction over n in steps of 64
 //   LDS:  dY tile [128 m][64 n] image R;  W tile [64 n][128 k'] as 4 sub-tiles (2 n-blocks x 2 col halves)
@@ -1034,6 +1238,7 @@ struct DwRing {
     int N[MGX_DW_MAX_GROUP], K[MGX_DW_MAX_GROUP];
     int first_tile[MGX_DW_MAX_GROUP + 1];                  // prefix sums of the 256 x 256 tile counts
     int n, splits, steps_per_split;
+    int ragged;                                            // some weight does not tile into whole 256 x 256 tiles (four-wave kernel only)
 };
 
 __global__ __launch_bounds__(512, 1) void linear_dw_ring_kernel(const DwRing g, int M, float* __restrict__ ws) {
@@ -1263,8 +1468,8 @@ __global__ __launch_bounds__(256, 1) void linear_dw_ring4_kernel(const DwRing g,
     int p = 0;
     while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
     const int N = g.N[p], K = g.K[p];
-    const int ntk = K >> 8, tl = t - g.first_tile[p];
-    const int n0 = (tl / ntk) << 8, k0 = (tl % ntk) << 8;
+    const int ntk = (K + 255) >> 8, tl = t - g.first_tile[p];
+    const int n0 = (tl / ntk) << 8, k0 = (tl % ntk) << 8;     // a weight's last tile row / column may be ragged (N, K % 8 == 0)
     const int total = M >> 5;
     const int s0 = sp * g.steps_per_split;
     const int G = min(total, s0 + g.steps_per_split) - s0;   // >= 1 (host)
@@ -1289,8 +1494,11 @@ __global__ __launch_bounds__(256, 1) void linear_dw_ring4_kernel(const DwRing g,
         for (int j = 0; j < 4; ++j) {
             const int r = 8 * j + (lane >> 3);
             const int chunk = (lane & 7) ^ (((r >> 1) & 1) << 2);
-            lt[64 * j] = (uint32_t)(((size_t)r * N + 64 * w + chunk * 8) * 2);
-            lt[64 * (4 + j)] = (uint32_t)(((size_t)r * K + 64 * w + chunk * 8) * 2);
+            // columns past a ragged edge: fetch the row's last 8 columns instead (in bounds; output element (n, k) depends on dY
+            // column n and X column k alone, and the fix-up pass never reads the rows / columns past the edge)
+            const int cy = min(64 * w + chunk * 8, N - 8 - n0), cx = min(64 * w + chunk * 8, K - 8 - k0);
+            lt[64 * j] = (uint32_t)(((size_t)r * N + cy) * 2);
+            lt[64 * (4 + j)] = (uint32_t)(((size_t)r * K + cx) * 2);
         }
         const int i15 = lane & 15, gq = lane >> 4, rq = i15 >> 2;
 #pragma unroll
@@ -1357,7 +1565,7 @@ __global__ __launch_bounds__(256, 1) void linear_dw_ring4_kernel(const DwRing g,
     for (int i = 0; i < 4; ++i) {
         if ((bias_mask >> i) & 1) {
             const float v = gsum[i] + __shfl_xor(gsum[i], 32, 64);
-            if (hh == 0) {
+            if (hh == 0 && n0 + 128 * wm + 32 * i + l31 < N) {
                 if (g.detb[p]) det_add(g.detb[p] + n0 + 128 * wm + 32 * i + l31, v);
                 else atomicAdd(g.gb[p] + n0 + 128 * wm + 32 * i + l31, v);
             }
@@ -1371,9 +1579,10 @@ __global__ __launch_bounds__(256) void dw_fixup_kernel(const DwRing g, const flo
     const int t = blockIdx.y;
     int p = 0;
     while (p + 1 < g.n && t >= g.first_tile[p + 1]) ++p;
-    const int K = g.K[p], ntk = K >> 8, tl = t - g.first_tile[p];
+    const int K = g.K[p], ntk = (K + 255) >> 8, tl = t - g.first_tile[p];
     const int n0 = (tl / ntk) << 8, k0 = (tl % ntk) << 8;
     const int e4 = blockIdx.x * 256 + threadIdx.x;           // float4 index inside the tile: 0 .. 16383
+    if (n0 + (e4 >> 6) >= g.N[p] || k0 + 4 * (e4 & 63) >= K) return;      // past a ragged edge
     const float* src = ws + (size_t)t * g.splits * 65536 + (size_t)e4 * 4;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < g.splits; ++s) {
@@ -1599,6 +1808,10 @@ static void set_attrs() {
     hipFuncSetAttribute((const void*)linear_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_dw_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_dw_ring4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+    hipFuncSetAttribute((const void*)linear_ring4_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+    hipFuncSetAttribute((const void*)linear_ring4_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+    hipFuncSetAttribute((const void*)linear_ring4_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+    hipFuncSetAttribute((const void*)linear_ring4_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dx_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipFuncSetAttribute((const void*)linear_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1626,6 +1839,14 @@ static int ring_grid(int M, int NO, int R) {
     return (int)(ntiles < cus ? ntiles : cus);
 }
 
+// the four-wave kernel's tile statement runs whole rounds of the 4-slot ring, at least two (reduction % 128 == 0, >= 256);
+// MGX_RING4=0 keeps the eight-wave kernel (A/B; experiment builds only)
+static bool ring4_shape(int R, long long out_elems) {
+    static int env = -2;
+    if (env == -2) env = gemm_knob("MGX_RING4", 1);
+    return env != 0 && R % 128 == 0 && R >= 256 && out_elems * 2 < (1ll << 32);      // (the epilogue addresses the output with 32-bit offsets)
+}
+
 extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C, int M, int N,
                               int K, int act, void* stream) {
     MGX_REQUIRE(A && W && C, MGX_ERR_NULL, "mgx_linear_fwd: NULL pointer");
@@ -1640,6 +1861,10 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
         return MGX_OK;
     }
     if (const int rg = ring_grid(M, N, K)) {
+        if (ring4_shape(K, (long long)M * N))
+            hipLaunchKernelGGL((linear_ring4_kernel<false, 0>), dim3(rg), dim3(256), RG_LDS, (hipStream_t)stream, A, W, bias,
+                               (const uint16_t*)nullptr, (const uint16_t*)nullptr, C, M, N, K, act);
+        else
         hipLaunchKernelGGL(linear_ring_kernel<false>, dim3(rg), dim3(512), RG_LDS, (hipStream_t)stream, A, W, bias,
                            (const uint16_t*)nullptr, (const uint16_t*)nullptr, C, M, N, K, act);
         MGX_CHECK_LAUNCH("mgx_linear_fwd");
@@ -1671,6 +1896,11 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
         // linear_ring_kernel<true> has ONE straight-line epilogue per operand (addend, else mask): a call with both would silently
         // drop the mask, so the invariant is checked where the kernel is launched, not only in the condition above
         MGX_REQUIRE(!(relu_y && addend), MGX_ERR_SHAPE, "mgx_linear_dx: the ring kernel takes a ReLU mask OR a residual addend, not both");
+#define MGX_RING4_DX(PRE) hipLaunchKernelGGL((linear_ring4_kernel<true, PRE>), dim3(rg), dim3(256), RG_LDS, (hipStream_t)stream, dY, W, \
+                                             (const float*)nullptr, relu_y, addend, dX, M, K, N, 0)
+        if (ring4_shape(N, (long long)M * K)) { if (addend) MGX_RING4_DX(2); else if (relu_y) MGX_RING4_DX(1); else MGX_RING4_DX(0); }
+#undef MGX_RING4_DX
+        else
         hipLaunchKernelGGL(linear_ring_kernel<true>, dim3(rg), dim3(512), RG_LDS, (hipStream_t)stream, dY, W,
                            (const float*)nullptr, relu_y, addend, dX, M, K, N, 0);
         MGX_CHECK_LAUNCH("mgx_linear_dx");
@@ -1724,7 +1954,16 @@ extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, f
     return MGX_OK;
 }
 
-// The ring kernel takes a group whose weights all tile into whole 256 x 256 tiles (every encoder-block projection does).
+// The ring kernel takes the weights that fill their 256 x 256 tiles at least to 60 % (N, K multiples of 8, at least 64): every
+// encoder-block projection tiles exactly; the vocabulary projection (448 x 512: 87.5 %) and cfg4's FFN weights (384 x 768: 75 %)
+// have a ragged last tile row / column, whose DMA offsets the kernel clamps and whose outer part the fix-up pass skips -- the wasted
+// MFMA work costs less than the 128 x 128 kernel's atomics and its half-idle MFMA pipe (round 5: 148 -> ~75 us for the vocabulary
+// projection at M = 131072).
+static bool dw_ring_shape(int N, int K) {
+    if (N % 8 != 0 || K % 8 != 0 || N < 64 || K < 64) return false;
+    const long long tiles = (long long)((N + 255) / 256) * ((K + 255) / 256);
+    return (long long)N * K * 10 >= tiles * 65536 * 6;
+}
 // plan: number of M-splits so that tiles x splits fills the CUs once; every split gets at least one 32-row step.
 static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRing* out) {
     static int env = -2;
@@ -1732,12 +1971,14 @@ static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRin
     if (env == 0 || M % 32 != 0 || M < 4096) return false;
     DwRing g;
     g.n = count;
+    g.ragged = 0;
     g.first_tile[0] = 0;
     for (int i = 0; i < count; ++i) {
         const mgx_dw_problem& q = problems[i];
-        if (q.N % 256 != 0 || q.K % 256 != 0) return false;
+        if (!dw_ring_shape(q.N, q.K)) return false;
         g.dY[i] = q.dY; g.X[i] = q.X; g.gW[i] = q.gW; g.gb[i] = q.gb; g.detb[i] = nullptr; g.N[i] = q.N; g.K[i] = q.K;
-        g.first_tile[i + 1] = g.first_tile[i] + (q.N / 256) * (q.K / 256);
+        g.ragged |= (q.N % 256 != 0 || q.K % 256 != 0);
+        g.first_tile[i + 1] = g.first_tile[i] + ((q.N + 255) / 256) * ((q.K + 255) / 256);
     }
     const int tiles = g.first_tile[count];
     static int cus = 0;                                    // queried once (the call is not cheap)
@@ -1757,13 +1998,12 @@ static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRin
     return true;
 }
 
-// The problems of a group whose weights tile into whole 256 x 256 tiles go to the ring kernel, the others (cfg4's FFN weights,
-// 384 x 768: d/2 is not a multiple of 256) to the 128 x 128 grouped kernel -- until round 4 one such weight sent the whole block
-// there (cfg4: 219 us per block, 12 % of the step).
+// The problems of a group whose weights fill their 256 x 256 tiles (dw_ring_shape) go to the ring kernel, the others to the
+// 128 x 128 grouped kernel -- until round 4 one such weight sent the whole block there (cfg4: 219 us per block, 12 % of the step).
 static int dw_split(const mgx_dw_problem* problems, int count, mgx_dw_problem* ring, int* nring, mgx_dw_problem* rest, int* nrest) {
     *nring = *nrest = 0;
     for (int i = 0; i < count; ++i) {
-        if (problems[i].N % 256 == 0 && problems[i].K % 256 == 0) ring[(*nring)++] = problems[i];
+        if (dw_ring_shape(problems[i].N, problems[i].K)) ring[(*nring)++] = problems[i];
         else rest[(*nrest)++] = problems[i];
     }
     return *nring;
@@ -1825,7 +2065,7 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int coun
         }
         static int four = -1;                              // 0: the eight-wave HIP kernel (A/B, experiment builds)
         if (four < 0) four = gemm_knob("MGX_DW_RING4", 1);
-        if (four)
+        if (four || rg.ragged)
             hipLaunchKernelGGL(linear_dw_ring4_kernel, dim3(tiles * rg.splits), dim3(256), RG_LDS, (hipStream_t)stream, rg, M,
                                (float*)workspace);
         else

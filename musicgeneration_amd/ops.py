@@ -305,10 +305,16 @@ def linear_dx(dy, w, relu_y=None, addend=None):
 
 
 def linear_dw(dy, x, gw, gb=None):
-    """gw f32 [N,K] += dy^T @ x ; gb f32 [N] += colsum(dy)"""
+    """gw f32 [N,K] += dy^T @ x ; gb f32 [N] += colsum(dy).  A weight the ring kernel takes (mgx_linear_dw_grouped_workspace() > 0:
+    many rows, tiles mostly full -- the vocabulary projection) goes there as a group of one: partial tiles + fix-up pass instead of
+    fp32 atomics"""
     _need_cuda(dy, x, gw, gb)
     N, K = gw.shape
     Mrows = dy.numel() // N
+    if dy.is_contiguous() and x.is_contiguous():
+        one = (_DwProblem * 1)(_DwProblem(ptr(dy), ptr(x), ptr(gw), ptr(gb), N, K))
+        if _lib.load().mgx_linear_dw_grouped_workspace(ctypes.cast(one, ctypes.c_void_p), 1, Mrows):
+            return linear_dw_grouped([(dy, x, gw, gb)])
     check(_lib.load().mgx_linear_dw(ptr(dy), ptr(x), ptr(gw), ptr(gb), Mrows, N, K, stream_ptr()), "mgx_linear_dw")
 
 

@@ -106,9 +106,14 @@ def test_ring_matches_tiled_kernels_bitwise(tmp_path):
     (4096 + 32 * 5, [(768, 256, True), (256, 256, False), (512, 256, True), (256, 512, False)]),   # 12 steps per unit, ragged last split
     (4096, [(256, 256, True)]),                          # one tile, 128 splits of ONE 32-row step (the short-stream paths)
     (12288, [(256, 256, False), (256, 256, True)]),      # 2-3 steps per unit
-    # a MIXED group (cfg4's block at d = 768: the FFN weights are 384 x 768, not whole 256 x 256 tiles): the ring-shaped weights
-    # take the ring kernel, the others the 128 x 128 grouped kernel, from one call
-    (4096, [(2304, 768, True), (768, 768, False), (384, 768, True), (768, 384, False)]),
+    # cfg4's block at d = 768: the FFN weights, 384 x 768 and 768 x 384, have a RAGGED last tile row / column (75 % of their tiles)
+    (4096, [(2304, 768, True), (768, 768, False), (384, 768, True), (768, 384, True)]),
+    # the vocabulary projection alone (448 x 512: second tile row 192 of 256) and with odd multiples of 8
+    (8192, [(448, 512, True)]),
+    (4096, [(456, 520, True), (264, 248, True)]),
+    # a MIXED group: the weights that fill their tiles take the ring kernel, the others (128 x 768: half a tile row) the 128 x 128
+    # grouped kernel, from one call
+    (4096, [(768, 768, True), (128, 768, True), (768, 384, False)]),
 ])
 def test_dw_ring_against_fp64_reference(M, shapes):
     """weight / bias gradients of a block's four projections through the ring TN kernel + fix-up pass (whole 256 x 256
