@@ -1,4 +1,5 @@
-"""The 256 x 256 ring GEMM (linear.hip: linear_ring_kernel) against the 128 x 128 kernels it replaces for the big projections:
+"""The 256 x 256 ring GEMMs (linear.hip: linear_ring_kernel, eight waves, HIP; linear_ring4_kernel, four waves, generated asm tile
+statement) against the 128 x 128 kernels they replace for the big projections:
 same inputs through both paths in two child processes (the path is chosen once per process by MGX_GEMM_RING, a knob that
 exists in EXPERIMENT builds only: the test builds `libmgx_ringab.so` with `_build.py --experiments` and loads it through
 MGX_LIB_PATH; the product library reads no environment variable), outputs
@@ -76,7 +77,8 @@ def _variant_lib():
 
 
 def _run(ring, path):
-    env = dict(os.environ, MGX_GEMM_RING=str(ring), MGX_LIB_PATH=_variant_lib())
+    # MGX_RING4=2: the four-wave asm kernel wherever its shape rules allow (the product takes it only for long streams of stages)
+    env = dict(os.environ, MGX_GEMM_RING=str(ring), MGX_RING4="2", MGX_LIB_PATH=_variant_lib())
     r = subprocess.run([sys.executable, "-c", CHILD, ROOT, path], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     return np.load(path)
