@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""Generator of the hand-scheduled gfx950 main loop of the weight-gradient ring GEMM (linear.hip: linear_dw_ring4_kernel).
+"""Generator of the hand-scheduled gfx950 main loops of the four-wave ring GEMMs (linear.hip): the weight-gradient kernel
+linear_dw_ring4_kernel (first half of this file) and the forward / dX kernel linear_ring4_kernel (second half: ring_tile).
 
-    python musicgeneration_amd/csrc/gen_gemm_asm.py            -> musicgeneration_amd/csrc/linear_dw_ring4_loop.inc
+    python musicgeneration_amd/csrc/gen_gemm_asm.py            -> musicgeneration_amd/csrc/linear_dw_ring4_loop.inc, linear_ring4_loop.inc
+
+Diagnostic builds (results are garbage, timing only; tools/dw4_clock.sh, tools/ring4_times.py): MGX_DW4_NODMA / NOREAD / NOMFMA / NOSYNC and
+MGX_RING4_DIAG in the environment of the build leave parts of the loops out.
+
+Weight gradient:
 
 gW[n][k] += sum_m dY[m][n] X[m][k] for one 256 x 256 tile and one M-split: the LDS-DMA ring of linear_dw_ring_kernel (4 stages of
 32 rows of dY and X, 32 KB each, images in 64-column sub-tiles with the transposing-read swizzle) driven by FOUR waves, one per SIMD,

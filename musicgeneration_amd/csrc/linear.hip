@@ -13,15 +13,18 @@
 //                                        buffer -- gradient accumulation across micro-batches for free.
 //   bias     gb += column sums of dY, folded into the dW kernel (its first k-tile column stages those rows anyway).
 //
-// Two families: the 128 x 128 kernels described above (any shape), and the 256 x 256 "ring" kernels further down
-// (linear_ring_kernel, linear_dw_ring_kernel: LDS-DMA staging, 4-stage ring, persistent workgroups) that the host
-// entry points pick for the big projections of an encoder block; both produce bit-identical forward / dX results.
+// Two families: the 128 x 128 kernels described above (any shape), and the 256 x 256 "ring" kernels further down that the host
+// entry points pick for the big projections of an encoder block -- LDS-DMA staging into a ring of stages, persistent workgroups --
+// in two generations: eight waves with 128 x 64 wave tiles written in HIP (linear_ring_kernel, linear_dw_ring_kernel) and, round 5,
+// four waves with 128 x 128 wave tiles whose main loops are generated gfx950 assembly owning all 256 accumulators of a wave
+// (linear_ring4_kernel, linear_dw_ring4_kernel; gen_gemm_asm.py).  All produce bit-identical forward / dX results.
+// A/B knobs of the GEMMs: gemm_knob() below.
 #include <stdlib.h>
 #include <type_traits>
 #include "rel_attn_common.hpp"
 #include "mgx.h"
 
-// A/B knobs (MGX_GEMM_RING, MGX_GEMM_SINGLE_BUF, MGX_DW_TARGET_WGS, MGX_DW_GROUP_WGS) exist in experiment builds only
+// A/B knobs (MGX_GEMM_RING, MGX_RING4, MGX_DW_RING4, MGX_GEMM_SINGLE_BUF, MGX_DW_TARGET_WGS, MGX_DW_GROUP_WGS) exist in experiment builds only
 // (`_build.py --variant NAME --experiments`, -DMGX_EXPERIMENTS=1): the product library reads no environment variable.
 // tests/test_gpu_ring.py builds such a variant to run the ring and the 128 x 128 kernels on the same inputs.
 #ifndef MGX_EXPERIMENTS
