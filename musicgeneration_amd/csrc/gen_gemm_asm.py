@@ -356,7 +356,12 @@ def ring_body(g: Gen, slot: int, first: bool, btrans: bool):
     rb2 = add(ring_reads(g, slot, 2, btrans, "b"), earliest=8, deadline=22, spread=8, name="rd_b2")
     rb3 = add(ring_reads(g, slot, 3, btrans, "b"), earliest=17, deadline=26, spread=8, name="rd_b3")   # F3: read by MFMAs 49-64 of the previous stage
     ra2 = add(ring_reads(g, slot, 2, btrans, "a"), earliest=17, deadline=29, spread=10, name="rd_a2")
-    bar1 = add([(lambda: g.raw("s_barrier"), COST["sync"])], pin=28, deadline=64, deps=rb1 + rb2 + rb3, name="barrier1")   # every wave has read B
+    def barrier1():
+        # the slot's B image is requested again right after this barrier: this wave's reads of it must have RETURNED, not only been
+        # issued (an LDS-DMA piece served by L2 lands 250+ cycles after its issue; a queue of LDS reads can be that long)
+        g.prewait(set().union(*[regs("v", rfrag(ks, "b", i), 4) for ks in (1, 2, 3) for i in range(4)]))
+        g.raw("s_barrier")
+    bar1 = add([(barrier1, COST["sync"])], pin=28, deadline=64, deps=rb1 + rb2 + rb3, name="barrier1")   # every wave has read B
     pb_, advb = ring_requests(g, slot, btrans, "b")
     dmb = add([(f, COST["salu"] + COST["vmem"]) for f in pb_], earliest=29, deadline=40, spread=8, deps=bar1, name="dma_b")
     add([(advb, 6 * COST["salu"])], earliest=37, deadline=63, deps=dmb, name="adv_b")
@@ -364,6 +369,7 @@ def ring_body(g: Gen, slot: int, first: bool, btrans: bool):
 
     def barrier2():
         g.wait_vm_tag(f"dmaa{oslot}")                      # this wave's pieces of the next stage have landed (its B image is older)
+        g.prewait(set().union(*[regs("v", rfrag(ks, "a", i), 4) for ks in (1, 2, 3) for i in range(4)]))     # ... and its reads of A have returned
         g.raw("s_barrier")
     bar2 = add([(barrier2, COST["sync"])], pin=44, deadline=64, deps=ra1 + ra2 + ra3, name="barrier2")     # ... and every wave has read A
     pa_, adva = ring_requests(g, slot, btrans, "a")
