@@ -1844,16 +1844,17 @@ static int ring_grid(int M, int NO, int R) {
 
 // the four-wave kernel's tile statement runs whole rounds of its two-slot ring, at least two (reduction % 128 == 0, >= 256);
 // MGX_RING4=0 keeps the eight-wave kernel (A/B; experiment builds only)
-// ... and the kernel pays per tile statement (parameter block, fragment addresses, the first stage's reads: ~1.5 K cycles) and per launch
-// (its first tile waits for both of its stages): measured inside the training step (profiles/r05_ring4_in_step.txt) it wins where a
-// workgroup runs 32 or more 64-column stages -- QKV and the attention output projection, forward and dX -- and loses 10-14 % on the
-// FFN's GEMMs (two to four tiles of four to eight stages per workgroup), which stay on the eight-wave kernel.
-static bool ring4_shape(int R, long long out_elems, int grid) {
+// ... and it does not win everywhere.  Measured per call site inside the training step (profiles/r05_ring4_in_step.txt, cfg2; cfg4 with
+// MGX_RING4=0/1/2): it wins 3-7 % on the QKV and output projections, forward and dX (8-24 stages of 64 columns per tile, output 512
+// columns or wider; cfg4's 768 x 768 projection with ONE tile per workgroup included), and loses 10-14 % on the FFN's GEMMs: tiles of
+// only four stages (reduction 256) pay the statement's fixed costs (parameter block, fragment addresses, first reads: ~1.5 K cycles)
+// per 11 K, and with a 256-column output every workgroup streams its own A rows against the same B tile -- two 64 KB requests in
+// flight keep the HBM less busy than the eight-wave kernel's four 32 KB ones.  Those stay on the eight-wave kernel.
+static bool ring4_shape(int R, int NO, long long out_elems) {
     static int env = -2;
     if (env == -2) env = gemm_knob("MGX_RING4", 1);
     if (env == 0 || R % 128 != 0 || R < 256 || out_elems * 2 >= (1ll << 32)) return false;     // (the epilogue addresses the output with 32-bit offsets)
-    const long long tiles_per_wg = (out_elems / 65536 + grid - 1) / grid;
-    return env == 2 || tiles_per_wg * (R / 64) >= 32;        // MGX_RING4=2 (experiment builds): wherever the shape allows
+    return env == 2 || (R >= 512 && NO >= 512);              // MGX_RING4=2 (experiment builds): wherever the shape allows
 }
 
 extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* C, int M, int N,
@@ -1870,7 +1871,7 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
         return MGX_OK;
     }
     if (const int rg = ring_grid(M, N, K)) {
-        if (ring4_shape(K, (long long)M * N, rg))
+        if (ring4_shape(K, N, (long long)M * N))
             hipLaunchKernelGGL((linear_ring4_kernel<false, 0>), dim3(rg), dim3(256), RG_LDS, (hipStream_t)stream, A, W, bias,
                                (const uint16_t*)nullptr, (const uint16_t*)nullptr, C, M, N, K, act);
         else
@@ -1907,7 +1908,7 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
         MGX_REQUIRE(!(relu_y && addend), MGX_ERR_SHAPE, "mgx_linear_dx: the ring kernel takes a ReLU mask OR a residual addend, not both");
 #define MGX_RING4_DX(PRE) hipLaunchKernelGGL((linear_ring4_kernel<true, PRE>), dim3(rg), dim3(256), RG_LDS, (hipStream_t)stream, dY, W, \
                                              (const float*)nullptr, relu_y, addend, dX, M, K, N, 0)
-        if (ring4_shape(N, (long long)M * K, rg)) { if (addend) MGX_RING4_DX(2); else if (relu_y) MGX_RING4_DX(1); else MGX_RING4_DX(0); }
+        if (ring4_shape(N, K, (long long)M * K)) { if (addend) MGX_RING4_DX(2); else if (relu_y) MGX_RING4_DX(1); else MGX_RING4_DX(0); }
 #undef MGX_RING4_DX
         else
         hipLaunchKernelGGL(linear_ring_kernel<true>, dim3(rg), dim3(512), RG_LDS, (hipStream_t)stream, dY, W,
