@@ -144,3 +144,27 @@ def test_bench_refuses_a_world_size_mismatch():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                            env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and '"metric"' not in r.stdout and "HIP device" in r.stderr
+
+
+def test_dw_grouped_workspace_says_which_weights_take_the_ring_path():
+    """mgx_linear_dw_grouped_workspace is host logic (the split-then-fix-up plan): > 0 exactly for the groups the ring kernel takes --
+    many rows, weights that fill their 256 x 256 tiles to 60 % (ragged last tile row / column allowed) -- and it sizes one fp32
+    partial tile per (tile, M-split).  Without a GPU the plan assumes 256 CUs."""
+    from musicgeneration_amd import _lib, ops
+    lib = _lib.load()
+
+    def need(shapes, M):
+        arr = (ops._DwProblem * len(shapes))()
+        for i, (N, K) in enumerate(shapes):
+            arr[i] = ops._DwProblem(16, 16, 16, None, N, K)
+        return lib.mgx_linear_dw_grouped_workspace(ctypes.cast(arr, ctypes.c_void_p), len(shapes), M)
+
+    block = [(1536, 512), (512, 512), (256, 512), (512, 256)]           # cfg2's encoder block: 20 tiles
+    n = need(block, 131072)
+    assert n > 0 and n % (20 * 65536 * 4) == 0 and 1 <= n // (20 * 65536 * 4) <= 256 // 20
+    assert need([(448, 512)], 131072) > 0                                # the vocabulary projection: second tile row 192 of 256
+    assert need([(384, 768), (768, 384)], 16384) > 0                     # cfg4's FFN weights: 75 % of their tiles
+    assert need([(128, 768)], 16384) == 0                                # half a tile row: the 128 x 128 kernel
+    assert need(block, 1024) == 0 and need(block, 131072 + 8) == 0       # few rows / M % 32 != 0: the 128 x 128 kernels
+    # a mixed group is sized for its ring-shaped weights only
+    assert need(block + [(128, 768)], 131072) == n
