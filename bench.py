@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for timed CPU steps beyond the first three")
     ap.add_argument("--no-decode", action="store_true", help="skip the cfg5 decode block (N=1 only)")
     ap.add_argument("--decode-len", type=int, default=8192)
     ap.add_argument("--decode-batch", type=int, default=32)
@@ -83,6 +83,17 @@ def parse():
                     "by bucket from inside it (same results).  The step-time difference against the default run is what the overlap "
                     "buys; with the per-bucket times of the `dp` block it tells \"RCCL slow\" from \"overlap lost\" on a first multi-GPU run")
     ap.add_argument("--one-device", action="store_true", help="all ranks use cuda:0 (rehearsal with --backend gloo)")
+    ap.add_argument("--side-cus", type=int, default=0, help="run the backward's off-critical-path, HBM-bound kernels (dE from the stored dS "
+                    "tiles, the blocks' weight gradients) on a side stream restricted to this many CUs (multiple of 8 = whole-XCD-balanced "
+                    "mask) beside the critical path, which gets the other CUs (ops.configure_streams; DESIGN.md 2.8).  0 = one stream")
+    ap.add_argument("--side-shared", action="store_true", help="with --side-cus: the main stream keeps the whole chip (only the side "
+                    "stream is masked) instead of the complement of the side stream's CUs")
+    ap.add_argument("--rccl-cus", type=int, default=0, help="N > 1: keep this many CUs (multiple of 8) free of the compute streams for "
+                    "RCCL's kernels (CU-masked compute stream; co-residency mitigation 2 of DESIGN.md 4)")
+    ap.add_argument("--nccl-channels", type=int, default=0, help="N > 1: NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = K for the ranks "
+                    "(K channels = K workgroups of RCCL's ring kernels; mitigation 1 of DESIGN.md 4).  0 = RCCL's default")
+    ap.add_argument("--buckets", type=int, default=0, help="N > 1: merge the per-layer gradient buckets into this many contiguous "
+                    "groups (2: one all-reduce mid-backward, one at its end; mitigation 3 of DESIGN.md 4).  0 = one bucket per layer")
     a = ap.parse_args()
     base = CFG4 if a.workload == "cfg4" else CFG2
     for k, dflt in (("batch", base["batch"]), ("seq_len", base["seq_len"]), ("d_model", base["d_model"]),
@@ -144,17 +155,20 @@ def _cpu_model():
     return platform.processor() or "unknown"
 
 
-def _time_cpu_trainer(V, d, nl, L, Bc, dropout, seconds, max_steps):
+def _time_cpu_trainer(V, d, nl, L, Bc, dropout, seconds, min_steps, max_steps):
+    """one untimed step (allocator / thread-pool warm-up), then at least `min_steps` timed ones (>= 3) and more while
+    the budget of `seconds` lasts"""
     from oracle import ref_cpu as R
     p = R.init_params(V, d, nl, L, seed=0)
     tr = R.CpuTrainer(p, pad=V - 1, d_cfg=d, dropout=dropout, accum=1)
     gen = torch.Generator().manual_seed(1234)
-    nsteps, t_used = 0, 0.0
-    while nsteps < 1 or (t_used < seconds and nsteps < max_steps):
+    nsteps, t_used = -1, 0.0
+    while nsteps < min_steps or (t_used < seconds and nsteps < max_steps):
         xf = torch.randint(0, V - 1, (Bc, L + 1), generator=gen)
         t0 = time.time()
         tr.step(xf[:, :-1].to(torch.int32), xf[:, 1:].to(torch.int32))
-        t_used += time.time() - t0
+        if nsteps >= 0:
+            t_used += time.time() - t0
         nsteps += 1
     return Bc * L * nsteps / t_used, nsteps, t_used
 
@@ -174,14 +188,14 @@ def cpu_baseline(args):
     torch.set_num_threads(ncores)
     V, d, nl, L = args.vocab, args.d_model, args.layers, args.seq_len
     Bc = args.cpu_batch
-    v2, n2, t2 = _time_cpu_trainer(V, d, nl, L, Bc, args.dropout, args.cpu_seconds, 3)
-    v1, n1, t1 = _time_cpu_trainer(309, 256, 2, 512, 8, args.dropout, 4.0, 20)
+    v2, n2, t2 = _time_cpu_trainer(V, d, nl, L, Bc, args.dropout, args.cpu_seconds, 3, 3)
+    v1, n1, t1 = _time_cpu_trainer(309, 256, 2, 512, 8, args.dropout, 4.0, 3, 20)
     return {"value": v2, "unit": "events/s", "cores": ncores, "kind": "port", "cpu_model": _cpu_model(),
             "host_cpus_visible": avail,
-            "sample": f"{n2} step(s) of the same cfg2 training step at batch {Bc} x L {L} "
+            "sample": f"{n2} timed steps (after one untimed) of the same cfg2 training step at batch {Bc} x L {L} "
                       f"(oracle/ref_cpu.py CpuTrainer, eager PyTorch fp32, {ncores} threads, {t2:.1f} s)",
             "cfg1": {"value": v1, "unit": "events/s",
-                     "sample": f"{n1} step(s) of BASELINE cfg1 (V=309, 2 layers, d=256, L=512, batch 8, fp32) in {t1:.1f} s, "
+                     "sample": f"{n1} timed steps (after one untimed) of BASELINE cfg1 (V=309, 2 layers, d=256, L=512, batch 8, fp32) in {t1:.1f} s, "
                                f"{ncores} threads"}}
 
 
@@ -276,7 +290,7 @@ def side_block(args, cfg, label, steps=6, warmup=3, kernel_timing=True):
         opt.zero_grad()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    mt.check_pads_trail()
+    mt.check_no_leading_pads()
     value = B * L * steps / dt
     out = {"workload": f"{label}: MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} bf16, "
                        f"per-GPU batch {B}, fwd+smoothed-CE+bwd+Adam/Noam, dropout {args.dropout}",
@@ -311,7 +325,7 @@ def pmc_traffic(kernel, B, L, d):
     FETCH_SIZE / WRITE_SIZE runs of this same command, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950).
     Only reported when this run has a shape the counters were collected on (cfg2 at the per-GPU batch in the file name)."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((os.path.join(prof, f) for f in (f"r05_traffic_cfg2_b{B}.json", f"r04_traffic_cfg2_b{B}.json", f"r03_traffic_cfg2_b{B}.json", f"r02_traffic_cfg2_b{B}.json", f"r01_traffic_cfg2_b{B}.json")
+    path = next((os.path.join(prof, f) for f in (f"r06_traffic_cfg2_b{B}.json", f"r05_traffic_cfg2_b{B}.json", f"r04_traffic_cfg2_b{B}.json", f"r03_traffic_cfg2_b{B}.json", f"r02_traffic_cfg2_b{B}.json", f"r01_traffic_cfg2_b{B}.json")
                  if os.path.exists(os.path.join(prof, f))), None)
     if path is None or (L, d) != (2048, 512):
         return {"traffic": None}
@@ -323,13 +337,18 @@ def pmc_traffic(kernel, B, L, d):
     heads = d // 64
     ds_half = B * heads * (L // 32) * (L // 32 + 1) // 2 * 2048          # causal half of dS, bf16 32x32 tiles
     io = B * L * d * 2                                                   # one bf16 [B,L,d] tensor
+    # ALGORITHMIC bytes: the op's bf16 inputs and outputs, each once.  DESIGN bytes: the bf16 dS tiles the backward stores once (dK/dV)
+    # and reads twice (dQ, dE) instead of recomputing -- traffic this design chose, not traffic the operation needs
     algo = {"rel_attn_fwd_kernel": 4 * io,                               # q,k,v in, ctx out
-            "rel_attn_dkv_kernel": 6 * io + ds_half,                     # q,k,v,dO in, dk,dv out + the dS tiles (by design)
-            "rel_attn_dq_lite_kernel": 2 * io + ds_half,                 # k in, dq out, dS in
-            "rel_attn_de_tiles_kernel": io + ds_half}[kernel]            # q in, dS in
+            "rel_attn_dkv_kernel": 6 * io,                               # q,k,v,dO in, dk,dv out
+            "rel_attn_dq_lite_kernel": 2 * io,                           # k in, dq out
+            "rel_attn_de_tiles_kernel": io}[kernel]                      # q in (dE out is 128 KB)
+    design = 0 if kernel == "rel_attn_fwd_kernel" else ds_half
     tr = sum(k[n]["hbm_bytes_per_launch"] for n in match)
     return {"traffic": tr, "traffic_unit": f"bytes/launch (PMC, {os.path.basename(path)})",
-            "algorithmic_bytes_per_launch": algo}
+            "algorithmic_bytes_per_launch": algo, "design_bytes_per_launch": design,
+            "design_bytes_note": "the causal half of dS as bf16 32x32 tiles, written by dK/dV and read by dQ and dE (DESIGN.md 2.2)",
+            "traffic_over_algorithmic": tr / algo, "traffic_over_algorithmic_plus_design": tr / (algo + design)}
 
 
 def _free_port():
@@ -412,6 +431,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.nccl_channels > 0:                         # before the communicator exists: RCCL reads them at init
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(args.nccl_channels)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -432,7 +453,11 @@ def main():
     torch.manual_seed(0)
     mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=args.dropout).to(dev)
     mt.train()
-    dp = DataParallel(mt)
+    # stream plan: a CU-masked side stream for the off-critical-path half of the backward and / or CUs kept free for RCCL
+    plan = _ops.configure_streams(args.side_cus, args.rccl_cus, partition=not args.side_shared, device=dev) \
+        if (args.side_cus or args.rccl_cus) else None
+    run_stream = _ops.main_stream(dev)
+    dp = DataParallel(mt, groups=args.buckets or None)
     dp.measure_overlap = world > 1
     dp.overlap = not args.no_overlap
     opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale)
@@ -464,19 +489,25 @@ def main():
         torch.cuda.synchronize()
 
     last = None
-    for i in range(args.warmup):
-        last = step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(run_stream):
+        for i in range(args.warmup):
+            last = step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = step(args.warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
-    mt.check_pads_trail()      # device-side pads-only-trail record of every forward above (read after the timed region)
+    mt.check_no_leading_pads()      # device-side no-leading-pads record of every forward above (read after the timed region)
+    streams_cfg = ({"side_cus": plan.side.cus if plan.side else 0, "main_cus": plan.main.cus if plan.main else "all",
+                    "reserved_for_rccl": plan.reserved} if plan is not None else "one stream, whole chip")
+    if plan is not None:
+        _ops.configure_streams(0, 0, device=dev)           # the side blocks below (kernel timing, cfg4, batch 8, decode) run on one stream
+        plan = None
     events = float(world) * B * L * args.steps
     value = events / dt
     loss_val = float(last["loss"].item())
@@ -490,13 +521,15 @@ def main():
         "config": {"workload": f"{'cfg2 REMI_EventSeq' if args.workload == 'cfg2' else 'cfg4 MuMIDI_EventSeq'} MusicTransformer V={V} layers={nl} d_model={d} seq_len={L} "
                                f"bf16, fwd+smoothed-CE+bwd+Adam/Noam, dropout {args.dropout}",
                    "global_batch": world * B, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
-                   "final_loss": loss_val, "deterministic": _ops.deterministic()},
+                   "final_loss": loss_val, "deterministic": _ops.deterministic(),
+                   "streams": streams_cfg},
         "model_mfma_frac": value * train_flops_per_event(nl, d, L, V) / (world * PEAK_BF16_TFLOPS * 1e12),
     }
     if world > 1:
         exposed = dp.exposed_ms()
         bms = dp.bucket_ms()
-        out["dp"] = dict(dp.describe(), buckets=len(mt.store().buckets), overlap=dp.overlap,
+        out["dp"] = dict(dp.describe(), buckets=len(dp.bucket_names()), bucket_names=dp.bucket_names(), overlap=dp.overlap,
+                         rccl_cus=args.rccl_cus, nccl_channels=(args.nccl_channels or "default"), side_cus=args.side_cus,
                          allreduce_bytes_per_step=dp.bytes_reduced // max(1, args.warmup + args.steps),
                          exposed_allreduce_ms_per_step=exposed,
                          exposed_note="compute-stream stall between the end of backward and the Adam kernel (HIP events "
@@ -547,7 +580,7 @@ def main():
         out["roofline"].update(pmc_traffic(dom_k, B, L, d))
         # MFMA-busy of the attention kernels from the committed PMC passes of this shape (tools/pmc_attn.sh: SQ_VALU_MFMA_BUSY_CYCLES
         # / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)); like `traffic`, a committed measurement of this command, not of this run
-        pmc_path = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"r0{r_}_pmc_attn_b{B}.json") for r_ in (5, 4)) if os.path.exists(p_)), "")
+        pmc_path = next((p_ for p_ in (os.path.join(ROOT, "profiles", f"r0{r_}_pmc_attn_b{B}.json") for r_ in (6, 5, 4)) if os.path.exists(p_)), "")
         if (L, d) == (2048, 512) and pmc_path:
             pk = json.load(open(pmc_path))["kernels"]
             for k in per_kernel:

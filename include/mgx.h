@@ -34,8 +34,8 @@ typedef enum {
 /* thread-local, NUL-terminated description of the last failure on this thread */
 const char* mgx_last_error(void);
 /* library/ABI version (bumped on any signature change) */
-int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows; 16: mgx_smooth_ce_bwd takes a device-side scale, mgx_pad_bitmap a flag, mgx_set_deterministic; 17: mgx_rel_attn_bwd_parts bit 6 */
-#define MGX_ABI_VERSION 17
+int mgx_abi_version(void);   /* 2: mgx_rel_attn_bwd takes a workspace; 3: mgx_linear_dx takes an addend; 4: mgx_linear_dw_grouped; 5: GRU training ops; 6: sampler grammar mask; 7: mgx_linear_ln_fwd; 8: mgx_rel_attn_fwd/_weights take a workspace; 9: mgx_rel_attn_decode takes a workspace (split-K); 10: mgx_linear_dw_grouped takes a workspace; 11: decode K/V caches are head-major [B,h,Lmax,64]; 12: mgx_decode_embed_linear, mgx_rel_attn_decode_splits; attention partials are 68 floats (acc[64], m, l, 2 pad); 13: mgx_rel_attn_bwd_parts: dK/dV stores the dS tiles, bits 1/3 read them, bit 5 = dQ by recomputation; 14: mgx_gru_step_fwd/bwd, mgx_gru_step_x_fwd, fragment-ordered weights (*_frag), mgx_rel_attn_fwd_nomask; 15: mgx_sample_topk_topp_rows; 16: mgx_smooth_ce_bwd takes a device-side scale, mgx_pad_bitmap a flag, mgx_set_deterministic; 17: mgx_rel_attn_bwd_parts bit 6; 18: mgx_pad_bitmap's flag records LEADING pads only, mgx_stream_create_cu_mask / mgx_stream_set_cus / mgx_stream_cus / mgx_stream_destroy, mgx_set_deterministic_stream, mgx_linear_kernel_id */
+#define MGX_ABI_VERSION 18
 /* number of visible HIP devices, or a negative mgx_status */
 int mgx_device_count(void);
 
@@ -54,13 +54,34 @@ int mgx_device_count(void);
  * library is deterministic as it is.
  *   scratch: device memory, 8-byte aligned, owned by the caller and alive until the mode is switched off with
  *            mgx_set_deterministic(NULL, 0); the largest user needs 8 * max(N*K + N, V*d, 64*L) bytes (16 MiB covers cfg4).
- *   PROCESS-GLOBAL, SINGLE-STREAM STATE -- the one exception to "every entry point is stateless and takes its stream" (SURVEY
- *   8b): the registered scratch is shared by every call of the process, so (a) calls that use it must be issued on ONE stream at a
- *   time (two streams would zero / fold each other's partial sums), (b) the setting applies to all threads and all model instances
- *   of the process, (c) switching it while such a call is in flight is undefined.  This matches the deployment the library is
- *   built for -- one process per GPU, one compute stream -- and is why it is a mode and not an argument.             */
+ *   PROCESS-GLOBAL STATE -- the one exception to "every entry point is stateless and takes its stream" (SURVEY 8b): (a) the
+ *   setting applies to all threads and all model instances of the process, (b) switching it while such a call is in flight is
+ *   undefined, (c) the scratch registered here serves the calls of ONE stream at a time (two streams sharing it would zero / fold
+ *   each other's partial sums): every FURTHER stream that issues such calls -- the CU-masked side stream of the backward's
+ *   off-critical-path kernels, below -- registers a buffer of its own with mgx_set_deterministic_stream (ABI 18); a stream
+ *   without one uses the buffer registered here.                                                                        */
 int mgx_set_deterministic(void* scratch, size_t bytes);
 int mgx_deterministic(void);          /* 1 while a scratch is registered */
+/* ABI 18: a scratch of its own for the calls issued on `stream` (same requirements as above; NULL forgets it).  The mode must be
+ * on (mgx_set_deterministic); switching the mode off forgets every per-stream buffer.                                    */
+int mgx_set_deterministic_stream(void* stream, void* scratch, size_t bytes);
+
+/* ---- CU-masked streams (ABI 18)                      the backward of layers.py:152-161 as train.py:265-277 drives it; SURVEY 8e
+ * A training step is half MFMA-bound kernels (attention dK/dV and forward, the QKV / output-projection GEMMs) and half kernels
+ * at the HBM rate, some of which feed only the optimiser (dE, the weight gradients): they can run BESIDE the critical path
+ * instead of inside it -- if the two are kept on disjoint CUs, since workgroups of two unrestricted streams are dispatched
+ * one kernel after the other.  The same mask keeps CUs free for RCCL's kernels under data parallelism.
+ *   mgx_stream_create_cu_mask: *stream = a new HIP stream (hipExtStreamCreateWithCUMask) restricted to the CUs whose bits are
+ *     set in mask[0 .. words-1].  Bit i is the driver's logical CU i: consecutive bits go round the XCDs first, then round the
+ *     shader engines of an XCD, so "the low n bits" = n/8 CUs of every XCD (tools/cumask_probe.hip prints the mapping of a box).
+ *   mgx_stream_set_cus / mgx_stream_cus: the number of CUs the library assumes for `stream` (set by the call above; settable for
+ *     a stream created elsewhere; 0 forgets; an unknown stream = the whole device).  The persistent GEMM kernels launch one
+ *     workgroup per CU of the stream they run on and plan their M-splits for that many.
+ *   mgx_stream_destroy: forgets the stream (CU count, deterministic scratch) and destroys it.                            */
+int mgx_stream_create_cu_mask(void** stream, const uint32_t* mask, int words);
+int mgx_stream_set_cus(void* stream, int cus);
+int mgx_stream_cus(void* stream);
+int mgx_stream_destroy(void* stream);
 
 /* ---- K1: token embedding * sqrt(d) + sinusoid PE (+dropout)      layers.py:226-229, 22-39 ----
  * tok int32 [rows] (rows = B*L), table f32 [V,d], pe f32 [L,d] (precomputed once, device resident),
@@ -75,10 +96,12 @@ int mgx_embed_bwd(const int32_t* tok, const uint16_t* dout, float* dtable,
 
 /* ---- A3: key-padding bitmap from tokens                          utils.py:58-83 --------------
  * bits uint32 [B, L/32]: bit (j&31) of word j>>5 set iff tok[b,j] == pad.  L % 32 == 0.
- * flag (ABI 16; device uint32[1] or NULL): bit 0 is OR-ed in, and never cleared, when some pad token is followed by a real
- *   token in its row.  Padding may only TRAIL a sequence: a query whose visible keys are all padding has no defined result
- *   in the reference (softmax of -1e9 + x in fp32, layers.py:99-102) and is outside the parity contract, so the host side
- *   reads this flag at its next synchronisation point and refuses such input (no host sync on the hot path).            */
+ * flag (ABI 16; device uint32[1] or NULL): bit 0 is OR-ed in, and never cleared, when a row STARTS with a pad token and holds a
+ *   real token later (ABI 18; until then: any pad followed by a real token).  Only leading padding creates queries whose
+ *   visible keys are all padding; such a query has no defined result in the reference (softmax of -1e9 + x in fp32,
+ *   layers.py:99-102) and is outside the parity contract, so the host side reads this flag at its next synchronisation point
+ *   and refuses such input (no host sync on the hot path).  Trailing and interior pads are masked as keys exactly like the
+ *   reference's look-ahead mask does (utils.py:58-83) and are accepted.                                                  */
 int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, uint32_t* flag, int B, int L, int pad, void* stream);
 
 /* ---- K3+K4: fused relative global attention (Shaw/Huang skewing)  layers.py:86-106,111-133 ---
@@ -216,6 +239,14 @@ int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16_t* relu_y,
  * Both ACCUMULATE (fp32 atomics), so gradient accumulation over micro-batches needs no extra pass. */
 int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, float* gb,
                   int M, int N, int K, void* stream);
+/* ABI 18: which kernel family mgx_linear_fwd (kind 0: C [M,N], reduction K) or mgx_linear_dx (kind 1 / 2 / 3: no epilogue
+ * operand / ReLU mask / residual addend; dX [M,K], reduction N) launches for this shape on `stream` -- no launch, no device
+ * access.  For tests and profiles: which of the binary's GEMM kernels a measured or checked call really ran.              */
+#define MGX_GEMM_SKINNY 0    /* M <= 32: weight-streaming kernel */
+#define MGX_GEMM_TILE128 1   /* 128 x 128 tiles, four waves */
+#define MGX_GEMM_RING8 2     /* 256 x 256 tiles, persistent LDS-DMA ring, eight waves */
+#define MGX_GEMM_RING4 3     /* 256 x 256 tiles, four waves, generated asm tile statement */
+int mgx_linear_kernel_id(int kind, int M, int N, int K, void* stream);
 /* the same for up to MGX_DW_MAX_GROUP weights whose dY / X share the row count M (the four projections of one
  * encoder block, layers.py:152-161), in one launch: fewer M-splits fill the chip, so less atomic traffic.  */
 #define MGX_DW_MAX_GROUP 8

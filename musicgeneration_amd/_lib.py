@@ -13,7 +13,7 @@ _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
 # the ABI the SIGNATURES table below was written for (MGX_ABI_VERSION of include/mgx.h).  A left-over
 # libmgx.so of another ABI still exports the same names: calling it with this table would shift arguments.
-EXPECTED_ABI = 17
+EXPECTED_ABI = 18
 
 # name -> argtypes ; every symbol declared in include/mgx.h (restype int unless noted)
 SIGNATURES = {
@@ -21,6 +21,12 @@ SIGNATURES = {
     "mgx_device_count": [],
     "mgx_set_deterministic": [_vp, _sz],
     "mgx_deterministic": [],
+    "mgx_set_deterministic_stream": [_vp, _vp, _sz],
+    "mgx_stream_create_cu_mask": [_vp, _vp, _i],
+    "mgx_stream_set_cus": [_vp, _i],
+    "mgx_stream_cus": [_vp],
+    "mgx_stream_destroy": [_vp],
+    "mgx_linear_kernel_id": [_i, _i, _i, _i, _vp],
     "mgx_embed_pe_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _vp],
     "mgx_pad_bitmap": [_vp, _vp, _vp, _i, _i, _i, _vp],

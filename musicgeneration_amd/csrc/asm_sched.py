@@ -291,3 +291,17 @@ def schedule(items, ngaps=44, budget0=None):
     return table, budget
 
 
+
+
+def write_if_changed(path, text):
+    """write a generated file only when its content differs: an unchanged schedule keeps its mtime, so a variant build (which
+    runs the generators too) does not make the product library look stale (musicgeneration_amd/_build.py: _stale)"""
+    try:
+        with open(path) as f:
+            if f.read() == text:
+                return False
+    except OSError:
+        pass
+    with open(path, "w") as f:
+        f.write(text)
+    return True

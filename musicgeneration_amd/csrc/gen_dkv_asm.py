@@ -27,7 +27,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asm_sched import COST, Gen, Item, a, chain, crow, regs, s, salu_items, schedule, v  # noqa: E402
+from asm_sched import COST, Gen, Item, a, chain, crow, regs, s, salu_items, schedule, v, write_if_changed  # noqa: E402
 
 # ---------------------------------------------------------------------------------------------------------------------
 # register map
@@ -639,7 +639,9 @@ def main():
 def write(here):
     lines, g = generate()
     path = os.path.join(here, "rel_attn_dkv64_loop_peel.inc" if PEEL else "rel_attn_dkv64_loop_stamp.inc" if STAMP else "rel_attn_dkv64_loop.inc")
-    with open(path, "w") as f:
+    import io
+    f = io.StringIO()
+    if True:
         f.write("// GENERATED by gen_dkv_asm.py -- do not edit.  The hand-scheduled main loop of rel_attn_dkv64_kernel (one asm statement):\n")
         f.write("// operands %0..%7 = dk[0][0], dk[0][1], dv[0][0], dv[0][1], dk[1][0], dk[1][1], dv[1][0], dv[1][1] (\"+a\"), %8 = LDS address of the\n")
         f.write("// wave's parameter block (\"s\").  Register map, schedule and hazard rules: gen_dkv_asm.py.\n")
@@ -651,6 +653,7 @@ def write(here):
                 f.write(f'    "{ln}\\n\\t" \\\n')
         f.write('    ""\n')
         f.write("#define MGX_DKV64_LOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+    write_if_changed(path, f.getvalue())
     n_loop = sum(1 for ln in lines if not ln.startswith(";") and not ln.endswith(":"))
     print(f"wrote {path}: {n_loop} instructions, s_nop wait states inserted: {g.nops}; counts {g.stats}", file=sys.stderr)
 

@@ -5,7 +5,8 @@ linear_dw_ring4_kernel (first half of this file) and the forward / dX kernel lin
     python musicgeneration_amd/csrc/gen_gemm_asm.py            -> musicgeneration_amd/csrc/linear_dw_ring4_loop.inc, linear_ring4_loop.inc
 
 Diagnostic builds (results are garbage, timing only; tools/dw4_clock.sh, tools/ring4_times.py): MGX_DW4_NODMA / NOREAD / NOMFMA / NOSYNC and
-MGX_RING4_DIAG in the environment of the build leave parts of the loops out.
+MGX_RING4_DIAG in the environment of the build leave parts of the loops out; such loops are written to linear_*_loop_diag.inc (untracked),
+which linear.hip includes instead of the tracked files when built with -DMGX_GEMM_DIAG=1.
 
 Weight gradient:
 
@@ -27,7 +28,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from asm_sched import COST, Gen, Item, a, chain, regs, s, schedule, v  # noqa: E402
+from asm_sched import COST, Gen, Item, a, chain, regs, s, schedule, v, write_if_changed  # noqa: E402
 
 V_L = 16             # lane
 V_VOY = 17           # ..20 DMA source offsets of this wave's four pieces of the dY image
@@ -52,6 +53,9 @@ NOMFMA = bool(os.environ.get("MGX_DW4_NOMFMA"))
 NOREAD = bool(os.environ.get("MGX_DW4_NOREAD"))
 RING_DIAG = os.environ.get("MGX_RING4_DIAG", "")     # "noa" / "nob": no DMA of the A / B image; "nora" / "norb": no fragment reads of A / B
 NOSYNC = os.environ.get("MGX_DW4_NOSYNC", "")        # "1": no wait, no barrier; "w": no wait; "b": no barrier
+# any of the knobs above: the (wrong-result) loops go to linear_*_loop_diag.inc, which linear.hip includes under -DMGX_GEMM_DIAG=1 --
+# never into the tracked files a product build reads (an exported knob used to turn the next auto-build into a garbage GEMM library)
+DIAG = bool(NODMA or NOMFMA or NOREAD or RING_DIAG or NOSYNC)
 
 
 def frag(fs, kind, i):
@@ -518,8 +522,10 @@ def ring_clobbers():
 
 
 def write_ring(here):
-    path = os.path.join(here, "linear_ring4_loop.inc")
-    with open(path, "w") as f:
+    path = os.path.join(here, "linear_ring4_loop_diag.inc" if DIAG else "linear_ring4_loop.inc")
+    import io
+    f = io.StringIO()
+    if True:
         f.write("// GENERATED by gen_gemm_asm.py -- do not edit.  One tile of linear_ring4_kernel<BTRANS, PRE> (one asm statement each): operands\n")
         f.write("// %0..%15 = acc[rt][ct] (\"=a\": all 256 AGPRs, written from C = 0), %16 = LDS address of the wave's parameter block (\"s\").\n")
         for btrans, name in ((False, "NT"), (True, "NN")):
@@ -535,6 +541,7 @@ def write_ring(here):
             print(f"wrote {path} ({name}): {n_ins} instructions, s_nop wait states inserted: {g.nops}", file=sys.stderr)
         f.write("#define MGX_RING4_CLOBBERS " + ", ".join(f'"{c}"' for c in ring_clobbers()) + "\n")
         f.write(f"#define MGX_RING4_EPI_STORES {EPI_STORES}\n")
+    write_if_changed(path, f.getvalue())
 
 
 def clobbers():
@@ -544,8 +551,10 @@ def clobbers():
 
 def write(here):
     lines, g = generate()
-    path = os.path.join(here, "linear_dw_ring4_loop.inc")
-    with open(path, "w") as f:
+    path = os.path.join(here, "linear_dw_ring4_loop_diag.inc" if DIAG else "linear_dw_ring4_loop.inc")
+    import io
+    f = io.StringIO()
+    if True:
         f.write("// GENERATED by gen_gemm_asm.py -- do not edit.  The hand-scheduled main loop of linear_dw_ring4_kernel (one asm statement):\n")
         f.write("// operands %0..%15 = acc[rt][ct] (\"+a\": all 256 AGPRs), %16..%19 = the bias-gradient partial sums (\"+v\"), %20 = LDS address of the\n")
         f.write("// wave's parameter block (\"s\").  Register map and schedule: gen_gemm_asm.py.\n")
@@ -557,6 +566,7 @@ def write(here):
                 f.write(f'    "{ln}\\n\\t" \\\n')
         f.write('    ""\n')
         f.write("#define MGX_DW4_LOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+    write_if_changed(path, f.getvalue())
     n_ins = sum(1 for ln in lines if not ln.startswith(";") and not ln.endswith(":"))
     print(f"wrote {path}: {n_ins} instructions, s_nop wait states inserted: {g.nops}; counts {g.stats}", file=sys.stderr)
 

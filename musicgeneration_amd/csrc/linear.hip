@@ -712,7 +712,11 @@ __global__ __launch_bounds__(512, 1) void linear_ring_kernel(const uint16_t* __r
 // bit-identical results.  Stages of 64 reduction columns in two 64 KB slots, so that every DMA instruction fetches whole 128-byte lines
 // (gen_gemm_asm.py).  LDS: 2 x 64 KB stages + 4 x 4 KB patches + 4 x 4 KB parameter blocks (bias at + 512) = 160 KB.
 // =================================================================================================
+#if defined(MGX_GEMM_DIAG) && MGX_GEMM_DIAG
+#include "linear_ring4_loop_diag.inc"      // timing-only loops of a diagnostic build (gen_gemm_asm.py with MGX_RING4_DIAG / MGX_DW4_NO*)
+#else
 #include "linear_ring4_loop.inc"
+#endif
 #ifdef MGX_DW4_TIMES
 extern __device__ unsigned long long mgx_dw4_times_buf[8 * 1024];
 #endif
@@ -1445,7 +1449,11 @@ __global__ __launch_bounds__(512, 1) void linear_dw_ring_kernel(const DwRing g, 
 // statement that owns them (gen_gemm_asm.py -> linear_dw_ring4_loop.inc; parameters through an LDS block as in rel_attn_dkv64.hip);
 // unit decoding, the parameter block and the epilogue stay HIP.  Same images, same stage order, same MFMA operand order as the
 // eight-wave kernel: the partial tiles are bit-identical to its.
+#if defined(MGX_GEMM_DIAG) && MGX_GEMM_DIAG
+#include "linear_dw_ring4_loop_diag.inc"
+#else
 #include "linear_dw_ring4_loop.inc"
+#endif
 #ifdef MGX_DW4_TIMES
 // diagnostic builds: s_memrealtime (100 MHz) at a unit's start, loop start, loop end and end, per workgroup (tools/dw4_times.py)
 __device__ unsigned long long mgx_dw4_times_buf[8 * 1024];     // [workgroup][4 real-time stamps, 4 shader-clock stamps]
@@ -1824,15 +1832,10 @@ static void set_attrs() {
 
 // The ring kernel pays when its 256 x 256 tiles fill the chip (one persistent workgroup per CU) without much padding.
 // MGX_GEMM_RING=0 / 1 forces it off / on where the shape allows (A/B timing; experiment builds only).
-static int ring_grid(int M, int NO, int R) {
-    static int cus = 0, env = -2;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        env = gemm_knob("MGX_GEMM_RING", -1);
-    }
+static int ring_grid(int M, int NO, int R, void* stream) {
+    static int env = -2;
+    if (env == -2) env = gemm_knob("MGX_GEMM_RING", -1);
+    const int cus = mgx_stream_cu_count(stream);            // a CU-masked stream: one persistent workgroup per CU it may use
     if (env == 0 || R % 32 != 0 || R < 128 || M % 256 != 0 || NO % 256 != 0) return 0;     // whole tiles only
     const long ntm = (M + 255) / 256, ntn = (NO + 255) / 256;
     const long ntiles = ntm * ntn;
@@ -1870,7 +1873,7 @@ extern "C" int mgx_linear_fwd(const uint16_t* A, const uint16_t* W, const float*
         MGX_CHECK_LAUNCH("mgx_linear_fwd");
         return MGX_OK;
     }
-    if (const int rg = ring_grid(M, N, K)) {
+    if (const int rg = ring_grid(M, N, K, stream)) {
         if (ring4_shape(K, N, (long long)M * N))
             hipLaunchKernelGGL((linear_ring4_kernel<false, 0>), dim3(rg), dim3(256), RG_LDS, (hipStream_t)stream, A, W, bias,
                                (const uint16_t*)nullptr, (const uint16_t*)nullptr, C, M, N, K, act);
@@ -1902,10 +1905,10 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
     MGX_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0, MGX_ERR_SHAPE,
                 "mgx_linear_dx: need N%%8==0 and K%%8==0 (got M=%d N=%d K=%d)", M, N, K);
     set_attrs();
-    if (const int rg = (relu_y && addend) ? 0 : ring_grid(M, K, N)) {   // dX [M,K] = dY [M,N] . W [N,K]: reduction over N, W read transposed
-        // linear_ring_kernel<true> has ONE straight-line epilogue per operand (addend, else mask): a call with both would silently
-        // drop the mask, so the invariant is checked where the kernel is launched, not only in the condition above
-        MGX_REQUIRE(!(relu_y && addend), MGX_ERR_SHAPE, "mgx_linear_dx: the ring kernel takes a ReLU mask OR a residual addend, not both");
+    if (const int rg = (relu_y && addend) ? 0 : ring_grid(M, K, N, stream)) {   // dX [M,K] = dY [M,N] . W [N,K]: reduction over N, W read transposed
+        // the ring kernels have ONE straight-line epilogue per operand (addend, else mask): a call with both never gets here (rg = 0
+        // above) and takes the 128 x 128 kernel.  relu_y and addend are [M,K] like dX: the epilogue's 32-bit offsets (bounded by
+        // ring4_shape's out_elems check) address all three
 #define MGX_RING4_DX(PRE) hipLaunchKernelGGL((linear_ring4_kernel<true, PRE>), dim3(rg), dim3(256), RG_LDS, (hipStream_t)stream, dY, W, \
                                              (const float*)nullptr, relu_y, addend, dX, M, K, N, 0)
         if (ring4_shape(N, K, (long long)M * K)) { if (addend) MGX_RING4_DX(2); else if (relu_y) MGX_RING4_DX(1); else MGX_RING4_DX(0); }
@@ -1928,6 +1931,20 @@ extern "C" int mgx_linear_dx(const uint16_t* dY, const uint16_t* W, const uint16
 #undef MGX_DX_LAUNCH
     MGX_CHECK_LAUNCH("mgx_linear_dx");
     return MGX_OK;
+}
+
+// Which kernel family a forward / dX call of this shape takes on `stream` (mgx.h: mgx_linear_kernel_id; tests assert that the
+// bench-shape calls they check really run the ring kernels of THIS binary).  Mirrors the dispatch of the two entry points above.
+extern "C" int mgx_linear_kernel_id(int kind, int M, int N, int K, void* stream) {
+    MGX_REQUIRE(kind >= 0 && kind <= 3 && M > 0 && N > 0 && K > 0, MGX_ERR_SHAPE, "mgx_linear_kernel_id: kind 0..3, positive sizes");
+    if (kind == 0) {                                       // forward: C [M,N] = A [M,K] . W [N,K]^T
+        if (M <= 32) return MGX_GEMM_SKINNY;
+        if (!ring_grid(M, N, K, stream)) return MGX_GEMM_TILE128;
+        return ring4_shape(K, N, (long long)M * N) ? MGX_GEMM_RING4 : MGX_GEMM_RING8;
+    }
+    // dX [M,K] = dY [M,N] . W [N,K]; kind 1: no epilogue operand, 2: ReLU mask, 3: residual addend (both: the 128 x 128 kernel)
+    if (!ring_grid(M, K, N, stream)) return MGX_GEMM_TILE128;
+    return ring4_shape(N, K, (long long)M * K) ? MGX_GEMM_RING4 : MGX_GEMM_RING8;
 }
 
 extern "C" int mgx_linear_dw(const uint16_t* dY, const uint16_t* X, float* gW, float* gb, int M, int N, int K,
@@ -1975,7 +1992,7 @@ static bool dw_ring_shape(int N, int K) {
     return (long long)N * K * 10 >= tiles * 65536 * 6;
 }
 // plan: number of M-splits so that tiles x splits fills the CUs once; every split gets at least one 32-row step.
-static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRing* out) {
+static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRing* out, int cus) {
     static int env = -2;
     if (env == -2) env = gemm_knob("MGX_GEMM_RING", -1);
     if (env == 0 || M % 32 != 0 || M < 4096) return false;
@@ -1991,13 +2008,6 @@ static bool dw_ring_plan(const mgx_dw_problem* problems, int count, int M, DwRin
         g.first_tile[i + 1] = g.first_tile[i] + ((q.N + 255) / 256) * ((q.K + 255) / 256);
     }
     const int tiles = g.first_tile[count];
-    static int cus = 0;                                    // queried once (the call is not cheap)
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
     if (tiles > cus) return false;
     const int total = M / 32;
     int splits = cus / tiles;
@@ -2024,7 +2034,8 @@ extern "C" size_t mgx_linear_dw_grouped_workspace(const mgx_dw_problem* problems
     if (!problems || count <= 0 || count > MGX_DW_MAX_GROUP) return 0;
     mgx_dw_problem ring[MGX_DW_MAX_GROUP], rest[MGX_DW_MAX_GROUP];
     int nr, ns;
-    if (!dw_split(problems, count, ring, &nr, rest, &ns) || !dw_ring_plan(ring, nr, M, &g)) return 0;
+    // (no stream here: planned for the whole device -- a CU-masked stream runs fewer M-splits, so this is an upper bound for it)
+    if (!dw_split(problems, count, ring, &nr, rest, &ns) || !dw_ring_plan(ring, nr, M, &g, mgx_stream_cu_count(nullptr))) return 0;
     return (size_t)g.first_tile[g.n] * g.splits * 65536 * sizeof(float);
 }
 
@@ -2037,7 +2048,7 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int coun
     int nring, nrest;
     const mgx_dw_problem* problems = problems_in;
     int count = count_in;
-    if (dw_split(problems_in, count_in, ring_p, &nring, rest_p, &nrest) && nrest > 0 && dw_ring_plan(ring_p, nring, M, nullptr)) {
+    if (dw_split(problems_in, count_in, ring_p, &nring, rest_p, &nrest) && nrest > 0 && dw_ring_plan(ring_p, nring, M, nullptr, mgx_stream_cu_count(stream))) {
         if (int rc = mgx_linear_dw_grouped(ring_p, nring, M, workspace, ws_bytes, stream)) return rc;
         problems = rest_p;
         count = nrest;
@@ -2055,7 +2066,7 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int coun
     }
     set_attrs();
     DwRing rg;
-    if (dw_ring_plan(problems, count, M, &rg)) {
+    if (dw_ring_plan(problems, count, M, &rg, mgx_stream_cu_count(stream))) {
         const size_t need = (size_t)rg.first_tile[rg.n] * rg.splits * 65536 * sizeof(float);
         MGX_REQUIRE(workspace && ws_bytes >= need && ((uintptr_t)workspace & 15) == 0, MGX_ERR_SHAPE,
                     "mgx_linear_dw_grouped: workspace must be 16-byte aligned and >= mgx_linear_dw_grouped_workspace() = %zu bytes "

@@ -115,6 +115,8 @@ void mgx_set_error(const char* fmt, ...);
 // Cross-workgroup sums as 64-bit fixed-point integer atomics (value * 2^30) into a caller-registered scratch, folded back to
 // fp32 by det_fold_kernel: the total is independent of the order in which the workgroups arrive.
 long long* mgx_det_scratch(size_t elems, void* stream, int* rc);
+// CUs the kernels of `stream` may run on: the device's count, or the size of the stream's CU mask (api.cpp, mgx_stream_create_cu_mask)
+int mgx_stream_cu_count(void* stream);
 constexpr float MGX_DET_SCALE = 1073741824.f;              // 2^30: resolution 9.3e-10
 // A partial sum that is NaN, infinite or >= 2^31 in magnitude has no fixed-point image (the conversion would give 0, garbage or a
 // wrapped value, and a diverging run would fold back to finite numbers).  Such a partial POISONS its destination instead: a signed

@@ -193,8 +193,12 @@ __global__ void pad_bitmap_kernel(const int32_t* __restrict__ tok, uint32_t* __r
         if (lane == 0) bits[i >> 5] = (uint32_t)m;
         if (lane == 32) bits[i >> 5] = (uint32_t)(m >> 32);
     }
-    // padding may only TRAIL a row: a pad followed by a real token raises the sticky flag
-    if (flag && p && (i % L) != L - 1 && tok[i + 1] != pad) atomicOr(flag, 1u);
+    // LEADING padding is the one input class outside the parity contract: a row that starts with a pad has
+    // queries whose every visible key is masked (the reference's result there is a rounding artefact of -1e9 + x).  A real token in
+    // such a row raises the sticky flag; trailing and interior pads (some real key j <= i for every real query i) do not -- the
+    // attention kernels mask those keys exactly as the reference's look-ahead mask does (utils.py:58-83).  An all-pad row has no
+    // real query and stays silent.
+    if (flag && i < total && !p && tok[i - (i % L)] == pad) atomicOr(flag, 1u);
 }
 extern "C" int mgx_pad_bitmap(const int32_t* tok, uint32_t* bits, uint32_t* flag, int B, int L, int pad, void* stream) {
     MGX_REQUIRE(tok && bits, MGX_ERR_NULL, "mgx_pad_bitmap: NULL pointer");

@@ -11,6 +11,7 @@ Bucket sizes at cfg2: 1.51 M params = 6.0 MB fp32 per layer; xGMI ring all-reduc
 from __future__ import annotations
 
 import contextlib
+import time
 from typing import Dict, List, Optional
 
 import torch
@@ -20,8 +21,12 @@ import torch.distributed as dist
 class DataParallel:
     """Wraps a MusicTransformer: hooks its bucket-ready callbacks, broadcasts rank 0's weights."""
 
-    def __init__(self, model, process_group=None, force_collectives: bool = False):
-        """``force_collectives``: issue every collective even in a world of one rank (broadcast, per-bucket all-reduce,
+    MAX_TIMED = 256        # per-bucket (issue, complete) pairs kept between two bucket_ms() calls (a train loop that never asks)
+
+    def __init__(self, model, process_group=None, force_collectives: bool = False, groups: Optional[int] = None):
+        """``groups``: merge the per-layer buckets into that many contiguous groups (``bench.py --buckets 2``: fewer, larger
+        collectives -- one at the half-way point of backward, one at its end; DESIGN.md section 4, co-residency mitigation 3).
+        ``force_collectives``: issue every collective even in a world of one rank (broadcast, per-bucket all-reduce,
         loss-weight all-reduce).  A sum over one rank is the identity, so results must equal a run without data
         parallelism up to the summation-order noise of the kernels' own fp32 atomics (bit-identical under
         MGX_DETERMINISTIC=1) -- which lets a single-GPU box prove RCCL communicator setup, stream ordering against the backward
@@ -44,6 +49,11 @@ class DataParallel:
         self._bucket_t: Dict[str, List] = {}
         self._host_t0: Dict[int, tuple] = {}
         self._mstream = None              # side stream that waits for each collective and records its completion (nccl only)
+        self._groups: Optional[List[tuple]] = None    # merged buckets: (group name, lo, hi, member names in flat-buffer order)
+        self._group_of: Dict[str, int] = {}
+        self._arrived: Dict[int, int] = {}
+        if groups is not None:
+            self.merge_buckets(groups)
         model._dp = self
         if self.world > 1 or self.force:
             st = model.store()
@@ -65,27 +75,72 @@ class DataParallel:
         finally:
             self._sync = old
 
+    def merge_buckets(self, groups: int) -> None:
+        """Merge the model's buckets (embedding | layer 0 .. N-1 | fc, contiguous in the flat gradient buffer in that order) into
+        ``groups`` contiguous runs of about equal byte size.  A group's all-reduce is issued when its LAST member reports ready;
+        backward completes the members from the top of the buffer down (fc, layer N-1, ..., layer 0, embedding), so the top group
+        goes out in the middle of backward and the bottom one at its end."""
+        st = self.model.store()
+        names = [b[0] for b in st.buckets]
+        if groups is None or groups >= len(names):
+            self._groups, self._group_of = None, {}
+            return
+        if groups < 1:
+            raise ValueError("merge_buckets: at least one group")
+        total = st.buckets[-1][2] - st.buckets[0][1]
+        out, cur, start = [], [], st.buckets[0][1]
+        for i, (bname, lo, hi) in enumerate(st.buckets):
+            cur.append(bname)
+            left_names, left_groups = len(names) - i - 1, groups - len(out) - 1
+            if left_groups == 0:
+                continue
+            if (hi - st.buckets[0][1]) * groups >= total * (len(out) + 1) or left_names == left_groups:
+                out.append(("+".join(cur), start, hi, tuple(cur)))
+                cur, start = [], hi
+        out.append(("+".join(cur), start, st.buckets[-1][2], tuple(cur)))
+        self._groups = out
+        self._group_of = {n: gi for gi, g in enumerate(out) for n in g[3]}
+        self._arrived = {}
+
+    def bucket_names(self) -> List[str]:
+        """the all-reduce units of a step, in flat-buffer order (merged groups when ``merge_buckets`` is in effect)"""
+        return [g[0] for g in self._groups] if self._groups else [b[0] for b in self.model.store().buckets]
+
     def bucket_ready(self, name: str):
-        """called from inside backward when every gradient of bucket ``name`` has been accumulated"""
+        """called from inside backward when every gradient of bucket ``name`` has been accumulated (from the context of the
+        stream that wrote the last of them: the collective is ordered behind that stream)"""
         if (self.world == 1 and not self.force) or not self._sync:
             return
+        if self._groups is not None:
+            gi = self._group_of[name]
+            self._arrived[gi] = self._arrived.get(gi, 0) + 1
+            if self._arrived[gi] < len(self._groups[gi][3]):
+                return
+            self._arrived[gi] = 0
+            name = self._groups[gi][0]
         if not self.overlap:
             self._pending.append(name)
             return
         self._issue(name)
 
+    def _slices(self):
+        if self._groups is not None:
+            return [(g[0], g[1], g[2]) for g in self._groups]
+        return self.model.store().buckets
+
     def _issue(self, name: str):
         st = self.model.store()
-        for bname, lo, hi in st.buckets:
+        for bname, lo, hi in self._slices():
             if bname == name:
                 t = st.grad[lo:hi]
                 timed = self.measure_overlap
                 nccl = timed and t.is_cuda and dist.get_backend(self.pg) == "nccl"
                 if nccl:
+                    # the issuing stream, now: with overlap the moment the bucket's gradients are complete; in no-overlap mode
+                    # _issue runs from wait_all(), i.e. after the whole backward (the bucket has been complete for a while)
                     ev0 = torch.cuda.Event(enable_timing=True)
-                    ev0.record()                           # compute stream: the moment the bucket's gradients are complete
+                    ev0.record()
                 elif timed:
-                    import time
                     t0 = time.perf_counter()
                 w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 if nccl:
@@ -96,7 +151,9 @@ class DataParallel:
                         w.wait()
                         ev1 = torch.cuda.Event(enable_timing=True)
                         ev1.record()
-                    self._bucket_t.setdefault(name, []).append((ev0, ev1))
+                    pairs = self._bucket_t.setdefault(name, [])
+                    pairs.append((ev0, ev1))
+                    del pairs[:-self.MAX_TIMED]
                 elif timed:
                     self._host_t0[id(w)] = (name, t0)       # gloo: host clock, closed in wait_all (wait() blocks the host there)
                 self._works.append(w)
@@ -120,9 +177,10 @@ class DataParallel:
         for w in self._works:
             w.wait()
             if id(w) in self._host_t0:
-                import time
                 name, t0 = self._host_t0.pop(id(w))
-                self._bucket_t.setdefault(name, []).append(time.perf_counter() - t0)
+                secs = self._bucket_t.setdefault(name, [])
+                secs.append(time.perf_counter() - t0)
+                del secs[:-self.MAX_TIMED]
         self._works.clear()
         if ev is not None:
             ev[1].record()

@@ -46,7 +46,7 @@ class MusicTransformer(torch.nn.Module):
         self._store: Optional[FlatStore] = None
         self._seed_ctr = 0
         self._dp = None                          # set by dp.DataParallel
-        self._pad_flag: Optional[torch.Tensor] = None   # device int32[1], sticky: a pad token was followed by a real one
+        self._pad_flag: Optional[torch.Tensor] = None   # device int32[1], sticky: a row started with padding and held real tokens
 
     # ------------------------------------------------------------------------------------------
     # flat storage
@@ -155,17 +155,20 @@ class MusicTransformer(torch.nn.Module):
         self._lp_store, self._lp = st, out
         return out
 
-    def check_pads_trail(self) -> None:
-        """The library-boundary twin of ``utils.check_pads_trail``: every ``forward`` lets the bitmap kernel record, on the
-        device, whether some pad token was followed by a real one (leading / interior padding: rows with fully masked queries,
-        outside the parity contract with the reference).  Reading the record is a device synchronisation,
-        so it is done here, on request -- train.py calls it where it prints metrics, bench.py after its timed region -- and
-        not inside ``forward``.  Raises ValueError and clears the record."""
+    def check_no_leading_pads(self) -> None:
+        """The library-boundary twin of ``utils.check_no_leading_pads``: every ``forward`` lets the bitmap kernel record, on the
+        device, whether some row STARTED with padding and held real tokens later (rows with fully masked queries, outside the
+        parity contract with the reference; trailing and interior pads are masked like the reference
+        masks them and are accepted).  Reading the record is a device synchronisation, so it is done here, on request --
+        train.py calls it where it prints metrics, bench.py after its timed region -- and not inside ``forward``.  Raises
+        ValueError and clears the record."""
         if self._pad_flag is not None and int(self._pad_flag.item()) != 0:
             self._pad_flag.zero_()
-            raise ValueError(f"a batch handed to MusicTransformer.forward had padding token {self.pad_token} followed by a "
-                             "real token: pads must only trail (leading / interior padding is outside the parity contract "
-                             "with the reference)")
+            raise ValueError(f"a batch handed to MusicTransformer.forward had a row that starts with padding token {self.pad_token} "
+                             "and holds real tokens later: leading padding is outside the parity contract with the reference "
+                             "(fully masked queries); pads may trail or sit inside a sequence")
+
+    check_pads_trail = check_no_leading_pads      # the name of rounds 4-5
 
     def forward(self, x, length=None, writer=None):
         if self.training or not self.infer:

@@ -31,23 +31,39 @@ def _need_cuda(*ts):
 # deterministic-reduction mode (include/mgx.h: mgx_set_deterministic)
 # --------------------------------------------------------------------------------------------------
 _det_scratch = None          # the registered buffer must outlive the mode: kept here
+_det_stream_scratch = {}     # stream pointer -> buffer of that stream (mgx_set_deterministic_stream)
+_DET_BYTES = 32 << 20
 
 
-def set_deterministic(on: bool = True, device=None, nbytes: int = 32 << 20) -> None:
+def set_deterministic(on: bool = True, device=None, nbytes: int = _DET_BYTES) -> None:
     """Switch the library's cross-workgroup sums (dE, vocabulary dW / db, block bias gradients, embedding gradient, loss
     statistics) to order-independent fixed-point integer atomics: repeated runs -- and a data-parallel run against the
     single-process run of the same global batch -- then agree bit for bit on everything the kernels compute.  Costs a few
-    percent; ``MGX_DETERMINISTIC=1`` in the environment switches it on when the first model moves to the GPU.  Process-wide;
-    use ONE stream for the training kernels while it is on."""
+    percent; ``MGX_DETERMINISTIC=1`` in the environment switches it on when the first model moves to the GPU.  Process-wide.
+    The scratch registered here serves ONE stream at a time; the CU-masked side stream of ``configure_streams`` gets a buffer
+    of its own (registered here when it exists already, by ``configure_streams`` when it is created later)."""
     global _det_scratch
     lib = _lib.load()
     if not on:
         check(lib.mgx_set_deterministic(None, 0), "mgx_set_deterministic")
         _det_scratch = None
+        _det_stream_scratch.clear()
         return
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=device if device is not None else torch.device("cuda"))
+    dev = device if device is not None else torch.device("cuda")
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     check(lib.mgx_set_deterministic(ptr(buf), buf.numel()), "mgx_set_deterministic")
     _det_scratch = buf
+    for plan in _STREAM_PLANS.values():
+        _det_register_stream(plan.side, nbytes)
+
+
+def _det_register_stream(ms, nbytes: int = _DET_BYTES) -> None:
+    """deterministic mode on: the masked stream ``ms`` issues calls that use the fixed-point scratch -> give it one of its own"""
+    if ms is None or not deterministic() or ms.ptr in _det_stream_scratch:
+        return
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=ms.device)
+    check(_lib.load().mgx_set_deterministic_stream(ms.ptr, ptr(buf), buf.numel()), "mgx_set_deterministic_stream")
+    _det_stream_scratch[ms.ptr] = buf
 
 
 def deterministic() -> bool:
@@ -55,11 +71,108 @@ def deterministic() -> bool:
 
 
 # --------------------------------------------------------------------------------------------------
+# CU-masked streams (include/mgx.h: mgx_stream_create_cu_mask) and the two-stream plan of the backward
+# --------------------------------------------------------------------------------------------------
+class MaskedStream:
+    """A HIP stream whose kernels may only run on ``cus`` CUs: logical CUs ``first .. first + cus - 1`` of the driver's
+    numbering, which deals consecutive CUs round the XCDs first -- so a run of n (a multiple of 8) is n/8 CUs of every XCD, and
+    two disjoint runs are disjoint sets of CUs.  ``.stream`` is the ``torch.cuda.ExternalStream`` over it (events, allocator,
+    ``with torch.cuda.stream(...)``), ``.ptr`` the raw ``hipStream_t`` the library's CU-count registry knows."""
+
+    def __init__(self, cus: int, first: int = 0, device=None):
+        lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        total = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if cus <= 0 or first < 0 or first + cus > total:
+            raise ValueError(f"MaskedStream: CUs {first}..{first + cus - 1} do not fit the device's {total}")
+        words = (total + 31) // 32
+        mask = (ctypes.c_uint32 * words)()
+        for i in range(first, first + cus):
+            mask[i // 32] |= 1 << (i % 32)
+        out = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.mgx_stream_create_cu_mask(ctypes.byref(out), ctypes.cast(mask, ctypes.c_void_p), words), "mgx_stream_create_cu_mask")
+        self.ptr, self.cus, self.first = out.value, cus, first
+        self.stream = torch.cuda.ExternalStream(self.ptr, device=self.device)
+
+    def close(self):
+        if self.ptr is not None:
+            self.stream.synchronize()
+            _det_stream_scratch.pop(self.ptr, None)
+            check(_lib.load().mgx_stream_destroy(self.ptr), "mgx_stream_destroy")
+            self.ptr = None
+
+
+class StreamPlan:
+    """``side``: the masked stream of the backward's off-critical-path kernels (dE from the stored dS tiles, the block's weight
+    gradients -- they feed only the optimiser); ``main``: the masked stream of everything else (the complement of ``side``
+    minus the CUs left to RCCL), or None when the caller's own stream stays unrestricted."""
+    __slots__ = ("side", "main", "reserved", "last")
+
+    def __init__(self, side, main, reserved):
+        self.side, self.main, self.reserved, self.last = side, main, reserved, None
+
+
+_STREAM_PLANS = {}           # device index -> StreamPlan
+
+
+def configure_streams(side_cus: int = 0, reserve_cus: int = 0, partition: bool = True, device=None):
+    """Run the HBM-bound, off-critical-path half of an encoder block's backward (``rel_attn_de_tiles_kernel`` and the grouped
+    weight-gradient launch: ~0.8 of a block's ~3 ms at the bench shape, none of it needed before the optimiser step / the
+    bucket's all-reduce) on a side stream restricted to ``side_cus`` CUs, BESIDE the MFMA-bound kernels of the critical path
+    instead of between them.  ``partition``: also create the main stream, restricted to the other CUs -- run the training step
+    inside ``with torch.cuda.stream(ops.main_stream())``; without it the caller's stream keeps the whole chip and the
+    dispatcher shares the side stream's CUs between the two.  ``reserve_cus``: CUs (the highest-numbered ones) that neither
+    stream may use -- left to RCCL's kernels under data parallelism.  ``side_cus = 0`` with
+    ``reserve_cus > 0``: only the main stream, masked.  Both zero: back to one unrestricted stream.  Returns the plan (or None)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    old = _STREAM_PLANS.pop(idx, None)
+    if old is not None:
+        torch.cuda.synchronize(dev)
+        for ms in (old.side, old.main):
+            if ms is not None:
+                ms.close()
+    if side_cus <= 0 and reserve_cus <= 0:
+        return None
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    if side_cus % 8 or reserve_cus % 8 or side_cus + reserve_cus >= total:
+        raise ValueError(f"configure_streams: side_cus and reserve_cus must be multiples of 8 (whole-XCD-balanced masks) summing to "
+                         f"less than {total}")
+    side = MaskedStream(side_cus, 0, dev) if side_cus > 0 else None
+    main = MaskedStream(total - side_cus - reserve_cus, side_cus, dev) if (partition or side is None) else None
+    plan = _STREAM_PLANS[idx] = StreamPlan(side, main, reserve_cus)
+    _det_register_stream(side)
+    return plan
+
+
+def stream_plan(device=None):
+    idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+    return _STREAM_PLANS.get(idx)
+
+
+def main_stream(device=None):
+    """the stream a training step should run on: the plan's masked main stream, else the current stream"""
+    plan = stream_plan(device)
+    return plan.main.stream if plan is not None and plan.main is not None else torch.cuda.current_stream(device)
+
+
+def join_side_stream(device=None) -> None:
+    """the current stream waits for everything issued on the side stream (called before the optimiser step, and by anything else
+    that reads the gradients the side stream accumulates)"""
+    plan = stream_plan(device)
+    if plan is not None and plan.side is not None and plan.last is not None:
+        torch.cuda.current_stream(device).wait_event(plan.last)
+        plan.last = None
+
+
+# --------------------------------------------------------------------------------------------------
 # raw launchers (no autograd)
 # --------------------------------------------------------------------------------------------------
 def pad_bitmap(tok: torch.Tensor, pad: int, flag: torch.Tensor | None = None) -> torch.Tensor:
     """tok int32 [B,L] -> uint32 bitmap [B, L/32] (stored as int32).  ``flag`` (int32[1] on the device, optional) gets bit 0
-    OR-ed in when a pad token is followed by a real token in its row (sticky; read it at a synchronisation point)."""
+    OR-ed in when a row starts with a pad token and holds a real token later (leading padding: fully masked queries; sticky;
+    read it at a synchronisation point)."""
     _need_cuda(tok, flag)
     B, L = tok.shape
     bits = torch.empty(B, L // 32, dtype=torch.int32, device=tok.device)
@@ -515,6 +628,7 @@ class _EmbedPE(torch.autograd.Function):
         embed_bwd(tok, dout.contiguous(), gtable, p_drop, seed)
         if done is not None:
             done()
+        join_side_stream(tok.device)      # last node of the backward: every gradient is complete in this stream's order
         return None, None, None, None, None, None, None
 
 
@@ -585,14 +699,44 @@ class _EncoderLayer(torch.autograd.Function):
         da, dres1 = add_ln_bwd(do1, a, h, lp.g1, mean1, rstd1, lp.gg1, lp.gb1, p_drop, seed + 1, lp.gbfc)
         del do1
         datt = linear_dx(da, lp.wfc)
-        dqkv = rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE)
-        del datt
+        plan = None if torch.cuda.is_current_stream_capturing() else stream_plan(h.device)
+        if plan is None or plan.side is None:
+            dqkv = rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE)
+            del datt
+            dh = linear_dx(dqkv, lp.wqkv, None, dres1)
+            # the block's four weight gradients (and the two bias gradients that are not LayerNorm by-products) in one launch
+            linear_dw_grouped([(dqkv, h, lp.gqkv, lp.gbqkv), (da, att, lp.gwfc, None), (df1, o1, lp.gwpre, lp.gbpre),
+                               (df2, f1, lp.gwsuf, None)])
+            if done is not None:
+                done()
+            return dh, None, None, None, None, None, None
+        # Two streams (configure_streams): dE and the weight gradients feed only the optimiser (and the bucket's all-reduce), and
+        # both run at the HBM rate -- they go to the CU-masked side stream, behind an event recorded once dK/dV (the dS tiles) and
+        # dQ (dqkv complete) are issued, while this stream carries on with the dX of the QKV projection and the next block's
+        # backward, whose heavy kernels are MFMA-bound.  The bucket callback runs in the side stream's context: the all-reduce
+        # it issues is ordered behind the gradients written there (everything this stream wrote into the bucket -- the
+        # LayerNorm and bias column sums -- precedes the event).
+        main, side = torch.cuda.current_stream(), plan.side.stream
+        B, L, _ = qkv.shape
+        ws = torch.empty(_lib.load().mgx_rel_attn_bwd_workspace(B, L, qkv.shape[2] // 3), dtype=torch.uint8, device=qkv.device)
+        dqkv = rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE, parts=1 | 4 | 2, workspace=ws)
+        ready = torch.cuda.Event()
+        ready.record(main)
         dh = linear_dx(dqkv, lp.wqkv, None, dres1)
-        # the block's four weight gradients (and the two bias gradients that are not LayerNorm by-products) in one launch
-        linear_dw_grouped([(dqkv, h, lp.gqkv, lp.gbqkv), (da, att, lp.gwfc, None), (df1, o1, lp.gwpre, lp.gbpre),
-                           (df2, f1, lp.gwsuf, None)])
-        if done is not None:
-            done()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE, parts=8, dqkv=dqkv, workspace=ws)
+            linear_dw_grouped([(dqkv, h, lp.gqkv, lp.gbqkv), (da, att, lp.gwfc, None), (df1, o1, lp.gwpre, lp.gbpre),
+                               (df2, f1, lp.gwsuf, None)])
+            if done is not None:
+                done()
+            plan.last = torch.cuda.Event()
+            plan.last.record(side)
+        # allocated on this stream, read on the other: the caching allocator must not hand the blocks out again before the side
+        # stream is through with them
+        for t in (qkv, att, datt, lse, ws, dqkv, h, da, df1, o1, df2, f1, padbits):
+            if t is not None:
+                t.record_stream(side)
         return dh, None, None, None, None, None, None
 
 

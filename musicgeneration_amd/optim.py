@@ -30,6 +30,7 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._t += 1
         dp = getattr(self.model, "_dp", None)
+        ops.join_side_stream(self.store.param.device)      # weight gradients / dE issued on the CU-masked side stream (ops.configure_streams)
         if dp is not None:
             dp.wait_all()                 # gradients of every bucket reduced (sum) before the update
         ops.adam_step(self.store.param, self.store.grad, self.m, self.v, self.store.shadow, g["lr"], g["betas"][0],

@@ -129,7 +129,7 @@ def main(argv=None):
         with torch.no_grad():
             ex, ey = dataset.slide_seq2seq_batch(2, options.max_seq, 'valid')
             try:                                           # the same host-side guard as on the training batches: early, and it names the phase
-                utils.check_pads_trail(ex, pad)
+                utils.check_no_leading_pads(ex, pad)
             except ValueError as err:
                 raise ValueError(f'evaluation batch: {err}') from err
             pred, _ = mt.forward(to_dev(ex))
@@ -180,7 +180,7 @@ def main(argv=None):
                     continue
                 # host-side, before the H2D copy, and OUTSIDE the try above: its ValueError (which rows, why) must reach the user
                 # instead of being taken for a failed draw (skipped silently / reported as a rank mismatch under DP)
-                utils.check_pads_trail(batch_x, pad)
+                utils.check_no_leading_pads(batch_x, pad)
                 batch_x, batch_y = to_dev(batch_x), to_dev(batch_y)
                 mt.train()
                 last_micro = (b + 1) % options.accum_grad == 0
@@ -202,9 +202,9 @@ def main(argv=None):
             eval_metrics = evaluate()
             if (e + 1) % options.saving_interval == 0:
                 save_model(e, eval_metrics['accuracy'])
-            # the device-side record of the pads-trail guard (this is a synchronisation point anyway).  AFTER the checkpoint: the
+            # the device-side record of the leading-pads guard (this is a synchronisation point anyway).  AFTER the checkpoint: the
             # flag is sticky and shared by training and evaluation forwards, so raising first would lose the epoch just trained
-            mt.check_pads_trail()
+            mt.check_no_leading_pads()
             dt = time.time() - t_meter
             log('\n====================================================')
             log('Epoch/Batch: {}/{}'.format(e, b))

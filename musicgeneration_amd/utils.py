@@ -52,18 +52,26 @@ def get_masked_with_pad_tensor(size, src, trg, pad_token):
     return all_pad, all_pad, key_is_pad | future[None, None]
 
 
-def check_pads_trail(batch, pad_token) -> None:
-    """Host-side guard at the data boundary (numpy / CPU tensor [B, L], before the H2D copy): padding may only TRAIL a
-    sequence.  A row whose first tokens are padding has queries with every visible key masked; there the reference's
-    softmax is a rounding artefact of ``-1e9 + x`` in fp32 (layers.py:99-102) and the kernels return the uniform average
-    over j <= i instead -- outside the parity contract, so such input is refused rather than trained on."""
+def check_no_leading_pads(batch, pad_token) -> None:
+    """Host-side guard at the data boundary (numpy / CPU tensor [B, L], before the H2D copy): a sequence must not START with
+    padding.  A row whose first tokens are padding has queries with every visible key masked; there the reference's softmax is
+    a rounding artefact of ``-1e9 + x`` in fp32 (layers.py:99-102) and the kernels return the uniform average over j <= i
+    instead -- outside the parity contract, so such input is refused rather than trained on.  Trailing and
+    interior pads are fine: every real query still sees a real key, and the kernels mask the padded keys exactly as the
+    reference's look-ahead mask does (utils.py:58-83).  A row of nothing but padding has no real query and passes."""
     import numpy as np
     a = batch.numpy() if isinstance(batch, torch.Tensor) else np.asarray(batch)
+    if a.ndim != 2 or a.shape[1] == 0:
+        return
     is_pad = (a == pad_token)
-    if is_pad.any() and bool((is_pad[:, :-1] & ~is_pad[:, 1:]).any()):
-        rows = np.nonzero((is_pad[:, :-1] & ~is_pad[:, 1:]).any(axis=1))[0][:4].tolist()
-        raise ValueError(f"padding token {pad_token} is followed by a real token in batch rows {rows}: pads must only trail "
-                         "(leading / interior padding is outside the parity contract with the reference)")
+    bad = is_pad[:, 0] & ~is_pad.all(axis=1)
+    if bool(bad.any()):
+        rows = np.nonzero(bad)[0][:4].tolist()
+        raise ValueError(f"batch rows {rows} start with padding token {pad_token} and hold real tokens later: leading padding is "
+                         "outside the parity contract with the reference (fully masked queries); pads may trail or sit inside")
+
+
+check_pads_trail = check_no_leading_pads      # the name of rounds 4-5, when interior pads were refused as well
 
 
 def event_indeces_to_midi_file(event_indeces, midi_file_name, velocity_scale=0.8):

@@ -174,7 +174,8 @@ def test_full_size_grouped_dW():
 def test_cfg4_shaped_model_step():
     """BASELINE cfg4 as a MODEL (MuMIDI V=486, 12 layers, d=768 = 12 heads, L=4096), batch 1:
     (a) one cfg4-shaped layer + vocabulary projection against the oracle's fp32 forward on the same tokens (trailing pads),
-    (b) the full 12-layer model takes optimiser steps with finite, decreasing loss."""
+    (b) the full 12-layer model LEARNS at batch 4: ten optimiser steps on a learnable task take the loss down by
+        more than 1 nat with finite gradients at every step."""
     from musicgeneration_amd.criterion import CustomSchedule, SmoothCrossEntropyLoss
     from musicgeneration_amd.network import MusicTransformer
     from musicgeneration_amd.optim import FusedAdam
@@ -202,21 +203,33 @@ def test_cfg4_shaped_model_step():
     torch.manual_seed(0)
     mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=12, max_seq=L, dropout=0.0).cuda().train()
     opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9)
-    sch = CustomSchedule(d, warmup_steps=60, optimizer=opt)      # (warm-up 20 overshoots at batch 4: 6.02 at step 4, 6.42 at step 5)
+    # Noam warm-up 60: the rate climbs by 7.8e-5 per step (7.8e-4 at step 10).  Round 5 ran this test on uniformly random targets
+    # with warm-up 20 and saw 6.02 at step 4, 6.42 at step 5: a 12-layer post-LN stack at a rate of 2e-3 five steps after
+    # initialisation overshoots (the same schedule at batch 1 happened to pass) -- the schedule's doing, not the kernels'; and random
+    # targets leave only ln 485 - 6.35 = -0.17 nat to learn, so that test could not tell a working backward from a broken one.
+    sch = CustomSchedule(d, warmup_steps=60, optimizer=opt)
     lossf = SmoothCrossEntropyLoss(0.1, V, pad)
-    # per-GPU batch 4: cfg4's single-GPU share, the shape bench.py's cfg4 block runs
-    xf = torch.randint(0, V - 1, (4, L + 1), device="cuda")
-    xi, yi = xf[:, :-1].to(torch.int32), xf[:, 1:].to(torch.int32)
+    # per-GPU batch 4 = cfg4's single-GPU share (the shape bench.py's cfg4 block runs: its QKV / output-projection GEMMs take the
+    # four-wave ring kernels of the product binary), on the learnable task of test_training_trajectory_follows_the_oracle:
+    # next token = previous + 1 (mod V - 1), a fresh random start per row and step
+    g = torch.Generator().manual_seed(5)
     losses = []
     for _ in range(10):
+        start = torch.randint(0, V - 1, (4, 1), generator=g)
+        seq = ((start + torch.arange(L + 1)[None, :]) % (V - 1)).cuda()
+        xi, yi = seq[:, :-1].to(torch.int32).contiguous(), seq[:, 1:].to(torch.int32).contiguous()
         loss = lossf(mt(xi), yi)
         loss.backward()
+        st = mt.store()
+        assert torch.isfinite(st.grad).all(), "non-finite gradient"
         sch.step()
         opt.zero_grad()
         losses.append(loss.item())
     assert all(torch.isfinite(torch.tensor(losses))), losses
-    # 16 K uniformly random targets: what ten steps can learn is the uniform prediction (ln 485 = 6.18 from 6.35 at initialisation)
-    assert min(losses[2:]) < losses[0] - 0.05, losses
+    # measured on MI355X (tools/cfg4_learn_probe.py): 6.32, 6.02, 5.59, 4.91, 4.10, 3.24, 2.38, 1.66, 1.21, 0.99 -- the floor of the
+    # smoothed loss (eps 0.1, V 486) is 0.95.  Required: a drop of at least 1 nat within the ten steps, and no step going up by more than 0.1
+    assert losses[-1] < losses[0] - 1.0, losses
+    assert all(b <= a + 0.1 for a, b in zip(losses, losses[1:])), losses
 
 
 def _det_bench_shape_run(scale):

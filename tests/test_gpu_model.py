@@ -514,27 +514,81 @@ def test_optimizer_state_roundtrips_with_torch_adam():
         assert (p.detach() - q.detach().cpu()).abs().max().item() <= 3e-6, n
 
 
-def test_library_boundary_records_pads_that_do_not_trail():
-    """MusicTransformer.forward itself (not only train.py's host-side check) notices leading / interior padding: the bitmap
-    kernel raises a sticky device flag, read by check_pads_trail() at the caller's next synchronisation point."""
+def test_library_boundary_records_leading_pads_only():
+    """MusicTransformer.forward itself (not only train.py's host-side check) notices LEADING padding -- the one input class with
+    fully masked queries: the bitmap kernel raises a sticky device flag, read by check_no_leading_pads() at the caller's next
+    synchronisation point.  Trailing and interior pads are ordinary input (the reference accepts them, utils.py:58-83)."""
     from musicgeneration_amd.network import MusicTransformer
     torch.manual_seed(0)
     V, L = 50, 64
     mt = MusicTransformer(embedding_dim=128, vocab_size=V, num_layer=1, max_seq=L, dropout=0.0).cuda().train()
-    x = torch.randint(0, V - 1, (3, L), dtype=torch.int32)
+    x = torch.randint(0, V - 1, (4, L), dtype=torch.int32)
     x[1, L - 7:] = V - 1                         # trailing pads: fine
-    x[2, L - 1] = V - 1                          # a pad in the last column of the last row: no "next token" to look at
+    x[2, L - 1] = V - 1                          # a pad in the last column of a row
+    x[0, 10] = V - 1                             # an interior pad: fine since ABI 18
+    x[3, :] = V - 1                              # a row of nothing but padding: no real query, silent
     mt(x.cuda())
-    mt.check_pads_trail()
-    bad = x.clone()
-    bad[0, 10] = V - 1                           # interior pad
-    mt(bad.cuda())
-    mt(x.cuda())                                 # the record is sticky across later clean batches
-    with pytest.raises(ValueError, match="pads must only trail"):
-        mt.check_pads_trail()
-    mt.check_pads_trail()                        # ... and cleared by the report
+    mt.check_no_leading_pads()
     lead = x.clone()
     lead[1, :4] = V - 1                          # leading pads
     mt(lead.cuda())
+    mt(x.cuda())                                 # the record is sticky across later clean batches
+    with pytest.raises(ValueError, match="leading padding"):
+        mt.check_no_leading_pads()
+    mt.check_no_leading_pads()                   # ... and cleared by the report
+    one = x.clone()
+    one[2, 0] = V - 1                            # a single pad in column 0 of a row whose next token is real
+    mt(one.cuda())
     with pytest.raises(ValueError):
-        mt.check_pads_trail()
+        mt.check_pads_trail()                    # (the old name is an alias)
+
+
+def test_model_with_interior_pads_matches_the_oracle():
+    """interior pads reach the kernels through MusicTransformer.forward and give the reference's result --
+    logits of a 2-layer model on rows with pads inside and at the end against the oracle's fp32 forward with the reference's
+    look-ahead mask (utils.py:58-83: key j masked iff trg[j] == pad or j > i), and the gradients of the smoothed CE (pad targets
+    ignored, criterion.py:52-60) against the oracle's autograd.  Tolerances (bf16 kernels vs fp32): logits <= 3e-2 * max|logit|
+    and 1e-2 relative L2, loss 2e-2 relative, gradients cosine >= 0.99."""
+    from musicgeneration_amd.criterion import SmoothCrossEntropyLoss
+    from musicgeneration_amd.network import MusicTransformer
+    from oracle import ref_cpu as R
+    V, d, nl, L, B = 60, 128, 2, 96, 3
+    pad = V - 1
+    p0 = R.init_params(V, d, nl, L, seed=21)
+    for k in p0:
+        if k.endswith("embedding.weight") or k.endswith("rga.E"):
+            p0[k] = p0[k] * 0.3
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, V - 1, (B, L), generator=g)
+    y = torch.randint(0, V - 1, (B, L), generator=g)
+    x[0, 5] = pad
+    x[0, 40:43] = pad                                       # interior pads (a single one and a run)
+    x[1, 17] = pad
+    x[1, L - 9:] = pad                                      # interior + trailing
+    y[x == pad] = pad
+    params = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    ref_logits = R.model_forward(params, x, pad)[0]
+    ref_loss = R.smooth_ce(ref_logits, y, 0.1, V, pad)
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0)
+    mt.load_state_dict({k: v.clone() for k, v in p0.items()})
+    mt = mt.cuda().train()
+    logits = mt(x.to(torch.int32).cuda())
+    got = logits.float().cpu()
+    assert torch.isfinite(got).all()
+    ref = ref_logits.detach()
+    assert (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-2
+    mt.check_no_leading_pads()                               # interior pads raise nothing
+    loss = SmoothCrossEntropyLoss(0.1, V, pad)(logits, y.to(torch.int32).cuda())
+    assert abs(loss.item() - ref_loss.item()) <= 2e-2 * abs(ref_loss.item())
+    loss.backward()
+    ref_loss.backward()
+    checked = 0
+    for n, p in mt.named_parameters():
+        a, b = p.grad.float().cpu().flatten(), params[n].grad.flatten()
+        if b.norm() < 1e-7 or n.endswith("Wk.bias"):         # Wk.bias: exactly-zero true gradient, rounding noise on both sides (DESIGN 5)
+            continue
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        assert cos >= 0.99, (n, cos)
+        checked += 1
+    assert checked >= 20

@@ -192,3 +192,100 @@ def test_dw_ring4_matches_the_eight_wave_kernel_bitwise(tmp_path):
         elif k.startswith("gb") and not k.startswith("gbref"):
             scale = np.abs(res[0]["gbref" + k[2:]]).max()
             assert np.abs(res[0][k] - res[1][k]).max() < 1e-5 * scale, f"{k}: bias gradient"
+
+
+# (kind, M, N, K, epilogue, expected kernel family): forward C [M,N] = act(A [M,K] . W [N,K]^T + b); dX [M,K] = dY [M,N] . W [N,K]
+# (reduction N) with a ReLU mask / a residual addend.  The shapes are the bench's: cfg2 at batch 32 / 64 (M = 65,536 / 131,072:
+# QKV 1536 x 512, output projection 512 x 512, FFN 256 x 512 and 512 x 256) and cfg4 at batch 8 (M = 32,768: QKV 2304 x 768).
+_PRODUCT_SHAPES = [
+    ("fwd", 65536, 1536, 512, "bias", "RING4"),
+    ("fwd", 131072, 512, 512, "bias", "RING4"),
+    ("fwd", 32768, 2304, 768, "bias", "RING4"),
+    ("fwd", 131072, 256, 512, "bias+relu", "RING8"),       # FFN_pre: 256-column output -> the eight-wave kernel
+    ("fwd", 131072, 512, 256, "bias", "RING8"),            # FFN_suf: reduction 256
+    ("dx", 131072, 1536, 512, "addend", "RING4"),          # dX of QKV + the residual gradient
+    ("dx", 131072, 512, 512, "none", "RING4"),             # dX of the output projection
+    ("dx", 65536, 512, 512, "mask", "RING4"),              # (mask-only four-wave variant: not a call site of the model, still a kernel of the binary)
+    ("dx", 131072, 512, 256, "mask", "RING8"),             # dX of FFN_suf under FFN_pre's ReLU
+    ("dx", 131072, 256, 512, "addend", "RING8"),           # dX of FFN_pre + the residual gradient
+    ("dx", 32768, 2304, 768, "addend", "RING4"),
+]
+
+
+@pytest.mark.parametrize("kind,M,N,K,epi,family", _PRODUCT_SHAPES)
+def test_product_library_ring_kernels_at_bench_shapes(kind, M, N, K, epi, family):
+    """the ring forward / dX kernels of the PRODUCT binary (libmgx.so, no experiment build, no environment
+    knob) at shapes that pass its own gates -- the GEMMs bench.py's step really runs -- against an fp32 product of the same
+    bf16 operands computed on the GPU.  `mgx_linear_kernel_id` (ABI 18) states which kernel family the call took, so the
+    test cannot silently check the 128 x 128 kernels instead.  Tolerance as test_linear_fwd: |err| <= 2^-7 max|ref| + 1e-3
+    (one bf16 rounding of the result), and 5e-3 relative L2."""
+    import torch
+    from musicgeneration_amd import _lib, ops
+    assert "MGX_LIB_PATH" not in os.environ, "this test is about the product library"
+    lib = _lib.load()
+    fam = {"RING8": 2, "RING4": 3}[family]
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(M // 256 + N + K)
+
+    def rnd(*s, scale=1.0):
+        return (torch.randn(*s, generator=g) * scale).to(dev).bfloat16()
+    if kind == "fwd":
+        assert lib.mgx_linear_kernel_id(0, M, N, K, None) == fam
+        a, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+        bias = torch.randn(N, generator=g).to(dev)
+        act = 1 if "relu" in epi else 0
+        out = ops.linear_fwd(a, w, bias, act)
+        ref = a.float() @ w.float().t() + bias
+        if act:
+            ref = ref.relu()
+    else:
+        k_id = {"none": 1, "mask": 2, "addend": 3}[epi]
+        assert lib.mgx_linear_kernel_id(k_id, M, N, K, None) == fam
+        dy, w = rnd(M, N), rnd(N, K, scale=N ** -0.5)
+        y = rnd(M, K) if epi == "mask" else None
+        add = rnd(M, K) if epi == "addend" else None
+        out = ops.linear_dx(dy, w, y, add)
+        ref = dy.float() @ w.float()
+        if y is not None:
+            ref = ref * (y.float() > 0)
+        if add is not None:
+            # the kernel rounds the product to bf16, adds the bf16 addend in fp32 and rounds once more
+            ref = ref + add.float()
+    torch.cuda.synchronize()
+    got = out.float()
+    assert torch.isfinite(got).all()
+    tol = 2 ** -7 * ref.abs().max().item() + 1e-3
+    if epi == "addend":
+        tol *= 2                                            # two roundings
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"max err {err} > {tol}"
+    assert ((got - ref).norm() / ref.norm()).item() < 5e-3
+
+
+def test_linear_kernel_id_follows_the_stream_cu_count():
+    """the persistent ring kernels take a call when its 256 x 256 tiles fill 3/4 of the CUs of the stream it is issued on: a
+    CU-masked stream (mgx_stream_create_cu_mask, ABI 18) with a quarter of the chip sends a quarter-size GEMM down the ring path
+    that the whole device would give to the 128 x 128 kernels -- and the result is the same to the bit (same reduction order)"""
+    import ctypes
+    import torch
+    from musicgeneration_amd import _lib, ops
+    lib = _lib.load()
+    torch.zeros(1, device="cuda")
+    M, N, K = 16384, 512, 512                               # 128 tiles: < 192 on the whole device
+    assert lib.mgx_linear_kernel_id(0, M, N, K, None) == 1
+    side = ops.MaskedStream(64)
+    try:
+        assert lib.mgx_stream_cus(side.ptr) == 64
+        assert lib.mgx_linear_kernel_id(0, M, N, K, side.ptr) == 3
+        g = torch.Generator(device="cpu").manual_seed(3)
+        a = torch.randn(M, K, generator=g).cuda().bfloat16()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().bfloat16()
+        b = torch.randn(N, generator=g).cuda()
+        whole = ops.linear_fwd(a, w, b, 0)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side.stream):
+            masked = ops.linear_fwd(a, w, b, 0)
+        side.stream.synchronize()
+        assert torch.equal(whole.view(torch.int16), masked.view(torch.int16))
+    finally:
+        side.close()

@@ -211,19 +211,22 @@ def test_data_check_vocab_rejects_out_of_range_ids(tmp_path):
         ds.check_vocab(309)
 
 
-def test_check_pads_trail_accepts_tail_padding_and_refuses_leading_or_interior():
-    """The data-boundary guard behind DESIGN.md section 5: rows whose padding is not a suffix are outside the parity contract
-    (the reference's result there is a rounding artefact, fixture g2b_leadpad) and are refused before they reach the GPU."""
+def test_leading_pads_are_refused_and_trailing_or_interior_pads_accepted():
+    """The data-boundary guard behind DESIGN.md section 5: only rows that START with padding (and hold real tokens later) have
+    fully masked queries -- outside the parity contract (the reference's result there is a rounding artefact, fixture
+    g2b_leadpad) -- and are refused before they reach the GPU.  Trailing and interior pads are what the reference's look-ahead
+    mask handles (utils.py:58-83) and pass, as does a row of nothing but padding (no real query)."""
     import numpy as np
     import pytest
     from musicgeneration_amd import utils
     pad = 9
-    ok = np.array([[1, 2, 3, 9, 9], [4, 5, 6, 7, 8], [9, 9, 9, 9, 9]], dtype=np.int16)
-    utils.check_pads_trail(ok, pad)
-    utils.check_pads_trail(torch.from_numpy(ok.astype(np.int64)), pad)
-    for bad in ([[9, 1, 2, 3, 4]], [[1, 9, 2, 9, 9]]):
-        with pytest.raises(ValueError, match="pads must only trail"):
-            utils.check_pads_trail(np.array(bad, dtype=np.int16), pad)
+    ok = np.array([[1, 2, 3, 9, 9], [4, 5, 6, 7, 8], [9, 9, 9, 9, 9], [1, 9, 2, 9, 9], [1, 2, 9, 3, 4]], dtype=np.int16)
+    utils.check_no_leading_pads(ok, pad)
+    utils.check_no_leading_pads(torch.from_numpy(ok.astype(np.int64)), pad)
+    utils.check_pads_trail(ok, pad)                        # the old name is an alias
+    for bad in ([[9, 1, 2, 3, 4]], [[9, 9, 2, 9, 9]], [[1, 2, 3, 4, 5], [9, 9, 9, 9, 1]]):
+        with pytest.raises(ValueError, match="leading padding"):
+            utils.check_no_leading_pads(np.array(bad, dtype=np.int16), pad)
 
 
 def test_pack_frag_layout_matches_the_header():

@@ -31,7 +31,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "musicgeneration_amd", "csrc"))
-from asm_sched import COST, Gen, Item, a, chain, crow, regs, s, salu_items, schedule, v  # noqa: E402
+from asm_sched import COST, Gen, Item, a, chain, crow, regs, s, salu_items, schedule, v, write_if_changed  # noqa: E402
 
 # ---------------------------------------------------------------------------------------------------------------------
 # register map
@@ -632,7 +632,9 @@ def clobbers():
 def write(here):
     lines, g = generate()
     path = os.path.join(here, "rel_attn_fwd64_loop_stamp.inc" if STAMP else "rel_attn_fwd64_loop.inc")
-    with open(path, "w") as f:
+    import io
+    f = io.StringIO()
+    if True:
         f.write("// GENERATED by gen_fwd_asm.py -- do not edit.  The hand-scheduled sweep of rel_attn_fwd64_kernel (one asm statement):\n")
         f.write("// operands %0..%3 = oA0, oA1, oB0, oB1 (\"=&a\"), %4..%7 = m_A, l_A, m_B, l_B (\"=&v\"), %8..%15 = the scaled q fragments of tiles A, B\n")
         f.write("// (\"a\"), %16 = LDS address of the wave's parameter block (\"s\").  Register map, schedule and hazard rules: gen_fwd_asm.py.\n")
@@ -644,6 +646,7 @@ def write(here):
                 f.write(f'    "{ln}\\n\\t" \\\n')
         f.write('    ""\n')
         f.write("#define MGX_FWD64_LOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()) + "\n")
+    write_if_changed(path, f.getvalue())
     n_ins = sum(1 for ln in lines if not ln.startswith(";") and not ln.endswith(":"))
     print(f"wrote {path}: {n_ins} instructions, s_nop wait states inserted: {g.nops}; counts {g.stats}", file=sys.stderr)
 
