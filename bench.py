@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--side-cus", type=int, default=0, help="run the backward's off-critical-path, HBM-bound kernels (dE from the stored dS "
                     "tiles, the blocks' weight gradients) on a side stream restricted to this many CUs (multiple of 8 = whole-XCD-balanced "
                     "mask) beside the critical path, which gets the other CUs (ops.configure_streams; DESIGN.md 2.8).  0 = one stream")
+    ap.add_argument("--side-work", choices=("de", "dw", "both"), default="both", help="with --side-cus: what the side stream runs -- the dE "
+                    "kernel, the weight gradients, or both")
     ap.add_argument("--side-shared", action="store_true", help="with --side-cus: the main stream keeps the whole chip (only the side "
                     "stream is masked) instead of the complement of the side stream's CUs")
     ap.add_argument("--rccl-cus", type=int, default=0, help="N > 1: keep this many CUs (multiple of 8) free of the compute streams for "
@@ -454,7 +456,8 @@ def main():
     mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=args.dropout).to(dev)
     mt.train()
     # stream plan: a CU-masked side stream for the off-critical-path half of the backward and / or CUs kept free for RCCL
-    plan = _ops.configure_streams(args.side_cus, args.rccl_cus, partition=not args.side_shared, device=dev) \
+    plan = _ops.configure_streams(args.side_cus, args.rccl_cus, partition=not args.side_shared, device=dev,
+                                  side_work={"de": 1, "dw": 2, "both": 3}[args.side_work]) \
         if (args.side_cus or args.rccl_cus) else None
     run_stream = _ops.main_stream(dev)
     dp = DataParallel(mt, groups=args.buckets or None)

@@ -2048,7 +2048,7 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int coun
     int nring, nrest;
     const mgx_dw_problem* problems = problems_in;
     int count = count_in;
-    if (dw_split(problems_in, count_in, ring_p, &nring, rest_p, &nrest) && nrest > 0 && dw_ring_plan(ring_p, nring, M, nullptr, mgx_stream_cu_count(stream))) {
+    if (dw_split(problems_in, count_in, ring_p, &nring, rest_p, &nrest) && nrest > 0 && dw_ring_plan(ring_p, nring, M, nullptr, mgx_stream_cu_count(mgx_deterministic() ? nullptr : stream))) {
         if (int rc = mgx_linear_dw_grouped(ring_p, nring, M, workspace, ws_bytes, stream)) return rc;
         problems = rest_p;
         count = nrest;
@@ -2066,7 +2066,10 @@ extern "C" int mgx_linear_dw_grouped(const mgx_dw_problem* problems_in, int coun
     }
     set_attrs();
     DwRing rg;
-    if (dw_ring_plan(problems, count, M, &rg, mgx_stream_cu_count(stream))) {
+    // the M-splits are planned for the CUs of the stream the call is issued on -- except in deterministic mode: the partial tiles
+    // are added in split order, so the number of splits is part of the result's bits, and a run with the weight gradients on a
+    // CU-masked side stream must equal the one-stream run bit for bit (tests/test_gpu_dp.py): there the plan is the whole device's
+    if (dw_ring_plan(problems, count, M, &rg, mgx_stream_cu_count(mgx_deterministic() ? nullptr : stream))) {
         const size_t need = (size_t)rg.first_tile[rg.n] * rg.splits * 65536 * sizeof(float);
         MGX_REQUIRE(workspace && ws_bytes >= need && ((uintptr_t)workspace & 15) == 0, MGX_ERR_SHAPE,
                     "mgx_linear_dw_grouped: workspace must be 16-byte aligned and >= mgx_linear_dw_grouped_workspace() = %zu bytes "

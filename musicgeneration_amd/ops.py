@@ -95,28 +95,46 @@ class MaskedStream:
         self.ptr, self.cus, self.first = out.value, cus, first
         self.stream = torch.cuda.ExternalStream(self.ptr, device=self.device)
 
-    def close(self):
+    def close(self, destroy: bool = False):
+        """forget the stream.  The HIP stream itself is only destroyed on request: the caching allocator keeps the stream of every
+        block that was allocated on it or marked with ``record_stream`` and records an event on it when such a block is freed --
+        long after this call, possibly at interpreter shutdown -- so destroying a stream that tensors have touched is a
+        use-after-free.  A forgotten stream costs one idle hardware queue."""
         if self.ptr is not None:
             self.stream.synchronize()
-            _det_stream_scratch.pop(self.ptr, None)
-            check(_lib.load().mgx_stream_destroy(self.ptr), "mgx_stream_destroy")
+            if destroy:
+                _det_stream_scratch.pop(self.ptr, None)
+                check(_lib.load().mgx_stream_destroy(self.ptr), "mgx_stream_destroy")
             self.ptr = None
+
+
+_MASKED = {}                 # (device index, first, cus) -> MaskedStream: created once, reused by every later plan
+
+
+def masked_stream(cus: int, first: int = 0, device=None) -> "MaskedStream":
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, first, cus)
+    ms = _MASKED.get(key)
+    if ms is None or ms.ptr is None:
+        ms = _MASKED[key] = MaskedStream(cus, first, dev)
+    return ms
 
 
 class StreamPlan:
     """``side``: the masked stream of the backward's off-critical-path kernels (dE from the stored dS tiles, the block's weight
     gradients -- they feed only the optimiser); ``main``: the masked stream of everything else (the complement of ``side``
     minus the CUs left to RCCL), or None when the caller's own stream stays unrestricted."""
-    __slots__ = ("side", "main", "reserved", "last")
+    __slots__ = ("side", "main", "reserved", "last", "work")
 
-    def __init__(self, side, main, reserved):
-        self.side, self.main, self.reserved, self.last = side, main, reserved, None
+    def __init__(self, side, main, reserved, work=3):
+        self.side, self.main, self.reserved, self.last, self.work = side, main, reserved, None, work
 
 
 _STREAM_PLANS = {}           # device index -> StreamPlan
 
 
-def configure_streams(side_cus: int = 0, reserve_cus: int = 0, partition: bool = True, device=None):
+def configure_streams(side_cus: int = 0, reserve_cus: int = 0, partition: bool = True, device=None, side_work: int = 3):
     """Run the HBM-bound, off-critical-path half of an encoder block's backward (``rel_attn_de_tiles_kernel`` and the grouped
     weight-gradient launch: ~0.8 of a block's ~3 ms at the bench shape, none of it needed before the optimiser step / the
     bucket's all-reduce) on a side stream restricted to ``side_cus`` CUs, BESIDE the MFMA-bound kernels of the critical path
@@ -124,24 +142,23 @@ def configure_streams(side_cus: int = 0, reserve_cus: int = 0, partition: bool =
     inside ``with torch.cuda.stream(ops.main_stream())``; without it the caller's stream keeps the whole chip and the
     dispatcher shares the side stream's CUs between the two.  ``reserve_cus``: CUs (the highest-numbered ones) that neither
     stream may use -- left to RCCL's kernels under data parallelism.  ``side_cus = 0`` with
-    ``reserve_cus > 0``: only the main stream, masked.  Both zero: back to one unrestricted stream.  Returns the plan (or None)."""
+    ``reserve_cus > 0``: only the main stream, masked.  Both zero: back to one unrestricted stream.  ``side_work``: what goes to
+    the side stream -- bit 0 the dE kernel, bit 1 the weight gradients.  Returns the plan (or None)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    old = _STREAM_PLANS.pop(idx, None)
-    if old is not None:
-        torch.cuda.synchronize(dev)
-        for ms in (old.side, old.main):
-            if ms is not None:
-                ms.close()
+    if _STREAM_PLANS.pop(idx, None) is not None:
+        torch.cuda.synchronize(dev)                        # (the plan's streams stay alive in _MASKED: see MaskedStream.close)
     if side_cus <= 0 and reserve_cus <= 0:
         return None
     total = torch.cuda.get_device_properties(dev).multi_processor_count
     if side_cus % 8 or reserve_cus % 8 or side_cus + reserve_cus >= total:
         raise ValueError(f"configure_streams: side_cus and reserve_cus must be multiples of 8 (whole-XCD-balanced masks) summing to "
                          f"less than {total}")
-    side = MaskedStream(side_cus, 0, dev) if side_cus > 0 else None
-    main = MaskedStream(total - side_cus - reserve_cus, side_cus, dev) if (partition or side is None) else None
-    plan = _STREAM_PLANS[idx] = StreamPlan(side, main, reserve_cus)
+    side = masked_stream(side_cus, 0, dev) if side_cus > 0 else None
+    main = masked_stream(total - side_cus - reserve_cus, side_cus, dev) if (partition or side is None) else None
+    if side is not None and side_work not in (1, 2, 3):
+        raise ValueError("configure_streams: side_work is 1 (dE), 2 (weight gradients) or 3 (both)")
+    plan = _STREAM_PLANS[idx] = StreamPlan(side, main, reserve_cus, side_work)
     _det_register_stream(side)
     return plan
 
@@ -719,16 +736,25 @@ class _EncoderLayer(torch.autograd.Function):
         main, side = torch.cuda.current_stream(), plan.side.stream
         B, L, _ = qkv.shape
         ws = torch.empty(_lib.load().mgx_rel_attn_bwd_workspace(B, L, qkv.shape[2] // 3), dtype=torch.uint8, device=qkv.device)
-        dqkv = rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE, parts=1 | 4 | 2, workspace=ws)
+        de_side, dw_side = bool(plan.work & 1), bool(plan.work & 2)
+        dqkv = rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE, parts=(1 | 4 | 2) if de_side else 15, workspace=ws)
         ready = torch.cuda.Event()
         ready.record(main)
         dh = linear_dx(dqkv, lp.wqkv, None, dres1)
+        group = [(dqkv, h, lp.gqkv, lp.gbqkv), (da, att, lp.gwfc, None), (df1, o1, lp.gwpre, lp.gbpre), (df2, f1, lp.gwsuf, None)]
+        if not dw_side:
+            linear_dw_grouped(group)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE, parts=8, dqkv=dqkv, workspace=ws)
-            linear_dw_grouped([(dqkv, h, lp.gqkv, lp.gbqkv), (da, att, lp.gwfc, None), (df1, o1, lp.gwpre, lp.gbpre),
-                               (df2, f1, lp.gwsuf, None)])
+            if de_side:
+                rel_attn_bwd(qkv, lp.E, padbits, att, datt, lse, lp.gE, parts=8, dqkv=dqkv, workspace=ws)
+            if dw_side:
+                linear_dw_grouped(group)
             if done is not None:
+                if not dw_side:                            # the weight gradients were issued on the other stream, after `ready`
+                    again = torch.cuda.Event()
+                    again.record(main)
+                    side.wait_event(again)
                 done()
             plan.last = torch.cuda.Event()
             plan.last.record(side)

@@ -16,6 +16,11 @@ def main(out_path):
     rank = int(os.environ.get("RANK", "0"))
     torch.cuda.set_device(0)
     rccl1 = os.environ.get("MGX_TEST_RCCL1") == "1"    # one rank, backend "nccl" (= RCCL), every collective forced
+    # the co-residency mitigations of DESIGN.md section 4 (bench.py --rccl-cus / --side-cus / --buckets / --nccl-channels)
+    rccl_cus, side_cus = int(os.environ.get("MGX_TEST_RCCL_CUS", "0")), int(os.environ.get("MGX_TEST_SIDE_CUS", "0"))
+    groups = int(os.environ.get("MGX_TEST_BUCKETS", "0")) or None
+    if os.environ.get("MGX_TEST_NCCL_CHANNELS"):
+        os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = os.environ["MGX_TEST_NCCL_CHANNELS"]
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     elif rccl1:
@@ -31,35 +36,41 @@ def main(out_path):
     if world == 1:
         torch.manual_seed(100)
         mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=L, dropout=0.0).cuda().train()
-    dp = DataParallel(mt, force_collectives=rccl1)
+    from musicgeneration_amd import ops
+    plan = ops.configure_streams(side_cus, rccl_cus) if (side_cus or rccl_cus) else None
+    dp = DataParallel(mt, force_collectives=rccl1, groups=groups)
     opt = FusedAdam(mt, lr=0.0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale)
     sch = CustomSchedule(d, warmup_steps=20, optimizer=opt)
     lossf = SmoothCrossEntropyLoss(0.1, V, V - 1)
     g = torch.Generator().manual_seed(9)
     losses = []
-    for it in range(6):
-        xf = torch.randint(0, V - 1, (B, L + 1), generator=g)          # the GLOBAL batch, pad-free
-        if world > 1:
-            xf = xf[rank * (B // world):(rank + 1) * (B // world)]
-        x, y = xf[:, :-1].to(torch.int32).cuda(), xf[:, 1:].to(torch.int32).cuda()
-        loss = lossf(mt(x), y)
-        if rccl1:                                                       # the loss-weight all-reduce too (== 1 here)
-            loss = loss * dp.loss_weight((y != V - 1).sum())
-        loss.backward()
-        if it == 0:                                                     # the (all-reduced) gradient of the first step, before Adam
-            dp.wait_all()
-            torch.cuda.synchronize()
-            gr = mt.store().grad.double() * dp.grad_scale
-            first = {"grad_sum": float(gr.sum()), "grad_abs": float(gr.abs().sum()), "grad_l2": float(gr.norm())}
-        sch.step()                                                      # waits for the bucket all-reduces, then Adam
-        opt.zero_grad()
-        losses.append(float(dp.all_reduce_scalar_mean(loss.detach())))
+    with torch.cuda.stream(ops.main_stream()):     # the plan's masked main stream, or the current stream
+        for it in range(6):
+            xf = torch.randint(0, V - 1, (B, L + 1), generator=g)          # the GLOBAL batch, pad-free
+            if world > 1:
+                xf = xf[rank * (B // world):(rank + 1) * (B // world)]
+            x, y = xf[:, :-1].to(torch.int32).cuda(), xf[:, 1:].to(torch.int32).cuda()
+            loss = lossf(mt(x), y)
+            if rccl1:                                                       # the loss-weight all-reduce too (== 1 here)
+                loss = loss * dp.loss_weight((y != V - 1).sum())
+            loss.backward()
+            if it == 0:                                                     # the (all-reduced) gradient of the first step, before Adam
+                dp.wait_all()
+                torch.cuda.synchronize()
+                gr = mt.store().grad.double() * dp.grad_scale
+                first = {"grad_sum": float(gr.sum()), "grad_abs": float(gr.abs().sum()), "grad_l2": float(gr.norm())}
+            sch.step()                                                      # waits for the bucket all-reduces, then Adam
+            opt.zero_grad()
+            losses.append(float(dp.all_reduce_scalar_mean(loss.detach())))
     st = mt.store()
     import hashlib
-    from musicgeneration_amd import ops
     res = {"losses": losses, "param_sum": float(st.param.double().sum()), "param_abs": float(st.param.double().abs().sum()),
            "param_hash": hashlib.sha256(st.param.detach().cpu().numpy().tobytes()).hexdigest(), "deterministic": ops.deterministic(),
-           "buckets": len(st.buckets), "bytes_reduced": dp.bytes_reduced, "describe": dp.describe(), **first}
+           "buckets": len(st.buckets), "bytes_reduced": dp.bytes_reduced, "describe": dp.describe(), **first,
+           "allreduce_units": dp.bucket_names(),
+           "streams": None if plan is None else {"side": plan.side.cus if plan.side else 0, "main": plan.main.cus if plan.main else None,
+                                                 "reserved": plan.reserved},
+           "nccl_channels": os.environ.get("NCCL_MAX_NCHANNELS")}
     if rank == 0:
         json.dump(res, open(out_path, "w"))
     if world > 1 or rccl1:

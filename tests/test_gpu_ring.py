@@ -273,8 +273,8 @@ def test_linear_kernel_id_follows_the_stream_cu_count():
     torch.zeros(1, device="cuda")
     M, N, K = 16384, 512, 512                               # 128 tiles: < 192 on the whole device
     assert lib.mgx_linear_kernel_id(0, M, N, K, None) == 1
-    side = ops.MaskedStream(64)
-    try:
+    side = ops.masked_stream(64)
+    if True:
         assert lib.mgx_stream_cus(side.ptr) == 64
         assert lib.mgx_linear_kernel_id(0, M, N, K, side.ptr) == 3
         g = torch.Generator(device="cpu").manual_seed(3)
@@ -287,5 +287,3 @@ def test_linear_kernel_id_follows_the_stream_cu_count():
             masked = ops.linear_fwd(a, w, b, 0)
         side.stream.synchronize()
         assert torch.equal(whole.view(torch.int16), masked.view(torch.int16))
-    finally:
-        side.close()
