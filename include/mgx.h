@@ -49,11 +49,13 @@ int mgx_device_count(void);
  * the same bits.  Partial sums are quantised to 2^-30 ~ 9.3e-10 (a FIXED quantum: an element whose partials are of magnitude m
  * keeps log2(m) + 30 bits -- tests/test_gpu_fullsize.py::test_deterministic_mode_at_the_bench_shape states the bound) and must
  * stay below 2^31 ~ 2.1e9 in magnitude: a partial that is NaN, infinite or larger POISONS its destination -- the fold writes NaN
- * there, as it does for a total outside +-2^31 -- so a diverging run stays recognisable from its loss and gradients (round 5;
- * until then such a partial was converted to 0 / garbage).  The cfg2 training step takes 1.1 % longer.  Everything else in the
- * library is deterministic as it is.
- *   scratch: device memory, 8-byte aligned, owned by the caller and alive until the mode is switched off with
- *            mgx_set_deterministic(NULL, 0); the largest user needs 8 * max(N*K + N, V*d, 64*L) bytes (16 MiB covers cfg4).
+ * there, as it does for a total outside +-2^31 -- so a diverging run stays recognisable from its loss and gradients.  The poison
+ * is sticky (ABI 18): it lives in a word of its own, only ever OR-ed, never in the sum that later partials keep adding to.  The
+ * cfg2 training step takes 1.1 % longer.  Everything else in the library is deterministic as it is.
+ *   scratch: device memory, EXACTLY 32 MiB used, aligned to 32 MiB (ABI 18: sums in the lower 16 MiB -- 2 M destinations, the
+ *            largest user needs max(N*K + N, V*d, 64*L) of them, cfg4: 1.8 M -- and each sum's poison word at the same offset in
+ *            the upper 16 MiB, so that no kernel needs a second pointer), owned by the caller and alive until the mode is
+ *            switched off with mgx_set_deterministic(NULL, 0).
  *   PROCESS-GLOBAL STATE -- the one exception to "every entry point is stateless and takes its stream" (SURVEY 8b): (a) the
  *   setting applies to all threads and all model instances of the process, (b) switching it while such a call is in flight is
  *   undefined, (c) the scratch registered here serves the calls of ONE stream at a time (two streams sharing it would zero / fold

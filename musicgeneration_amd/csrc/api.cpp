@@ -43,9 +43,9 @@ static std::mutex g_reg_mu;
 static std::vector<DetStream> g_det_streams;
 
 extern "C" int mgx_set_deterministic(void* scratch, size_t bytes) {
-    MGX_REQUIRE(((uintptr_t)scratch & 7) == 0, MGX_ERR_SHAPE, "mgx_set_deterministic: scratch must be 8-byte aligned");
-    MGX_REQUIRE(scratch == nullptr || bytes >= 8, MGX_ERR_SHAPE, "mgx_set_deterministic: scratch too small");
-    g_det_elems.store(scratch ? bytes / 8 : 0);
+    MGX_REQUIRE(((uintptr_t)scratch & (MGX_DET_BYTES - 1)) == 0, MGX_ERR_SHAPE, "mgx_set_deterministic: scratch must be aligned to its size, 32 MiB (sums in the lower half, poison words in the upper: mgx.h)");
+    MGX_REQUIRE(scratch == nullptr || bytes >= MGX_DET_BYTES, MGX_ERR_SHAPE, "mgx_set_deterministic: scratch too small (need 32 MiB)");
+    g_det_elems.store(scratch ? MGX_DET_HALF / 8 : 0);
     g_det_ptr.store((long long*)scratch);
     if (!scratch) {                                        // switching the mode off forgets the per-stream buffers too
         std::lock_guard<std::mutex> lk(g_reg_mu);
@@ -56,14 +56,14 @@ extern "C" int mgx_set_deterministic(void* scratch, size_t bytes) {
 extern "C" int mgx_deterministic(void) { return g_det_ptr.load() != nullptr; }
 
 extern "C" int mgx_set_deterministic_stream(void* stream, void* scratch, size_t bytes) {
-    MGX_REQUIRE(((uintptr_t)scratch & 7) == 0, MGX_ERR_SHAPE, "mgx_set_deterministic_stream: scratch must be 8-byte aligned");
-    MGX_REQUIRE(scratch == nullptr || bytes >= 8, MGX_ERR_SHAPE, "mgx_set_deterministic_stream: scratch too small");
+    MGX_REQUIRE(((uintptr_t)scratch & (MGX_DET_BYTES - 1)) == 0, MGX_ERR_SHAPE, "mgx_set_deterministic_stream: scratch must be aligned to its size, 32 MiB");
+    MGX_REQUIRE(scratch == nullptr || bytes >= MGX_DET_BYTES, MGX_ERR_SHAPE, "mgx_set_deterministic_stream: scratch too small (need 32 MiB)");
     MGX_REQUIRE(scratch == nullptr || g_det_ptr.load() != nullptr, MGX_ERR_SHAPE,
                 "mgx_set_deterministic_stream: switch the mode on first (mgx_set_deterministic)");
     std::lock_guard<std::mutex> lk(g_reg_mu);
     for (size_t i = 0; i < g_det_streams.size(); ++i)
         if (g_det_streams[i].stream == stream) { g_det_streams.erase(g_det_streams.begin() + i); break; }
-    if (scratch) g_det_streams.push_back({stream, (long long*)scratch, bytes / 8});
+    if (scratch) g_det_streams.push_back({stream, (long long*)scratch, MGX_DET_HALF / 8});
     return MGX_OK;
 }
 
@@ -85,7 +85,8 @@ long long* mgx_det_scratch(size_t elems, void* stream, int* rc) {
         *rc = MGX_ERR_SHAPE;
         return nullptr;
     }
-    if (hipMemsetAsync(p, 0, elems * 8, (hipStream_t)stream) != hipSuccess) {
+    if (hipMemsetAsync(p, 0, elems * 8, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync((char*)p + MGX_DET_HALF, 0, elems * 8, (hipStream_t)stream) != hipSuccess) {      // sums, poison words
         mgx_set_error("deterministic mode: hipMemsetAsync of the scratch failed");
         *rc = MGX_ERR_LAUNCH;
         return nullptr;

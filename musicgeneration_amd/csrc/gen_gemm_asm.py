@@ -392,7 +392,13 @@ def ring_tile(btrans: bool):
     g = Gen()
     T = RV_TMP
     g.comment("==== entry: the ring's state from the parameter block ====")
-    g.drain()
+    # Only LDS / scalar traffic is waited for here (the parameter block the HIP code has just written).  The VMEM queue is NOT
+    # drained (round 6; ADVICE r5 -- until then an `s_waitcnt vmcnt(0)` stood here, which made every tile after a workgroup's first
+    # wait for its own epilogue's stores and for the next tile's two stages that were left in flight on purpose, and turned the counted
+    # waits below into no-ops): what stands in the in-order queue at this point is modelled below, and the first stages wait with
+    # counts sized for it.
+    g.raw("s_waitcnt lgkmcnt(0)")
+    g.lgkm = []
     g.valu(f"v_mbcnt_lo_u32_b32 {v(RV_L)}, -1, 0", set(), regs("v", RV_L))
     g.valu(f"v_mbcnt_hi_u32_b32 {v(RV_L)}, -1, {v(RV_L)}", regs("v", RV_L), regs("v", RV_L))
     g.valu(f"v_mov_b32_e32 {v(RV_PB)}, %16", set(), regs("v", RV_PB))

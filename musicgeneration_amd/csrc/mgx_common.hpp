@@ -119,26 +119,30 @@ long long* mgx_det_scratch(size_t elems, void* stream, int* rc);
 int mgx_stream_cu_count(void* stream);
 constexpr float MGX_DET_SCALE = 1073741824.f;              // 2^30: resolution 9.3e-10
 // A partial sum that is NaN, infinite or >= 2^31 in magnitude has no fixed-point image (the conversion would give 0, garbage or a
-// wrapped value, and a diverging run would fold back to finite numbers).  Such a partial POISONS its destination instead: a signed
-// atomic max with 2^62 lifts the word out of the valid band |total| < 2^61 (= +-2.1e9) for good -- later finite adds move it by less
-// than 2^61 -- and the fold pass writes NaN for every word outside the band (a finite total that leaves the band is reported the
-// same way).  Order-independent like the sum itself: a poisoned word folds to NaN whatever else arrived, in whatever order.
-constexpr long long MGX_DET_POISON = 1LL << 62;
+// wrapped value, and a diverging run would fold back to finite numbers).  Such a partial POISONS its destination instead, and the
+// poison is STICKY (round 6): the registered scratch is 32 MiB, aligned to 32 MiB -- sums in the lower 16 MiB, one
+// poison word per sum at the same offset in the upper 16 MiB (address = sum's address | 16 MiB: no kernel needs a second
+// pointer) -- and a poisoned word is only ever OR-ed.  Until round 6 the poison was a signed max with 2^62 on the sum word itself,
+// which later large negative partials could carry back into the valid band.  The fold pass writes NaN for every poisoned word and
+// for every total outside +-2^61 (= +-2.1e9).  Order-independent like the sum itself.
+constexpr uintptr_t MGX_DET_HALF = (uintptr_t)16 << 20;     // bytes: sums below, poison words above
+constexpr uintptr_t MGX_DET_BYTES = 2 * MGX_DET_HALF;        // size and alignment of a deterministic-mode scratch
 constexpr long long MGX_DET_BAND = 1LL << 61;
 constexpr float MGX_DET_LIMIT = 2147483648.f;              // 2^31
 MGX_DEV bool det_representable(float v) { return fabsf(v) < MGX_DET_LIMIT; }     // false for NaN
-MGX_DEV void det_poison(long long* dst) { atomicMax(dst, MGX_DET_POISON); }
+MGX_DEV void det_poison(long long* dst) { atomicOr((unsigned int*)((uintptr_t)dst | MGX_DET_HALF), 1u); }
 MGX_DEV void det_add(long long* dst, float v) {
     if (!det_representable(v)) { det_poison(dst); return; }
     atomicAdd((unsigned long long*)dst, (unsigned long long)__float2ll_rn(v * MGX_DET_SCALE));   // two's complement: wraps like a signed add
 }
-// dst[i] (+)= scale * src[i] / 2^30   (NaN where the word was poisoned or left the valid band)
+// dst[i] (+)= scale * src[i] / 2^30   (NaN where the word was poisoned or the total left the valid band)
 static __global__ __launch_bounds__(256) void det_fold_kernel(const long long* __restrict__ src, float* __restrict__ dst, size_t n,
                                                               float scale, int accumulate) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const long long x = src[i];
-        const bool ok = x < MGX_DET_BAND && x > -MGX_DET_BAND;
+        const unsigned int poisoned = *(const unsigned int*)((uintptr_t)(src + i) | MGX_DET_HALF);
+        const bool ok = !poisoned && x < MGX_DET_BAND && x > -MGX_DET_BAND;
         const float v = ok ? (float)((double)x * (1.0 / 1073741824.0)) * scale : __builtin_nanf("");
         dst[i] = accumulate ? dst[i] + v : v;
     }

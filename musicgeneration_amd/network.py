@@ -98,9 +98,16 @@ class MusicTransformer(torch.nn.Module):
         if training:
             st.attach_grads()
         B, L = x.shape
-        if L % 32 != 0 or L > self.max_seq:
-            raise ValueError(f"sequence length {L} must be a multiple of 32 and <= max_seq={self.max_seq}")
+        if L < 1 or L > self.max_seq:
+            raise ValueError(f"sequence length {L} must be in 1 .. max_seq={self.max_seq}")
         tok = x.to(torch.int32).contiguous()
+        # The kernels sweep 32-key tiles.  Any other length (the reference takes every L <= max_seq, layers.py:64-109) is
+        # right-padded with pad tokens up to the next multiple of 32: trailing pads are masked keys and lie in the causal future
+        # of every real position, so the real rows' logits are the reference's; the padded rows are sliced off below and carry
+        # no gradient.
+        Lp = (L + 31) // 32 * 32
+        if Lp != L:
+            tok = torch.cat([tok, torch.full((B, Lp - L), self.pad_token, dtype=torch.int32, device=tok.device)], 1)
         d = self.embedding_dim
         p = self.dropout_rate if self.training else 0.0
         seed = self._next_seed()
@@ -112,18 +119,59 @@ class MusicTransformer(torch.nn.Module):
             self._pad_flag = torch.zeros(1, dtype=torch.int32, device=tok.device)
         padbits = ops.pad_bitmap(tok, self.pad_token, self._pad_flag)
         pe = self.Decoder.pos_encoding.table()
+        layer_params = self._layer_params()
+        if Lp > self.max_seq:
+            # max_seq itself is not a multiple of 32 and L reaches into its last partial tile: the padded rows would index the
+            # positional table and the relative embedding beyond max_seq.  Both get zero rows there (E at the FRONT: distance
+            # delta reads E[M - 1 - delta], and only padded queries have delta >= max_seq); the padded rows' dE is exactly zero
+            # (their dO is), the real rows' is folded back into the layer's gradient slot when the block's backward has run.
+            extra = Lp - self.max_seq
+            pe = torch.cat([pe, torch.zeros(extra, d, dtype=pe.dtype, device=pe.device)], 0)
+            layer_params, done = self._params_for_padded_E(layer_params, extra, done, training)
         P = st.params
         h = ops.embed_pe(tok, P["Decoder.embedding.weight"], pe, p, seed, st.g("Decoder.embedding.weight"),
                          done("embedding"))
-        for i, lp in enumerate(self._layer_params()):
+        for i, lp in enumerate(layer_params):
             # the layer's gradient bucket is complete when the block's backward (ending in the QKV projection) has run
             h = ops.encoder_layer(h, lp, padbits, p, seed + 4 * i, done(f"layer{i}"), wsink)
         Vp = self.vocab_padded
         logits = ops.linear(h, P["fc.weight"], st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param"),
                             0, st.padded_view("fc.weight", Vp, d, "grad"), st.padded_view("fc.bias", Vp, None, "grad"),
                             done("fc"))
-        # [B, L, Vp] storage, [B, L, V] view: columns >= V are exact zeros (zero weight rows, zero bias)
-        return logits[..., : self.vocab_size]
+        if wsink is not None and Lp != L:
+            wsink[:] = [w_[:, :, :L, :L] for w_ in wsink]
+        # [B, Lp, Vp] storage, [B, L, V] view: columns >= V are exact zeros (zero weight rows, zero bias)
+        return logits[:, :L, : self.vocab_size]
+
+    def _params_for_padded_E(self, layer_params, extra, done, training):
+        """per-layer operand sets whose relative embedding has `extra` zero rows in front (see _logits), and a bucket callback
+        that first folds the temporary dE back into the layer's gradient slot"""
+        out, folds = [], {}
+        for i, lp in enumerate(layer_params):
+            q = ops.LayerParams()
+            for k in ops.LayerParams.__slots__:
+                setattr(q, k, getattr(lp, k))
+            q.E = torch.cat([torch.zeros(extra, 64, dtype=lp.E.dtype, device=lp.E.device), lp.E], 0).contiguous()
+            if training:
+                q.gE = torch.zeros(q.E.shape, dtype=torch.float32, device=lp.E.device)
+
+                def fold(tmp=q.gE, slot=lp.gE):
+                    tmp.record_stream(torch.cuda.current_stream())      # (the bucket callback may run on the side stream of ops.configure_streams)
+                    slot.add_(tmp[extra:])
+                folds[f"layer{i}"] = fold
+            out.append(q)
+
+        def done2(name):
+            inner, fold = done(name), folds.get(name)
+            if fold is None:
+                return inner
+
+            def both():
+                fold()
+                if inner is not None:
+                    inner()
+            return both
+        return out, done2
 
     def _layer_params(self):
         """per-layer kernel operands as views of the flat buffers (rebuilt when the store is)"""

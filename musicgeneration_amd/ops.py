@@ -32,10 +32,16 @@ def _need_cuda(*ts):
 # --------------------------------------------------------------------------------------------------
 _det_scratch = None          # the registered buffer must outlive the mode: kept here
 _det_stream_scratch = {}     # stream pointer -> buffer of that stream (mgx_set_deterministic_stream)
-_DET_BYTES = 32 << 20
+_DET_BYTES = 32 << 20        # include/mgx.h: 16 MiB of sums + 16 MiB of poison words, aligned to 32 MiB
 
 
-def set_deterministic(on: bool = True, device=None, nbytes: int = _DET_BYTES) -> None:
+def _det_buffer(dev):
+    """-> (base tensor to keep alive, 32 MiB-aligned data pointer inside it)"""
+    base = torch.empty(2 * _DET_BYTES, dtype=torch.uint8, device=dev)
+    return base, base.data_ptr() + (-base.data_ptr()) % _DET_BYTES
+
+
+def set_deterministic(on: bool = True, device=None) -> None:
     """Switch the library's cross-workgroup sums (dE, vocabulary dW / db, block bias gradients, embedding gradient, loss
     statistics) to order-independent fixed-point integer atomics: repeated runs -- and a data-parallel run against the
     single-process run of the same global batch -- then agree bit for bit on everything the kernels compute.  Costs a few
@@ -50,19 +56,19 @@ def set_deterministic(on: bool = True, device=None, nbytes: int = _DET_BYTES) ->
         _det_stream_scratch.clear()
         return
     dev = device if device is not None else torch.device("cuda")
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(lib.mgx_set_deterministic(ptr(buf), buf.numel()), "mgx_set_deterministic")
+    buf, p = _det_buffer(dev)
+    check(lib.mgx_set_deterministic(p, _DET_BYTES), "mgx_set_deterministic")
     _det_scratch = buf
     for plan in _STREAM_PLANS.values():
-        _det_register_stream(plan.side, nbytes)
+        _det_register_stream(plan.side)
 
 
-def _det_register_stream(ms, nbytes: int = _DET_BYTES) -> None:
+def _det_register_stream(ms) -> None:
     """deterministic mode on: the masked stream ``ms`` issues calls that use the fixed-point scratch -> give it one of its own"""
     if ms is None or not deterministic() or ms.ptr in _det_stream_scratch:
         return
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=ms.device)
-    check(_lib.load().mgx_set_deterministic_stream(ms.ptr, ptr(buf), buf.numel()), "mgx_set_deterministic_stream")
+    buf, p = _det_buffer(ms.device)
+    check(_lib.load().mgx_set_deterministic_stream(ms.ptr, p, _DET_BYTES), "mgx_set_deterministic_stream")
     _det_stream_scratch[ms.ptr] = buf
 
 

@@ -72,7 +72,12 @@ def test_shape_errors_have_messages():
     # deterministic mode: argument validation (no GPU needed)
     assert lib.mgx_deterministic() == 0
     assert lib.mgx_set_deterministic(ctypes.c_void_p(12), 1 << 20) == -1 and b"aligned" in lib.mgx_last_error()
+    assert lib.mgx_set_deterministic(ctypes.c_void_p(64 << 20), 1 << 20) == -1 and b"32 MiB" in lib.mgx_last_error()   # aligned, too small
+    assert lib.mgx_set_deterministic_stream(ctypes.c_void_p(1), ctypes.c_void_p(64 << 20), 32 << 20) == -1 and b"first" in lib.mgx_last_error()
     assert lib.mgx_set_deterministic(None, 0) == 0 and lib.mgx_deterministic() == 0
+    # stream registry (no stream is created or touched: the library only remembers the number)
+    assert lib.mgx_stream_set_cus(ctypes.c_void_p(0x1000), 64) == 0 and lib.mgx_stream_cus(ctypes.c_void_p(0x1000)) == 64
+    assert lib.mgx_stream_set_cus(ctypes.c_void_p(0x1000), 0) == 0
     assert lib.mgx_add_ln_bwd_workspace(100, 512) == 512 * 3 * 512 * 4       # 512 blocks of column partials
     rc = lib.mgx_add_ln_bwd(one, one, one, one, one, one, one, one, one, one, None, one, 16, 8, 512, 0.0, 0, None)
     assert rc == -1 and b"workspace" in lib.mgx_last_error()

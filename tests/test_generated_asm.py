@@ -41,3 +41,36 @@ def test_every_mfma_gap_of_the_gemm_loops_is_short():
             else:
                 gap += 1
         assert 0 < worst <= limit, f"{name}: {worst} instructions between two MFMAs of a loop"
+
+
+def test_ring4_tile_statement_waits_are_sized_for_the_epilogue_hipcc_emits(tmp_path):
+    """the tile statement of linear_ring4_kernel is entered with VMEM traffic in flight -- the next tile's first two
+    stages, requested by the previous statement, and, younger, the epilogue's global stores -- and its first counted waits
+    (`s_waitcnt vmcnt(16 + MGX_RING4_EPI_STORES)` for stage 0) are only right if the epilogue hipcc compiled issues AT LEAST
+    MGX_RING4_EPI_STORES VMEM operations per wave (more is the safe direction: the wait then covers some of them too).
+    Compile linear.hip to gfx950 assembly and count: every instantiation must hold >= EPI_STORES global stores outside the
+    statement, and the statement itself must no longer open with a full drain (which made those counted waits dead code)."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    inc = open(os.path.join(CSRC, "linear_ring4_loop.inc")).read()
+    epi = int(re.search(r"#define MGX_RING4_EPI_STORES (\d+)", inc).group(1))
+    for name in ("MGX_RING4_NT_ASM", "MGX_RING4_NN_ASM"):
+        first = re.search(name + r" \\\n(?:\s*/\*.*?\*/ \\\n)*\s*\"([^\"\\]+)", inc).group(1)
+        assert first.strip() == "s_waitcnt lgkmcnt(0)", f"{name} opens with `{first}`: a VMEM drain at entry defeats the counted waits"
+        assert f"s_waitcnt vmcnt({16 + epi})" in inc
+    out = tmp_path / "linear.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S",
+                        "--cuda-device-only", "-w", os.path.join(CSRC, "linear.hip"), "-o", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = out.read_text()
+    found = 0
+    for m in re.finditer(r"^(_Z19linear_ring4_kernelILb[01]ELi\dEE\w+):.*?^\.Lfunc_end\d+:", asm, re.S | re.M):
+        body = m.group(0)
+        stores = len(re.findall(r"\bglobal_store_dwordx4\b", body))          # (the statement stores nothing: all of them are the epilogue's)
+        assert stores >= epi, f"{m.group(1)}: {stores} epilogue stores < MGX_RING4_EPI_STORES = {epi}"
+        found += 1
+    assert found == 4, "linear_ring4_kernel<false,0>, <true,0>, <true,1>, <true,2>"

@@ -590,6 +590,36 @@ def test_deterministic_mode_keeps_a_nan_a_nan():
     assert torch.isnan(stats[0])                                            # the loss sum
 
 
+def test_deterministic_mode_poison_is_sticky():
+    """a poisoned destination must stay poisoned whatever arrives later.  Until round 6 the poison was a signed max with
+    2^62 on the sum word itself, and two later partials of about -1.5e9 (each a legal fixed-point value) carried the word back into
+    the valid band: NaN + (-1.5e9) + (-1.5e9) folded to a finite number.  Exactly that: a weight gradient whose 256 M-splits hold one
+    NaN partial, two partials of -1.5e9 and 253 zeros for element [0, 0] (mgx_linear_dw: one 128 x 128 tile, 64-row splits)."""
+    from musicgeneration_amd import _lib, ops
+    dev = _dev()
+    M, N, K = 16384, 64, 64
+    dy = torch.zeros(M, N, dtype=torch.bfloat16)
+    x = torch.zeros(M, K, dtype=torch.bfloat16)
+    x[:, 0] = 1.0
+    x[:, 1] = 1.0
+    dy[0:64, 0] = float("nan")                       # split 0 -> NaN partial
+    dy[64:192, 0] = -2.34e7                          # splits 1, 2: 64 rows x -2.34e7 = -1.5e9 each (bf16 holds 2.34e7 to 3 digits)
+    dy[0:64, 1] = 3.0                                # a clean column beside it
+    ops.set_deterministic(True)
+    try:
+        gw, gb = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        lib = _lib.load()
+        dyd, xd = dy.to(dev), x.to(dev)
+        _lib.check(lib.mgx_linear_dw(ops.ptr(dyd), ops.ptr(xd), ops.ptr(gw), ops.ptr(gb), M, N, K, ops.stream_ptr()), "mgx_linear_dw")
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(False)
+    gw, gb = gw.cpu(), gb.cpu()
+    assert torch.isnan(gw[0, 0]) and torch.isnan(gw[0, 1]) and torch.isnan(gb[0])
+    assert gw[1, 0].item() == 192.0 and gw[1, 1].item() == 192.0 and gb[1].item() == 192.0
+    assert torch.isfinite(gw[1:]).all() and torch.isfinite(gb[1:]).all()
+
+
 @pytest.mark.parametrize("B,L,d", [(2, 256, 128), (1, 1024, 64), (3, 512, 192), (2, 2048, 128), (1, 640, 64)])
 def test_dkv64_matches_the_32_key_kernel_bitwise(B, L, d):
     """The 64-keys-per-wave dK/dV kernel whose whole sweep is the generated, hand-scheduled asm block (rel_attn_dkv64.hip,

@@ -592,3 +592,62 @@ def test_model_with_interior_pads_matches_the_oracle():
         assert cos >= 0.99, (n, cos)
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("max_seq,L", [(128, 50), (100, 100), (100, 70), (64, 33), (40, 7)])
+def test_any_sequence_length_up_to_max_seq_matches_the_oracle(max_seq, L):
+    """VERDICT r5 missing 5: the reference takes every L <= max_seq, and any max_seq (layers.py:64-109, E is [max_seq, 64]); the
+    kernels sweep 32-key tiles.  MusicTransformer.forward pads other lengths with trailing pad tokens (masked keys in the causal
+    future of every real row) and, when that reaches past a max_seq that is itself no multiple of 32, the positional table and
+    the relative embedding with zero rows -- logits and every gradient against the oracle's fp32 forward / autograd at exactly
+    that (max_seq, L).  Tolerances as the interior-pad test."""
+    from musicgeneration_amd.criterion import SmoothCrossEntropyLoss
+    from musicgeneration_amd.network import MusicTransformer
+    from oracle import ref_cpu as R
+    V, d, nl, B = 60, 128, 2, 3
+    pad = V - 1
+    p0 = R.init_params(V, d, nl, max_seq, seed=31)
+    for k in p0:
+        if k.endswith("embedding.weight") or k.endswith("rga.E"):
+            p0[k] = p0[k] * 0.3
+    g = torch.Generator().manual_seed(L)
+    x = torch.randint(0, V - 1, (B, L), generator=g)
+    y = torch.randint(0, V - 1, (B, L), generator=g)
+    if L > 8:
+        x[1, L - 3:] = pad
+        y[1, L - 3:] = pad
+    params = {k: v.clone().requires_grad_(True) for k, v in p0.items()}
+    ref_logits = R.model_forward(params, x, pad)[0]
+    ref_loss = R.smooth_ce(ref_logits, y, 0.1, V, pad)
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=max_seq, dropout=0.0)
+    mt.load_state_dict({k: v.clone() for k, v in p0.items()})
+    mt = mt.cuda().train()
+    logits = mt(x.to(torch.int32).cuda())
+    assert tuple(logits.shape) == (B, L, V)
+    got, ref = logits.float().cpu(), ref_logits.detach()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-2
+    loss = SmoothCrossEntropyLoss(0.1, V, pad)(logits, y.to(torch.int32).cuda())
+    assert abs(loss.item() - ref_loss.item()) <= 2e-2 * abs(ref_loss.item())
+    loss.backward()
+    ref_loss.backward()
+    mt.check_no_leading_pads()
+    checked = 0
+    for n, p in mt.named_parameters():
+        a, b = p.grad.float().cpu(), params[n].grad
+        assert a.shape == b.shape, n
+        a, b = a.flatten(), b.flatten()
+        if b.norm() < 1e-7 or n.endswith("Wk.bias"):
+            continue
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        assert cos >= 0.99, (n, cos)
+        checked += 1
+    assert checked >= 20
+    # eval: (logits, weights) as the reference returns them, weights [B,h,L,L]
+    mt.eval()
+    mt.return_attention_weights = True
+    with torch.no_grad():
+        lg, ws = mt(x.to(torch.int32).cuda())
+    assert tuple(lg.shape) == (B, L, V) and len(ws) == nl and tuple(ws[0].shape) == (B, d // 64, L, L)
+    assert (ws[0].sum(-1) - 1).abs().max().item() < 2e-2
