@@ -2,7 +2,8 @@
 same prints, same checkpoint dict {'net','optimizer','epoch'} and file name, same loop semantics
 (train.py:252-329: per-epoch batches, loss/accum_grad, Noam schedule step every accum_grad
 micro-batches, 2-sample eval per epoch, save every 50 epochs and on Ctrl-C) -- running on the MI355X
-kernels.  Extras that do not change the defaults: --num-layers --d-model --repr --dropout --dp.
+kernels.  Extras that do not change the defaults: --num-layers --d-model --repr --dropout --dp, and the
+data-parallel co-residency knobs --rccl-cus --nccl-channels --buckets.
 
 The reference parses -b/-e/-l/-w/-S/-i/-g but its loop reads config.* instead; here the
 flags are honoured, with the reference's config constants as their defaults.  Unlike the reference
@@ -49,6 +50,11 @@ def get_options(argv=None):
     parser.add_option('--accum-grad', dest='accum_grad', type='int', default=config.accum_grad)
     parser.add_option('--field', dest='field', type='string', default=None, help="MuMIDI .data dict field")
     parser.add_option('--max-batches', dest='max_batches', type='int', default=0, help='stop after N micro-batches')
+    # data-parallel co-residency knobs (the same three as bench.py): CUs kept free of the compute stream for
+    # RCCL's kernels, the number of RCCL channels, per-layer gradient buckets merged into K groups
+    parser.add_option('--rccl-cus', dest='rccl_cus', type='int', default=0, help='multiple of 8; 0 = the compute stream uses the whole chip')
+    parser.add_option('--nccl-channels', dest='nccl_channels', type='int', default=0, help="0 = RCCL's default")
+    parser.add_option('--buckets', dest='buckets', type='int', default=0, help='0 = one all-reduce per layer')
     return parser.parse_args(argv)[0]
 
 
@@ -67,6 +73,18 @@ def vocab_of(repr_name):
 
 def main(argv=None):
     options = get_options(argv)
+    prev = torch.cuda.current_stream() if torch.cuda.is_available() else None
+    try:
+        return _run(options)
+    finally:
+        if options.rccl_cus > 0 and prev is not None:      # --rccl-cus made a masked stream the current one: hand the caller its own back
+            from . import ops
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(prev)
+            ops.configure_streams(0, 0)
+
+
+def _run(options):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -78,7 +96,14 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if options.nccl_channels > 0:                      # before the communicator exists: RCCL reads them at init
+            os.environ["NCCL_MIN_NCHANNELS"] = os.environ["NCCL_MAX_NCHANNELS"] = str(options.nccl_channels)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if options.rccl_cus > 0:
+        # every kernel of this process from here on runs on a stream restricted to the other CUs (ops.configure_streams)
+        from . import ops
+        ops.configure_streams(0, options.rccl_cus, device=device)
+        torch.cuda.set_stream(ops.main_stream(device))
 
     vocab = vocab_of(options.repr)
     pad = vocab - 1
@@ -116,7 +141,7 @@ def main(argv=None):
     mt = MusicTransformer(**model_config)
     mt.to(device)
     from .dp import DataParallel
-    dp = DataParallel(mt) if multi_gpu else None
+    dp = DataParallel(mt, groups=options.buckets or None) if multi_gpu else None
     opt = FusedAdam(mt, lr=0, betas=(0.9, 0.98), eps=1e-9, grad_scale=dp.grad_scale if dp else 1.0)
     scheduler = CustomSchedule(config.embedding_dim, optimizer=opt)   # d_model of the schedule = config constant, as in train.py:144
     start_epoch = 0

@@ -53,6 +53,20 @@ def test_train_cli_checkpoint_resume_generate(tmp_path, capsys):
     NoteSeq.from_midi_file(files[0])          # parses
 
 
+def test_train_cli_with_the_co_residency_knobs(tmp_path, capsys):
+    """train.py --rccl-cus 16 --buckets 2 --nccl-channels 2 (single process here: the compute stream is masked
+    to 240 CUs, the data-parallel knobs are accepted and idle) trains, and hands the caller's stream back afterwards"""
+    from musicgeneration_amd import ops, train
+    data, out = str(tmp_path / "data"), str(tmp_path / "ckpt") + "/"
+    _dataset(data)
+    before = torch.cuda.current_stream().cuda_stream
+    train.main(["-d", data, "-s", out, "-b", "4", "-M", "64", "--num-layers", "1", "--d-model", "128", "-e", "1", "-i", "1",
+                "--rccl-cus", "16", "--buckets", "2", "--nccl-channels", "2"])
+    log = capsys.readouterr().out
+    assert "Train >>>> Loss:" in log and "Done saving" in log
+    assert torch.cuda.current_stream().cuda_stream == before and ops.stream_plan() is None
+
+
 def test_melody_rnn_train_cli(tmp_path, capsys):
     """Event_MelodyRNN/train.py's flags and 'segment' loop on the GRU backward-through-time kernels: the loss of a
     learnable synthetic corpus goes down over epochs, a reference-format state_dict is written per epoch and loads back."""

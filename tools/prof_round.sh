@@ -2,11 +2,11 @@
 # One GPU call that regenerates the round's profile artefacts under gpurun_out/prof/ (copy the ones to keep into profiles/):
 #   kernel trace of the bench step, PMC utilisation of the attention kernels, PMC traffic, the bench line, the decode trace,
 #   timings of every attention kernel alone, the cfg4 kernel trace.
-# usage (GPU box, repo root): bash tools/prof_round.sh <tag> [batch]      e.g. r03 64   (batch: default = the bench default, 64)
+# usage (GPU box, repo root): bash tools/prof_round.sh <tag> [batch]      e.g. r03 64   (batch: default = the bench default, 128 since round 6)
 set -o pipefail
 export TMPDIR=/tmp
 TAG=${1:-rXX}
-B=${2:-64}
+B=${2:-128}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 export TMPD=/tmp/mgx_prof_$$; mkdir -p $TMPD

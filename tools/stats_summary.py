@@ -1,4 +1,5 @@
-import csv, sys
+import csv, sys, signal
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)      # `| head` closes the pipe: end quietly
 rows = list(csv.DictReader(open(sys.argv[1])))
 nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
