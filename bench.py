@@ -622,6 +622,9 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        # rank 0 was busy for a second or two more (kernel timing, JSON): the ranks leave the process group together, so that no
+        # communicator is torn down under a peer that has already exited
+        dist.barrier()
         dist.destroy_process_group()
 
 
