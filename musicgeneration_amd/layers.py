@@ -185,18 +185,25 @@ class FlatStore:
     """Flat fp32 parameter / gradient buffers + bf16 shadow for an ordered list of parameters."""
 
     def __init__(self, named: List[Tuple[str, torch.nn.Parameter]], device, buckets: List[Tuple[str, List[str]]],
-                 padded: Optional[Dict[str, int]] = None):
+                 padded: Optional[Dict[str, int]] = None, colpad: Optional[Dict[str, int]] = None):
         """``padded[name]`` = number of elements to reserve for ``name`` (>= numel): the tail stays zero in
         every buffer (parameters, gradients, moments, shadow) -- used to pad the vocabulary projection to a
-        multiple of 64 rows so all GEMM dimensions are tile-aligned."""
+        multiple of 64 rows so all GEMM dimensions are tile-aligned.
+        ``colpad[name]`` = padded COLUMN count of a 2-D parameter: it is stored as [rows, colpad] with zero columns
+        beyond its own, and the Parameter becomes the strided view ``[:, :cols]`` of that -- the FFN's second
+        weight when d_model / 2 is not a multiple of 64 (the GEMMs' reduction length; round 6)."""
         self.names = [n for n, _ in named]
         self.offsets: Dict[str, Tuple[int, int]] = {}
         self.reserved: Dict[str, int] = {}
+        self.colpad: Dict[str, int] = dict(colpad or {})
         padded = padded or {}
         off = 0
         for n, p in named:
             self.offsets[n] = (off, p.numel())
             res = max(p.numel(), padded.get(n, 0))
+            if n in self.colpad:
+                assert p.dim() == 2 and self.colpad[n] >= p.shape[1]
+                res = p.shape[0] * self.colpad[n]
             self.reserved[n] = res
             off += (res + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
@@ -204,12 +211,12 @@ class FlatStore:
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=device)
         self.params = {}
+        self.shapes = {n: tuple(p.shape) for n, p in named}
         for n, p in named:
-            o, k = self.offsets[n]
-            view = self.param[o:o + k].view(p.shape)
+            view = self.view(self.param, n)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.grad[o:o + k].view(p.shape)
+            p.grad = self.view(self.grad, n)
             self.params[n] = p
         # bucket = (name, start, end) contiguous range of the flat buffers
         self.buckets: List[Tuple[str, int, int]] = []
@@ -221,13 +228,22 @@ class FlatStore:
         self.sync_shadow(force=True)
 
     # ---- views ------------------------------------------------------------------------------------
-    def w(self, name):          # bf16 shadow view with the parameter's shape
+    def view(self, buf, name):
+        """the region of parameter ``name`` in flat buffer ``buf`` (parameters, gradients, shadow, or an optimiser's moments laid
+        out alike) with the parameter's own shape: contiguous, or -- column-padded parameters -- the [:, :cols] view of its
+        [rows, colpad] storage"""
         o, k = self.offsets[name]
-        return self.shadow[o:o + k].view(self.params[name].shape)
+        shp = self.shapes[name]
+        if name in self.colpad:
+            cp = self.colpad[name]
+            return buf[o:o + shp[0] * cp].view(shp[0], cp)[:, :shp[1]]
+        return buf[o:o + k].view(shp)
+
+    def w(self, name):          # bf16 shadow view with the parameter's shape
+        return self.view(self.shadow, name)
 
     def g(self, name):          # fp32 gradient view
-        o, k = self.offsets[name]
-        return self.grad[o:o + k].view(self.params[name].shape)
+        return self.view(self.grad, name)
 
     def padded_view(self, name, rows, cols=None, what="shadow"):
         """view over the reserved (zero-padded) region of ``name`` as [rows, cols] (or [rows])"""
@@ -271,8 +287,7 @@ class FlatStore:
         if lost:
             self.grad.zero_()
             for n, p in self.params.items():
-                o, k = self.offsets[n]
-                p.grad = self.grad[o:o + k].view(p.shape)
+                p.grad = self.view(self.grad, n)
 
 
 class Encoder(torch.nn.Module):

@@ -39,6 +39,10 @@ class MusicTransformer(torch.nn.Module):
         # is the same rule (pad = last vocabulary id), overridable per model
         self.pad_token = vocab_size - 1
         self.vocab_padded = (vocab_size + 63) // 64 * 64     # rows of the vocabulary GEMM (zero rows beyond V)
+        if embedding_dim % 64 != 0:
+            raise ValueError("the MI355X kernels fix the head width at 64 (the reference's h = d // 64, dh = d // h, layers.py:219): "
+                             f"embedding_dim must be a multiple of 64, got {embedding_dim}")
+        self.ffn_padded = (embedding_dim // 2 + 63) // 64 * 64      # FFN width in the flat buffers (zero rows / columns beyond d/2)
         self.Decoder = Encoder(num_layers=self.num_layer, d_model=self.embedding_dim,
                                input_vocab_size=self.vocab_size, rate=dropout, max_len=max_seq)
         self.fc = torch.nn.Linear(self.embedding_dim, self.vocab_size)
@@ -63,7 +67,18 @@ class MusicTransformer(torch.nn.Module):
         buckets.append(("fc", ["fc.weight", "fc.bias"]))
         assert set(order) == set(named), "flat order must cover every parameter exactly once"
         padded = {"fc.weight": self.vocab_padded * self.embedding_dim, "fc.bias": self.vocab_padded}
-        return [(n, named[n]) for n in order], buckets, padded
+        # FFN width d/2 (layers.py:143-144) padded to the GEMMs' reduction granule of 64 when d = 64 * odd (d = 192, 320, ...): zero
+        # rows / bias entries of FFN_pre, zero columns of FFN_suf -- ReLU(0) = 0 feeds zero columns, every gradient there is exactly 0,
+        # Adam leaves zeros zero.  The Parameters keep the reference's shapes (state_dict, checkpoints).
+        colpad = {}
+        H, Hp, d = self.embedding_dim // 2, self.ffn_padded, self.embedding_dim
+        if Hp != H:
+            for i in range(self.num_layer):
+                pre = f"Decoder.enc_layers.{i}."
+                padded[pre + "FFN_pre.weight"] = Hp * d
+                padded[pre + "FFN_pre.bias"] = Hp
+                colpad[pre + "FFN_suf.weight"] = Hp
+        return [(n, named[n]) for n in order], buckets, padded, colpad
 
     def store(self) -> FlatStore:
         dev = self.fc.weight.device
@@ -71,8 +86,8 @@ class MusicTransformer(torch.nn.Module):
             if dev.type != "cuda":
                 raise ops._lib.MgxError("MusicTransformer runs on the MI355X kernels only: move it to a HIP "
                                         "device first (model.to('cuda')); there is no CPU fallback")
-            named, buckets, padded = self._flat_order()
-            self._store = FlatStore(named, dev, buckets, padded)
+            named, buckets, padded, colpad = self._flat_order()
+            self._store = FlatStore(named, dev, buckets, padded, colpad)
             if os.environ.get("MGX_DETERMINISTIC", "0") == "1" and not ops.deterministic():
                 ops.set_deterministic(True, dev)
         return self._store
@@ -193,10 +208,16 @@ class MusicTransformer(torch.nn.Module):
             lp.gwfc, lp.gbfc = st.g(pre + "rga.fc.weight"), st.g(pre + "rga.fc.bias")
             lp.g1, lp.b1 = P[pre + "layernorm1.weight"].data, P[pre + "layernorm1.bias"].data
             lp.gg1, lp.gb1 = st.g(pre + "layernorm1.weight"), st.g(pre + "layernorm1.bias")
-            lp.wpre, lp.bpre = st.w(pre + "FFN_pre.weight"), P[pre + "FFN_pre.bias"].data
-            lp.gwpre, lp.gbpre = st.g(pre + "FFN_pre.weight"), st.g(pre + "FFN_pre.bias")
-            lp.wsuf, lp.bsuf = st.w(pre + "FFN_suf.weight"), P[pre + "FFN_suf.bias"].data
-            lp.gwsuf, lp.gbsuf = st.g(pre + "FFN_suf.weight"), st.g(pre + "FFN_suf.bias")
+            H, Hp = d // 2, self.ffn_padded
+            if Hp == H:
+                lp.wpre, lp.bpre = st.w(pre + "FFN_pre.weight"), P[pre + "FFN_pre.bias"].data
+                lp.gwpre, lp.gbpre = st.g(pre + "FFN_pre.weight"), st.g(pre + "FFN_pre.bias")
+                lp.wsuf, lp.gwsuf = st.w(pre + "FFN_suf.weight"), st.g(pre + "FFN_suf.weight")
+            else:           # d = 64 * odd: the kernels see the zero-padded width (FlatStore: padded rows / colpad columns)
+                lp.wpre, lp.bpre = st.padded_view(pre + "FFN_pre.weight", Hp, d), st.padded_view(pre + "FFN_pre.bias", Hp, None, "param")
+                lp.gwpre, lp.gbpre = st.padded_view(pre + "FFN_pre.weight", Hp, d, "grad"), st.padded_view(pre + "FFN_pre.bias", Hp, None, "grad")
+                lp.wsuf, lp.gwsuf = st.padded_view(pre + "FFN_suf.weight", d, Hp), st.padded_view(pre + "FFN_suf.weight", d, Hp, "grad")
+            lp.bsuf, lp.gbsuf = P[pre + "FFN_suf.bias"].data, st.g(pre + "FFN_suf.bias")
             lp.g2, lp.b2 = P[pre + "layernorm2.weight"].data, P[pre + "layernorm2.bias"].data
             lp.gg2, lp.gb2 = st.g(pre + "layernorm2.weight"), st.g(pre + "layernorm2.bias")
             out.append(lp)
@@ -372,8 +393,8 @@ class MusicTransformer(torch.nn.Module):
                 bqkv=st.fused(pre + "rga.Wq.bias", pre + "rga.Wv.bias", 1, 3 * d, "param").view(3 * d),
                 E=st.w(pre + "rga.E"), wfc=st.w(pre + "rga.fc.weight"), bfc=Pm[pre + "rga.fc.bias"].data,
                 g1=Pm[pre + "layernorm1.weight"].data, b1=Pm[pre + "layernorm1.bias"].data,
-                w1=st.w(pre + "FFN_pre.weight"), bb1=Pm[pre + "FFN_pre.bias"].data,
-                w2=st.w(pre + "FFN_suf.weight"), bb2=Pm[pre + "FFN_suf.bias"].data,
+                w1=self._layer_params()[i].wpre, bb1=self._layer_params()[i].bpre,
+                w2=self._layer_params()[i].wsuf, bb2=Pm[pre + "FFN_suf.bias"].data,
                 g2=Pm[pre + "layernorm2.weight"].data, b2=Pm[pre + "layernorm2.bias"].data))
         wv, bv = st.padded_view("fc.weight", Vp, d), st.padded_view("fc.bias", Vp, None, "param")
         # grammar: [V, ceil(V/32)] bit table "token v may follow token t" (e.g. REMI_EventSeq.next_token_table()); applied

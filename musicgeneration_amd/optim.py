@@ -49,10 +49,8 @@ class FusedAdam(torch.optim.Optimizer):
         names = self._torch_order()
         state = {}
         for i, n in enumerate(names):
-            o, k = st.offsets[n]
-            shp = st.params[n].shape
-            state[i] = {"step": torch.tensor(float(self._t)), "exp_avg": self.m[o:o + k].view(shp).clone(),
-                        "exp_avg_sq": self.v[o:o + k].view(shp).clone()}
+            state[i] = {"step": torch.tensor(float(self._t)), "exp_avg": st.view(self.m, n).clone(),
+                        "exp_avg_sq": st.view(self.v, n).clone()}
         g = self.param_groups[0]
         group = {"lr": g["lr"], "betas": g["betas"], "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
@@ -70,11 +68,11 @@ class FusedAdam(torch.optim.Optimizer):
             s = sd["state"].get(i)
             if s is None:
                 continue
-            o, k = st.offsets[n]
+            k = st.offsets[n][1]
             if s["exp_avg"].numel() != k:
                 raise ValueError(f"optimizer state {i} has {s['exp_avg'].numel()} elements, parameter {n} has {k}")
-            self.m[o:o + k].copy_(s["exp_avg"].reshape(-1))
-            self.v[o:o + k].copy_(s["exp_avg_sq"].reshape(-1))
+            st.view(self.m, n).copy_(s["exp_avg"].reshape(st.shapes[n]))
+            st.view(self.v, n).copy_(s["exp_avg_sq"].reshape(st.shapes[n]))
             self._t = int(float(s["step"]))
         g = sd["param_groups"][0]
         self.param_groups[0]["lr"] = g["lr"]
