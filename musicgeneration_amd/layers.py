@@ -113,18 +113,32 @@ class RelativeGlobalAttention(torch.nn.Module):
 
     def forward(self, inputs, mask=None, **kwargs):
         """inputs = [q, k, v], each [B,L,d] (layers.py:64-109) -> (out [B,L,d], attention_weights [B,h,L,L] or None).
-        Self-attention shapes only (len_q == len_k <= max_seq, L % 32 == 0).  Computes in bf16; returns q's dtype."""
+        Self-attention shapes only (len_q == len_k <= max_seq; any such L since round 6: other lengths than multiples of the
+        kernels' 32-key tile are zero-padded at the end, the padded keys masked, the padded rows dropped).  Computes in bf16;
+        returns q's dtype."""
         q, k, v = inputs
         if not (q.shape == k.shape == v.shape) or q.dim() != 3 or q.shape[-1] != self.d:
             raise ValueError("expected three [B,L,d] tensors of one shape")
         _need_mask(mask)
         B, L, _ = q.shape
-        if L % 32 != 0 or L > self.max_seq:
-            raise ValueError(f"sequence length {L} must be a multiple of 32 and <= max_seq={self.max_seq}")
+        if L < 1 or L > self.max_seq:
+            raise ValueError(f"sequence length {L} must be in 1 .. max_seq={self.max_seq}")
         self.len_q = self.len_k = L
-        padbits = None if mask is None else _pad_bitmap_from_flags(key_padding_from_mask(mask, L))
+        Lp = (L + 31) // 32 * 32
+        padded = None if mask is None else key_padding_from_mask(mask, L)
+        same = q is k and k is v
+        E = self.E
+        if Lp != L:
+            tail = (0, 0, 0, Lp - L)
+            q = torch.nn.functional.pad(q, tail)
+            k, v = (q, q) if same else (torch.nn.functional.pad(k, tail), torch.nn.functional.pad(v, tail))
+            if padded is not None:
+                padded = torch.nn.functional.pad(padded, (0, Lp - L), value=True)
+            if Lp > self.max_seq:                                # distances >= max_seq only occur for padded queries: zero rows in FRONT
+                E = torch.cat([torch.zeros(Lp - self.max_seq, E.shape[1], dtype=E.dtype, device=E.device), E], 0)
+        padbits = None if padded is None else _pad_bitmap_from_flags(padded)
         bf = torch.bfloat16
-        if q is k and k is v:
+        if same:
             x16 = q.to(bf).contiguous()
             qkv = ops.linear_std(x16, torch.cat([self.Wq.weight, self.Wk.weight, self.Wv.weight], 0),
                                  torch.cat([self.Wq.bias, self.Wk.bias, self.Wv.bias], 0))
@@ -132,15 +146,17 @@ class RelativeGlobalAttention(torch.nn.Module):
             qkv = torch.cat([ops.linear_std(t.to(bf).contiguous(), lin.weight, lin.bias)
                              for t, lin in ((q, self.Wq), (k, self.Wk), (v, self.Wv))], -1)
         if mask is None:                                          # the reference's sampling call: no look-ahead, no padding mask
-            att = ops.rel_attn_fwd_nomask(qkv, self.E.detach().to(bf).contiguous())
-            return ops.linear_std(att, self.fc.weight, self.fc.bias).to(q.dtype), None
-        att, lse = ops.rel_attn_std(qkv, self.E, padbits)          # E is cut to its last L rows inside (M >= L)
-        out = ops.linear_std(att, self.fc.weight, self.fc.bias)
+            att = ops.rel_attn_fwd_nomask(qkv, E.detach().to(bf).contiguous(), L)      # keys >= L do not exist
+            return ops.linear_std(att[:, :L].contiguous(), self.fc.weight, self.fc.bias).to(inputs[0].dtype), None
+        att, lse = ops.rel_attn_std(qkv, E, padbits)               # E is cut to its last Lp rows inside (M >= Lp)
+        out = ops.linear_std(att[:, :L].contiguous() if Lp != L else att, self.fc.weight, self.fc.bias)
         weights = None
         if self.need_weights:
             with torch.no_grad():
-                weights = ops.rel_attn_weights(qkv.detach(), self.E.detach().to(bf).contiguous(), padbits, lse)
-        return out.to(q.dtype), weights
+                weights = ops.rel_attn_weights(qkv.detach(), E.detach().to(bf).contiguous(), padbits, lse)
+                if Lp != L:
+                    weights = weights[:, :, :L, :L]
+        return out.to(inputs[0].dtype), weights
 
 
 class EncoderLayer(torch.nn.Module):

@@ -262,13 +262,17 @@ class MusicTransformer(torch.nn.Module):
         st.sync_shadow()
         B, W = window.shape
         Lp = (W + 31) // 32 * 32
-        if Lp > self.max_seq:
-            raise ValueError(f"window {W} pads to {Lp} > max_seq={self.max_seq}")
+        if W > self.max_seq:
+            raise ValueError(f"window {W} > max_seq={self.max_seq}")
         dev, d, Pm = st.param.device, self.embedding_dim, st.params
         seq = torch.zeros(B, Lp, dtype=torch.int32, device=dev)
         seq[:, :W] = window.to(torch.int32)
-        hh = ops.embed_pe_fwd(seq, Pm["Decoder.embedding.weight"].data, self.Decoder.pos_encoding.table())
-        for lp in self._layer_params():
+        pe, layer_params = self.Decoder.pos_encoding.table(), self._layer_params()
+        if Lp > self.max_seq:          # max_seq is no multiple of 32: zero rows for the padded positions (see _logits)
+            pe = torch.cat([pe, torch.zeros(Lp - self.max_seq, d, dtype=pe.dtype, device=pe.device)], 0)
+            layer_params, _ = self._params_for_padded_E(layer_params, Lp - self.max_seq, lambda name: None, False)
+        hh = ops.embed_pe_fwd(seq, Pm["Decoder.embedding.weight"].data, pe)
+        for lp in layer_params:
             qkv = ops.linear_fwd(hh, lp.wqkv, lp.bqkv, 0)
             att = ops.rel_attn_fwd_nomask(qkv, lp.E, W)
             o1 = ops.add_ln_fwd(ops.linear_fwd(att, lp.wfc, lp.bfc, 0), hh, lp.g1, lp.b1, 1e-6)[0]

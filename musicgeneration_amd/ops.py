@@ -809,18 +809,27 @@ def embed_pe(tok, table, pe, p_drop=0.0, seed=0, gtable=None, done=None):
 # flat-buffer nodes above (no per-call rounding, gradients accumulated in place).
 # --------------------------------------------------------------------------------------------------
 class _LinearStd(torch.autograd.Function):
+    """y = act(x @ W^T + b) with returned gradients.  A reduction length that is no multiple of the GEMMs' granule of 64 (the FFN's
+    second projection at d_model = 64 * odd: K = d / 2) is zero-padded here, per call; the model's flat-buffer path pads once,
+    inside its buffers (network._flat_order)."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         w16 = weight.detach().to(BF16).contiguous()
-        y = linear_fwd(x, w16, None if bias is None else bias.detach().float().contiguous(), act)
+        K = w16.shape[1]
+        Kp = (K + 63) // 64 * 64
+        if Kp != K:
+            w16 = torch.nn.functional.pad(w16, (0, Kp - K))
+            x = torch.nn.functional.pad(x, (0, Kp - K))
+        y = linear_fwd(x.contiguous(), w16, None if bias is None else bias.detach().float().contiguous(), act)
         ctx.save_for_backward(x, w16, y if act else None)
-        ctx.meta = (weight.dtype, bias is not None, bias.dtype if bias is not None else None)
+        ctx.meta = (weight.dtype, bias is not None, bias.dtype if bias is not None else None, K)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w16, y = ctx.saved_tensors
-        wdt, has_b, bdt = ctx.meta
+        wdt, has_b, bdt, K = ctx.meta
         dy = dy.contiguous()
         gw = torch.zeros(w16.shape, dtype=torch.float32, device=dy.device)
         gb = torch.zeros(w16.shape[0], dtype=torch.float32, device=dy.device) if has_b else None
@@ -828,6 +837,8 @@ class _LinearStd(torch.autograd.Function):
             dy = torch.where(y > 0, dy, torch.zeros_like(dy))
         dx = linear_dx(dy, w16)
         linear_dw(dy, x, gw, gb)
+        if w16.shape[1] != K:
+            dx, gw = dx[..., :K], gw[:, :K]
         return dx, gw.to(wdt), (gb.to(bdt) if has_b else None), None
 
 

@@ -64,7 +64,7 @@ def test_layer_forward_mask_contract():
     with pytest.raises(ValueError, match="look-ahead"):
         rga([x, x, x], full)
     with pytest.raises(ValueError):
-        rga([x[:, :20], x[:, :20], x[:, :20]], full[..., :20, :20])            # L % 32 != 0
+        rga([x[:, :20], x[:, :20], x[:, :20]], full[..., :20, :20])            # not the look-ahead mask either (any L is fine since round 6)
 
 
 def test_encoder_and_layer_forward_match_oracle():
@@ -123,3 +123,56 @@ def test_encoder_and_layer_forward_match_oracle():
     o_ref, _ = R.encoder_layer({k: v.detach() for k, v in p.items()}, "Decoder.enc_layers.0.", x, R.look_ahead_mask(tok, pad),
                                d // 64, 0.0, False)
     assert _rel(out, o_ref) <= 2e-2
+
+
+@pytest.mark.parametrize("d,max_len,L", [(192, 50, 50), (128, 96, 41), (320, 64, 64)])
+def test_stand_alone_layers_take_any_length_and_any_64h_width(d, max_len, L):
+    """the layer-level call surface (Encoder / EncoderLayer / RelativeGlobalAttention.forward) over the reference's whole range with
+    heads of 64: any L <= max_seq (zero-padded to the kernels' 32-key tile inside rga.forward, the relative embedding with zero rows in
+    front where the padding reaches past max_seq) and d_model = 64 h for odd h (FFN width d / 2 = 32 * odd, zero-padded per call in
+    ops._LinearStd) -- hidden states, attention weights and every gradient against the oracle"""
+    from musicgeneration_amd.layers import Encoder
+    from musicgeneration_amd import utils
+    from oracle import ref_cpu as R
+    V, nl, B = 70, 2, 2
+    pad = V - 1
+    p = R.init_params(V, d, nl, max_len, seed=6)
+    for k in p:
+        if k.endswith("embedding.weight") or k.endswith("rga.E"):
+            p[k] = p[k] * 0.3
+    enc = Encoder(num_layers=nl, d_model=d, input_vocab_size=V, rate=0.0, max_len=max_len)
+    enc.load_state_dict({k[len("Decoder."):]: v for k, v in p.items() if k.startswith("Decoder.")}, strict=True)
+    enc = enc.cuda().train()
+    g = torch.Generator().manual_seed(L)
+    tok = torch.randint(0, V - 1, (B, L), generator=g)
+    tok[1, -5:] = pad
+    tok[0, 7] = pad                                                            # an interior pad
+    _, _, lam = utils.get_masked_with_pad_tensor(L, tok, tok, pad)
+    hid, ws = enc(tok.cuda(), lam.cuda())
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref, wref = R.decoder_stack(pr, tok, R.look_ahead_mask(tok, pad))
+    assert tuple(hid.shape) == (B, L, d) and tuple(ws[0].shape) == (B, d // 64, L, L)
+    assert _rel(hid, ref.detach()) <= 2e-2
+    assert (ws[1].cpu() - wref[1].detach()).abs().max().item() <= 2e-2
+    wsum = torch.linspace(-1, 1, hid.numel()).reshape(hid.shape)
+    (hid * wsum.cuda()).sum().backward()
+    R.EMULATE_BF16 = True
+    try:
+        pe = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ref_e, _ = R.decoder_stack(pe, tok, R.look_ahead_mask(tok, pad))
+        (ref_e * wsum).sum().backward()
+    finally:
+        R.EMULATE_BF16 = False
+    for name, prm in enc.named_parameters():
+        if name.endswith("Wk.bias"):
+            continue
+        assert prm.grad.shape == pe["Decoder." + name].grad.shape, name
+        assert _cos(prm.grad, pe["Decoder." + name].grad) >= 0.999, (name, _cos(prm.grad, pe["Decoder." + name].grad))
+    # the reference's sampling call (mask=None) at a length that is no multiple of 32
+    with torch.no_grad():
+        x = torch.randn(B, L, d, generator=g) * 0.5
+        out, w = enc.enc_layers[0].rga([x.cuda()] * 3, None)
+    pl = {"rga." + k: v.detach().float().cpu() for k, v in enc.enc_layers[0].rga.state_dict().items()}
+    ref0, _ = R.rga_forward(pl, "rga.", x, None, d // 64)
+    assert w is None and tuple(out.shape) == (B, L, d)
+    assert (out.float().cpu() - ref0).abs().max().item() <= 3e-2 * ref0.abs().max().item()
