@@ -75,7 +75,10 @@ def test_rccl_world_of_one_matches_no_dp(tmp_path):
     for a, b in zip(one["losses"], rccl["losses"]):
         assert abs(a - b) <= tol * abs(a), (one["losses"], rccl["losses"], noise)
     pnoise = abs(one["param_sum"] - again["param_sum"]) / one["param_abs"]
-    assert abs(one["param_sum"] - rccl["param_sum"]) <= max(10 * pnoise, 1e-5) * one["param_abs"]
+    # (floor 3e-5 of the parameters' L1 norm: one pair of plain runs measured 1.06e-5 against a third -- round 6 -- while the losses
+    #  agreed to 1e-4; a bucket reduced before its last gradient kernel had finished loses whole gradient terms, >= 1e-3.  The
+    #  deterministic-mode twin below asserts bit-identity, which is the sharp form of this test)
+    assert abs(one["param_sum"] - rccl["param_sum"]) <= max(10 * pnoise, 3e-5) * one["param_abs"]
 
 
 def test_deterministic_mode_repeats_bit_for_bit_and_rccl_world_of_one_equals_no_dp(tmp_path):
