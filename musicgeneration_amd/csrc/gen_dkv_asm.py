@@ -75,7 +75,12 @@ V_STAMP = 246        # ..253 (stamp builds): cycle sums
 STAMP = False
 ST_CACHE = os.environ.get("MGX_DKV64_ST", "nt")          # experiment: cache policy of the dS stores (nt | plain | sc1 | sc0sc1)
 ST_PINS = [int(x) for x in os.environ.get("MGX_DKV64_STPIN", "").split(",") if x]      # experiment: the MFMA shadows of the four dS stores
-PEEL = 0             # timing experiments (results wrong): 1 no dS stores | 2 no E loads | 4 no DMA | 8 no skew | 16 no exp | 32 no merge | 64 no stats reads | 128 no tr reads
+# experiment (round 6): the two waves of a workgroup run the same instruction stream in lock step (one barrier per iteration), so their
+# dS stores -- 1 KB each through the CU's one store path -- always collide; "a,b,c,d:e,f,g,h" gives wave 0 and wave 1 their OWN shadows
+# for the four stores (every store is emitted twice, under EXEC = (w == 0) / (w == 1); an EXEC = 0 store moves no data)
+STAGGER = [[int(x) for x in part.split(",")] for part in os.environ.get("MGX_DKV64_STAGGER", "").split(":") if part]
+S_W0M, S_W1M = 18, 20   # (main bodies, STAGGER) lane masks of wave 0 / wave 1: all ones or zero -- the registers of S_FULL, which only the masked bodies use
+PEEL = 0             # timing experiments (results wrong): 1 no dS stores | 2 no E loads | 4 no DMA | 8 no skew | 16 no exp | 32 no merge | 64 no stats reads | 128 no tr reads | 256 only wave 0 stores dS | 512 control of 256
 
 OFF_QR, OFF_OR, OFF_ST = 0, 12288, 24576      # three LDS buffers per image: query tile t in buffer t % 3
 ST_BYTES = 512
@@ -343,9 +348,26 @@ class Step:
         for u in range(2):
             for ss in range(2):
                 src = V_DP + 16 * u + 8 * ss
-                out.append(lambda u=u, ss=ss, src=src: g.vmem_store(
-                    f"global_store_dwordx4 {v(V_L16)}, {v(src, 4)}, {s(S_SP, 2)} offset:{2048 * u + 1024 * ss}{ST_SUFFIX}", tag,
-                    regs("v", V_L16) | regs("v", src, 4) | regs("s", S_SP, 2)))
+
+                def f(u=u, ss=ss, src=src, wave=None):
+                    # PEEL 256 / 512 (round 6, timing only): is a store's ~90 cycles the two waves of a workgroup -- and the other
+                    # workgroup of the CU -- pushing 1 KB each through the CU's store path AT THE SAME POINT of the body?  256: only
+                    # wave 0's stores move data (wave 1: EXEC = 0, still counted in vmcnt); 512: the same three SALU instructions around
+                    # every store with all waves storing (what the wrapper itself costs)
+                    if PEEL & 768:
+                        g.salu(f"s_cmp_eq_u32 {s(S_W)}, 0", regs("s", S_W), {"scc"})
+                        g.salu(f"s_cselect_b64 exec, -1, {'0' if PEEL & 256 else '-1'}", {"scc"}, {"exec"})
+                    if wave is not None:
+                        g.salu(f"s_mov_b64 exec, {s((S_W0M, S_W1M)[wave], 2)}", regs("s", (S_W0M, S_W1M)[wave], 2), {"exec"})
+                    g.vmem_store(f"global_store_dwordx4 {v(V_L16)}, {v(src, 4)}, {s(S_SP, 2)} offset:{2048 * u + 1024 * ss}{ST_SUFFIX}", tag,
+                                 regs("v", V_L16) | regs("v", src, 4) | regs("s", S_SP, 2))
+                    if PEEL & 768 or wave is not None:
+                        g.salu("s_mov_b64 exec, -1", (), {"exec"})
+                if STAGGER:
+                    out.append(lambda f=f: f(wave=0))
+                    out.append(lambda f=f: f(wave=1))
+                else:
+                    out.append(f)
         return out
 
 
@@ -410,11 +432,19 @@ def body(g: Gen, b: int, do_cur: bool = True, masked: bool = False, listing=None
             for u, it in enumerate(sts):
                 it.deps += cvds[u]
         else:
-            sts = chain(add(st.st_dS(f"st{b}"), COST["store"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
-            for k, it in enumerate(sts):
-                it.deps += cvds[k >> 1][4 * (k & 1): 4 * (k & 1) + 4]
-                if ST_PINS:
-                    it.pin = ST_PINS[k]
+            if STAGGER:
+                # items (store k, wave 0), (store k, wave 1), k = 0..3: no chain -- each at its own pin, after the packs of its data
+                sts = add(st.st_dS(f"st{b}"), COST["store"] + 2 * COST["salu"], earliest=18, deadline=44, deps=sa[-1:], name="st_dS")
+                for j, it in enumerate(sts):
+                    k, wave = j >> 1, j & 1
+                    it.deps += cvds[k >> 1][4 * (k & 1): 4 * (k & 1) + 4]
+                    it.pin = STAGGER[wave][k]
+            else:
+                sts = chain(add(st.st_dS(f"st{b}"), COST["store"], earliest=20, deadline=44, deps=sa[-1:], name="st_dS"))
+                for k, it in enumerate(sts):
+                    it.deps += cvds[k >> 1][4 * (k & 1): 4 * (k & 1) + 4]
+                    if ST_PINS:
+                        it.pin = ST_PINS[k]
     ea = chain(add(st.ldE_addr(), COST["salu"], earliest=1, deadline=28, name="ldE_addr"))
     le = chain(add(st.ld_E(f"e{b}"), COST["vmem"], earliest=28, deadline=40, deps=ea[-1:], name="ld_E"))   # t2 = MFMAs 25-28
     m0 = add(st.merge(0), COST["valu"], earliest=27, deadline=38, name="merge0")                        # t0, t1 done after MFMA 24
@@ -563,6 +593,10 @@ def loop_tail(g: Gen, b: int, masked: bool):
     g.salu(f"s_cmp_lt_i32 {s(S_TM)}, 2", regs("s", S_TM), {"scc"})
     g.raw(f"s_cbranch_scc1 L_dkv_m{nb}_%=")
     # switch to the main bodies: their counted waits assume the main loop's own history, so start them from a drained state
+    if STAGGER:
+        g.salu(f"s_cmp_eq_u32 {s(S_W)}, 0", regs("s", S_W), {"scc"})
+        g.salu(f"s_cselect_b64 {s(S_W0M, 2)}, -1, 0", {"scc"}, regs("s", S_W0M, 2))
+        g.salu(f"s_cselect_b64 {s(S_W1M, 2)}, 0, -1", {"scc"}, regs("s", S_W1M, 2))
     g.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
     g.raw("s_nop 7")
     g.raw("s_nop 7")
@@ -626,12 +660,12 @@ def clobbers():
 def main():
     global STAMP, PEEL
     here = os.path.dirname(os.path.abspath(__file__))
-    if not (ST_PINS or ST_CACHE != "nt"):
+    if not (ST_PINS or STAGGER or ST_CACHE != "nt"):
         for STAMP in (False, True):
             write(here)
     STAMP = False
     PEEL = int(os.environ.get("MGX_DKV64_PEEL", "0"))
-    if PEEL or ST_PINS or ST_CACHE != "nt":          # experiment builds: a loop of their own, never the tracked one
+    if PEEL or ST_PINS or STAGGER or ST_CACHE != "nt":          # experiment builds: a loop of their own, never the tracked one
         PEEL = PEEL or 1 << 20
         write(here)
 
