@@ -80,7 +80,7 @@ ST_PINS = [int(x) for x in os.environ.get("MGX_DKV64_STPIN", "").split(",") if x
 # for the four stores (every store is emitted twice, under EXEC = (w == 0) / (w == 1); an EXEC = 0 store moves no data)
 STAGGER = [[int(x) for x in part.split(",")] for part in os.environ.get("MGX_DKV64_STAGGER", "").split(":") if part]
 S_W0M, S_W1M = 18, 20   # (main bodies, STAGGER) lane masks of wave 0 / wave 1: all ones or zero -- the registers of S_FULL, which only the masked bodies use
-PEEL = 0             # timing experiments (results wrong): 1 no dS stores | 2 no E loads | 4 no DMA | 8 no skew | 16 no exp | 32 no merge | 64 no stats reads | 128 no tr reads | 256 only wave 0 stores dS | 512 control of 256
+PEEL = 0             # timing experiments (results wrong): 1 no dS stores | 2 no E loads | 4 no DMA | 8 no skew | 16 no exp | 32 no merge | 64 no stats reads | 128 no tr reads | 256 only wave 0 stores dS | 512 control of 256 | 1024 no barrier in the loop bodies
 
 OFF_QR, OFF_OR, OFF_ST = 0, 12288, 24576      # three LDS buffers per image: query tile t in buffer t % 3
 ST_BYTES = 512
@@ -176,7 +176,8 @@ class Step:
 
         def f():
             g.wait_vm_tag(dma_tag)                         # this wave's pieces of tile n+1 have landed
-            g.raw("s_barrier")
+            if not (PEEL & 1024):                          # PEEL 1024 (round 6, timing only): what the per-iteration barrier of the two waves costs
+                g.raw("s_barrier")
         return [f]
 
     def dma_addr(self):
