@@ -14,7 +14,7 @@ Same class names, constructor arguments and ``state_dict`` keys (``Decoder.enc_l
 from __future__ import annotations
 
 import math
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch

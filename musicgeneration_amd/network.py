@@ -9,8 +9,7 @@ from __future__ import annotations
 
 import os
 
-import math
-from typing import List, Optional
+from typing import Optional
 
 import numpy as np
 import torch

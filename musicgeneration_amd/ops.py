@@ -6,8 +6,7 @@ eager PyTorch: a missing library or a non-CUDA tensor raises.
 """
 from __future__ import annotations
 
-import math
-from typing import Optional, Tuple
+from typing import Tuple
 
 import ctypes
 

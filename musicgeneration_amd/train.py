@@ -16,7 +16,6 @@ from __future__ import annotations
 import optparse
 import os
 import random
-import sys
 import time
 
 import torch
