@@ -74,3 +74,37 @@ def test_ring4_tile_statement_waits_are_sized_for_the_epilogue_hipcc_emits(tmp_p
         assert stores >= epi, f"{m.group(1)}: {stores} epilogue stores < MGX_RING4_EPI_STORES = {epi}"
         found += 1
     assert found == 4, "linear_ring4_kernel<false,0>, <true,0>, <true,1>, <true,2>"
+
+
+def test_every_register_the_asm_statements_name_is_in_their_clobber_lists():
+    """the asm statements use FIXED registers (everything but the accumulators, which are compiler-allocated
+    operands) and tell hipcc so through their clobber lists; a generator edit that reaches for a register outside its list would
+    silently corrupt a value the compiler keeps there.  Static check of the tracked loops: every vN / sN / aN (and every range
+    v[a:b]) in the instruction text is named by the statement's MGX_*_CLOBBERS."""
+    import re
+    for name, cl_macro, asm_macros in (("rel_attn_dkv64_loop.inc", "MGX_DKV64_LOOP_CLOBBERS", ["MGX_DKV64_LOOP_ASM"]),
+                                       ("linear_dw_ring4_loop.inc", "MGX_DW4_LOOP_CLOBBERS", ["MGX_DW4_LOOP_ASM"]),
+                                       ("linear_ring4_loop.inc", "MGX_RING4_CLOBBERS", ["MGX_RING4_NT_ASM", "MGX_RING4_NN_ASM"])):
+        text = open(os.path.join(CSRC, name)).read()
+        cl = re.search(r"#define " + cl_macro + r" (.*)", text).group(1)
+        clobbered = set(re.findall(r'"([vsa]\d+)"', cl))
+        assert {"vcc", "scc", "m0", "memory"} <= set(re.findall(r'"(\w+)"', cl))
+        used = set()
+        n_lines = 0
+        for line in text.split("\n"):
+            m = re.match(r'\s*"([^"]*?)(?:\\n\\t)?" \\?$', line)
+            if not m:
+                continue
+            ins = m.group(1).split(";")[0]
+            if not ins or ins.endswith(":"):
+                continue
+            n_lines += 1
+            for kind, a, b in re.findall(r"\b([vsa])\[(\d+):(\d+)\]", ins):
+                used |= {f"{kind}{i}" for i in range(int(a), int(b) + 1)}
+            ins_wo_ranges = re.sub(r"\b[vsa]\[\d+:\d+\]", "", ins)
+            # (operand tokens only: skip the mnemonic, which contains things like 'b32' / 'f32' but never a bare vN / sN / aN)
+            for tok in re.findall(r"(?<![\w.])([vsa]\d+)(?![\w\[])", ins_wo_ranges.split(None, 1)[1] if " " in ins_wo_ranges else ""):
+                used.add(tok)
+        assert n_lines > 500, f"{name}: parsed only {n_lines} instruction lines"
+        missing = sorted(used - clobbered, key=lambda r: (r[0], int(r[1:])))
+        assert not missing, f"{name}: registers used by the asm text but absent from {cl_macro}: {missing[:20]}"
