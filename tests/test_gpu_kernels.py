@@ -362,6 +362,73 @@ def test_rel_attn_bwd_matches_oracle_autograd(B, L, d, M, padcase):
     assert _relerr(dqkv[..., :d], dq2) < 5e-3
 
 
+def _fuzz_cases():
+    """32 seeded draws of (B, L, heads, M, pad pattern): lengths around the kernels' structural boundaries (one key tile, one 128-row
+    query block, 128-key blocks of the asm dK/dV kernel, L % 128 != 0 -> the 32-key kernel), 1-5 heads, E longer than L, and pads
+    trailing / interior / in whole tiles / in every row"""
+    import random
+    rng = random.Random(20260)
+    Ls = [32, 64, 96, 128, 160, 224, 256, 288, 384, 512]
+    out = []
+    for i in range(32):
+        L = rng.choice(Ls)
+        out.append((rng.randint(1, 3), L, rng.randint(1, 5), L + rng.choice([0, 0, 32, 100, 1]), rng.choice(["none", "trail", "interior", "both", "tile", "rows"]), i))
+    return out
+
+
+@pytest.mark.parametrize("B,L,heads,M,pads,seed", _fuzz_cases())
+def test_rel_attn_fuzz_forward_and_backward_match_oracle(B, L, heads, M, pads, seed):
+    """round 6: randomised shapes and pad patterns through mgx_rel_attn_fwd / mgx_rel_attn_bwd against the oracle's autograd --
+    tolerances of the fixed-shape tests above (ctx 2e-2 max|ref|, lse 2e-3, gradients cosine >= 0.999 and rel-L2 <= 2e-2).
+    No row may be fully masked (position 0 of every row is a real token: the parity contract)."""
+    from musicgeneration_amd import ops
+    from oracle import ref_cpu as R
+    dev = _dev()
+    d = 64 * heads
+    g = torch.Generator().manual_seed(7000 + seed)
+    qkv = (torch.randn(B, L, 3 * d, generator=g) * 0.8).to(torch.bfloat16)
+    E = (torch.randn(M, 64, generator=g) * 0.5).to(torch.bfloat16)
+    dctx = torch.randn(B, L, d, generator=g).to(torch.bfloat16)
+    pad = 9
+    tok = torch.randint(0, 9, (B, L), generator=g, dtype=torch.int32)
+    if pads in ("trail", "both"):
+        for b in range(B):
+            n = int(torch.randint(0, L // 2, (1,), generator=g))
+            if n:
+                tok[b, L - n:] = pad
+    if pads in ("interior", "both"):
+        idx = torch.randint(1, L, (B, 4), generator=g)
+        for b in range(B):
+            tok[b, idx[b]] = pad
+    if pads == "tile" and L >= 96:
+        tok[0, 32:64] = pad                                # a whole key tile of pads inside the sequence
+    if pads == "rows":
+        tok[:, 1::2] = pad                                 # every second key of every row
+    assert (tok[:, 0] != pad).all()
+    qr, Er = qkv.float().requires_grad_(True), E.float().requires_grad_(True)
+    ref_ctx, _, ref_logits = R.attn_core(qr, Er, _mask(tok, pad), heads)
+    (ref_ctx * dctx.float()).sum().backward()
+    bits = ops.pad_bitmap(tok.to(dev), pad) if pads != "none" else None
+    qd, Ed = qkv.to(dev), E.to(dev)
+    ctx, lse = ops.rel_attn_fwd(qd, Ed, bits)
+    dE = torch.zeros(M, 64, device=dev)
+    dqkv = ops.rel_attn_bwd(qd, Ed, bits, ctx, dctx.to(dev), lse, dE)
+    torch.cuda.synchronize()
+    ctxc, lsec, dqkv, dE = ctx.float().cpu(), lse.cpu(), dqkv.float().cpu(), dE.cpu()
+    assert torch.isfinite(ctxc).all() and torch.isfinite(dqkv).all() and torch.isfinite(dE).all()
+    rc = ref_ctx.detach()
+    assert (ctxc - rc).abs().max().item() <= 2e-2 * rc.abs().max().item()
+    ref_lse = torch.logsumexp(ref_logits.detach(), -1)
+    assert (lsec - ref_lse).abs().max().item() < 2e-3 * max(1.0, ref_lse.abs().max().item())
+    for name, lo in (("dq", 0), ("dk", d), ("dv", 2 * d)):
+        got, ref = dqkv[..., lo:lo + d], qr.grad[..., lo:lo + d]
+        assert _cos(got, ref) > 0.999, f"{name} cos {_cos(got, ref)}"
+        assert _relerr(got, ref) < 2e-2, f"{name} relerr {_relerr(got, ref)}"
+    assert _cos(dE, Er.grad) > 0.999 and _relerr(dE, Er.grad) < 2e-2
+    if M > L:
+        assert (dE[:M - L] == 0).all()
+
+
 @pytest.mark.parametrize("M,N,K,act", [(128, 128, 64, 0), (300, 340, 128, 0), (1000, 1536, 512, 0),
                                         (257, 256, 512, 1), (64, 64, 256, 1), (32, 1536, 512, 0), (7, 308, 320, 1),
                                         (2048, 512, 512, 0), (2304, 384, 64, 1), (4100, 340, 192, 0),
@@ -420,6 +487,52 @@ def test_linear_backward_kernels(M, N, K, relu):
     ref_gb = gb0 + dy.float().sum(0)
     assert _relerr(gw.cpu(), ref_gw) < 1e-4
     assert _relerr(gb.cpu(), ref_gb) < 1e-4
+
+
+def _gemm_fuzz_cases():
+    import random
+    rng = random.Random(606)
+    out = []
+    for i in range(24):
+        M = rng.choice([1, 7, 32, 33, 100, 257, 1000, 2048, 4099, 8192, 16384 + 32 * rng.randint(0, 3)])
+        N = 8 * rng.randint(1, 96)
+        K = 64 * rng.randint(1, 12)
+        out.append((M, N, K, rng.randint(0, 1), i))
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,act,seed", _gemm_fuzz_cases())
+def test_linear_fuzz_all_three_gemms_match_fp32(M, N, K, act, seed):
+    """round 6: randomised (M, N, K) through mgx_linear_fwd / mgx_linear_dx / mgx_linear_dw -- ragged tiles, one row, widths that are
+    no multiple of the 128 / 256 tiles, reduction lengths with a tail (dX reduces over N, any multiple of 8) -- against an fp32 product
+    of the same bf16 operands on the GPU; tolerances of test_linear_fwd / test_linear_backward_kernels"""
+    from musicgeneration_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9000 + seed)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = a.float() @ w.float().t() + bias
+    if act:
+        ref = ref.relu()
+    out = ops.linear_fwd(a, w, bias, act)
+    assert (out.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-3
+    dy = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    y = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    add = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    wd = (torch.randn(N, K, generator=g) / math.sqrt(N)).to(torch.bfloat16).to(dev)
+    rdx = dy.float() @ wd.float()
+    for relu_y, addend in ((None, None), (y, None), (None, add), (y, add)):
+        r = rdx * (relu_y.float() > 0) if relu_y is not None else rdx
+        r = r + addend.float() if addend is not None else r
+        dx = ops.linear_dx(dy, wd, relu_y, addend)
+        assert (dx.float() - r).abs().max().item() <= 2 ** -6 * r.abs().max().item() + 1e-3, (relu_y is not None, addend is not None)
+    gw0, gb0 = torch.randn(N, K, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+    gw, gb = gw0.clone(), gb0.clone()
+    ops.linear_dw(dy, a, gw, gb)
+    torch.cuda.synchronize()
+    rw, rb = gw0 + dy.float().t() @ a.float(), gb0 + dy.float().sum(0)
+    assert _relerr(gw, rw) < 1e-4 and _relerr(gb, rb) < 1e-4
 
 
 def test_linear_dw_grouped_matches_separate_launches():
