@@ -326,7 +326,8 @@ class MusicTransformer(torch.nn.Module):
     @torch.no_grad()
     def generate_cached(self, prior: torch.Tensor, length: int, temperature: float = 1.0, top_k: int = 0,
                         top_p: float = 1.0, seed: int = 0, use_graph: bool = True, return_probs: bool = False,
-                        grammar=None, prefill: str = "auto", return_cache: bool = False, groups: Optional[int] = None):
+                        grammar=None, prefill: str = "auto", return_cache: bool = False, groups: Optional[int] = None,
+                        masked_groups: bool = False):
         """Sample ``length`` events after ``prior`` [B,P] with per-layer K/V caches and absolute positions
         0..P+length-1 (requires P+length <= max_seq; no sliding window).  Every step runs
         embed -> N x (QKV GEMM, cached relative attention, fc, LN, FFN, LN) -> vocabulary GEMM -> fused
@@ -384,7 +385,12 @@ class MusicTransformer(torch.nn.Module):
             r.probs = probs_step[r.b0:b1] if return_probs else None
             r.kc, r.vc = [k[r.b0:b1] for k in kc], [v[r.b0:b1] for v in vc]
             r.ws = ops.rel_attn_decode_workspace(b1 - r.b0, total, d, dev)       # split-K partials (long caches only)
-            r.stream = torch.cuda.Stream()
+            # masked_groups (round 6 experiment): each sub-batch's stream restricted to its own 1/G of the CUs (ops.masked_stream)
+            if masked_groups and G > 1:
+                per = torch.cuda.get_device_properties(dev).multi_processor_count // G // 8 * 8
+                r.stream = ops.masked_stream(per, g * per, dev).stream
+            else:
+                r.stream = torch.cuda.Stream()
             subs.append(r)
         pe = self.Decoder.pos_encoding.table()
         Pm = st.params

@@ -8,19 +8,21 @@ ap.add_argument("--L", type=int, default=8192); ap.add_argument("--B", type=int,
 ap.add_argument("--d", type=int, default=512); ap.add_argument("--layers", type=int, default=6)
 ap.add_argument("--V", type=int, default=337); ap.add_argument("--no-graph", action="store_true")
 ap.add_argument("--groups", type=int, default=None, help="independent sub-batches on separate streams (default: generate_cached's own choice)")
+ap.add_argument("--masked", action="store_true", help="each group's stream on its own 1/G of the CUs (round 6 experiment)")
 a = ap.parse_args()
 torch.manual_seed(0)
 mt = MusicTransformer(embedding_dim=a.d, vocab_size=a.V, num_layer=a.layers, max_seq=a.L, dropout=0.0).cuda().eval()
 prior = torch.randint(0, a.V - 1, (a.B, 1), device="cuda")
-mt.generate_cached(prior, 64, top_p=0.9, seed=1, use_graph=not a.no_graph, groups=a.groups)      # warm-up
+mt.generate_cached(prior, 64, top_p=0.9, seed=1, use_graph=not a.no_graph, groups=a.groups, masked_groups=a.masked)      # warm-up
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-out = mt.generate_cached(prior, a.L - 1, top_p=0.9, seed=0, use_graph=not a.no_graph, groups=a.groups)
+out = mt.generate_cached(prior, a.L - 1, top_p=0.9, seed=0, use_graph=not a.no_graph, groups=a.groups, masked_groups=a.masked)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 steps = a.L - 1
 kv_bytes = a.layers * 2 * a.B * a.d * 2 * (steps * (steps + 1) / 2)           # K and V rows read over the whole run
 w_bytes = steps * 2 * sum(p.numel() for p in mt.parameters())
-print(f"cfg5 decode (groups={a.groups}): B={a.B} L={a.L} d={a.d} layers={a.layers}: {dt:.2f} s, {a.B*steps/dt:,.0f} tokens/s, "
+tag = " masked" if a.masked else ""
+print(f"cfg5 decode (groups={a.groups}{tag}): B={a.B} L={a.L} d={a.d} layers={a.layers}: {dt:.2f} s, {a.B*steps/dt:,.0f} tokens/s, "
       f"{1e3*dt/steps:.3f} ms/step avg; algorithmic KV traffic {kv_bytes/dt/1e9:,.0f} GB/s (+weights {w_bytes/dt/1e9:,.0f} GB/s)")
 assert out.shape == (a.B, a.L) and int(out.max()) < a.V
