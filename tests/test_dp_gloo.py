@@ -113,6 +113,32 @@ def _worker(rank, world, port, q):
             dp.bucket_ready("nope")
         m = dp.all_reduce_scalar_mean(torch.tensor(float(rank)))
         assert abs(m.item() - 0.5) < 1e-7
+        # merged buckets (bench.py --buckets K, DataParallel(groups=K); round 6): four buckets -> two contiguous groups; a group's
+        # all-reduce goes out when its LAST member reports ready, whatever the order, and the result is the same sum
+        cut = [0, offs[len(names) // 4], offs[half], offs[3 * len(names) // 4], n]
+        st.buckets = [(f"b{i}", cut[i], cut[i + 1]) for i in range(4)]
+        dp.merge_buckets(2)
+        units = dp.bucket_names()
+        assert len(units) == 2 and "+".join(units).split("+") == ["b0", "b1", "b2", "b3"]
+        sl = dp._slices()
+        assert sl[0][1] == 0 and sl[0][2] == sl[1][1] and sl[1][2] == n                  # the groups tile the flat buffer
+        st.grad.copy_(grads(mine))
+        issued = []
+        for b in ("b3", "b2", "b1", "b0"):                                                # backward order: top of the buffer first
+            dp.bucket_ready(b)
+            issued.append(len(dp._works))
+        members = [u.split("+") for u in units]
+        expect, done_ = [], 0
+        for b in ("b3", "b2", "b1", "b0"):
+            grp = next(mm for mm in members if b in mm)
+            if b == grp[0]:                                                               # its lowest member arrives last in backward order
+                done_ += 1
+            expect.append(done_)
+        assert issued == expect, (issued, expect, units)
+        dp.wait_all()
+        assert (st.grad * dp.grad_scale - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+        dp.merge_buckets(8)                                                               # >= the number of buckets: one all-reduce per bucket again
+        assert dp.bucket_names() == ["b0", "b1", "b2", "b3"]
         q.put((rank, "ok"))
     except Exception as e:  # noqa
         import traceback
