@@ -284,17 +284,13 @@ class MusicTransformer(torch.nn.Module):
     @torch.no_grad()
     def next_token_probs(self, window: torch.Tensor, reference_mask: bool = False) -> torch.Tensor:
         """softmax of the logits that follow the last token of ``window`` [B,W].  Default: causal semantics (the
-        training-time mask, see DESIGN.md 'decode semantics'); the window is right-padded to a multiple of 32 with pad
-        tokens, which lie in the masked future of every real position.  ``reference_mask=True``: the reference's own
+        training-time mask, see DESIGN.md 'decode semantics'); windows that are no multiple of 32 are right-padded inside
+        ``_logits`` with pad tokens, which lie in the masked future of every real position.  ``reference_mask=True``: the reference's own
         sampling call, ``Decoder(window, mask=None)`` (network.py:60-62)."""
         B, W = window.shape
         if reference_mask:
             return torch.softmax(self._logits_nomask(window)[:, W - 1].float(), -1)
-        Lp = (W + 31) // 32 * 32
-        if Lp != W:
-            padcol = torch.full((B, Lp - W), self.pad_token, dtype=window.dtype, device=window.device)
-            window = torch.cat([window, padcol], 1)
-        was = self.training
+        was = self.training                   # (_logits pads the window to the kernels' 32-key tile itself)
         self.eval()
         logits = self._logits(window)[:, W - 1].float()
         self.train(was)

@@ -749,3 +749,29 @@ def test_any_sequence_length_up_to_max_seq_matches_the_oracle(max_seq, L):
         lg, ws = mt(x.to(torch.int32).cuda())
     assert tuple(lg.shape) == (B, L, V) and len(ws) == nl and tuple(ws[0].shape) == (B, d // 64, L, L)
     assert (ws[0].sum(-1) - 1).abs().max().item() < 2e-2
+
+
+def test_sampling_windows_reach_past_a_max_seq_that_is_no_multiple_of_32():
+    """next_token_probs at max_seq = 40 (the kernels' tiles are 32 keys): windows of 33-40 tokens pad to 64 rows > max_seq -- zero rows
+    for the positional table and the relative embedding (network._params_for_padded_E) in both the causal and the reference's
+    mask=None call (network.py:60-62) -- against the oracle"""
+    from musicgeneration_amd.network import MusicTransformer
+    from oracle import ref_cpu as R
+    V, d, nl, M = 60, 128, 2, 40
+    p0 = R.init_params(V, d, nl, M, seed=51)
+    for k in p0:
+        if k.endswith("embedding.weight") or k.endswith("rga.E"):
+            p0[k] = p0[k] * 0.3
+    mt = MusicTransformer(embedding_dim=d, vocab_size=V, num_layer=nl, max_seq=M, dropout=0.0)
+    mt.load_state_dict({k: v.clone() for k, v in p0.items()})
+    mt = mt.cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    for W in (33, 37, 40, 7):
+        win = torch.randint(0, V - 1, (2, W), generator=g)
+        for causal in (True, False):
+            lg, _ = R.model_forward(p0, win, V - 1, causal=causal)
+            ref = lg.softmax(-1)[:, -1]
+            got = mt.next_token_probs(win.cuda(), reference_mask=not causal).cpu()
+            assert (got - ref).abs().max().item() < 2e-2, (W, causal)
+    out = mt.generate(win[:, :4].cuda(), length=3)
+    assert tuple(out.shape) == (2, 7)
