@@ -60,11 +60,23 @@ def test_train_cli_with_the_co_residency_knobs(tmp_path, capsys):
     data, out = str(tmp_path / "data"), str(tmp_path / "ckpt") + "/"
     _dataset(data)
     before = torch.cuda.current_stream().cuda_stream
-    train.main(["-d", data, "-s", out, "-b", "4", "-M", "64", "--num-layers", "1", "--d-model", "128", "-e", "1", "-i", "1",
-                "--rccl-cus", "16", "--buckets", "2", "--nccl-channels", "2"])
+    common = ["-d", data, "-s", out, "-b", "4", "-M", "64", "--num-layers", "1", "--d-model", "192", "-i", "1",
+              "--rccl-cus", "16", "--buckets", "2", "--nccl-channels", "2"]
+    train.main(common + ["-e", "1"])
     log = capsys.readouterr().out
     assert "Train >>>> Loss:" in log and "Done saving" in log
     assert torch.cuda.current_stream().cuda_stream == before and ops.stream_plan() is None
+    # d_model = 192 (three heads; FFN width 96, zero-padded to 128 inside the flat buffers): the checkpoint holds the reference's
+    # shapes, and a resumed run loads parameters and Adam state back into the padded storage
+    cks = sorted(glob.glob(out + "train-*.pth"))
+    ck = torch.load(cks[-1], map_location="cpu", weights_only=False)
+    assert ck["net"]["Decoder.enc_layers.0.FFN_suf.weight"].shape == (192, 96) and ck["net"]["Decoder.enc_layers.0.FFN_pre.weight"].shape == (96, 192)
+    names = [n for n in ck["net"]]
+    i_suf = ck["optimizer"]["param_names"].index("Decoder.enc_layers.0.FFN_suf.weight")
+    assert ck["optimizer"]["state"][i_suf]["exp_avg"].shape == (192, 96) and len(names) == len(ck["optimizer"]["param_names"])
+    train.main(common + ["-e", str(ck["epoch"] + 2), "-m", cks[-1]])
+    log = capsys.readouterr().out
+    assert "Success load" in log and "Train >>>> Loss:" in log
 
 
 def test_melody_rnn_train_cli(tmp_path, capsys):
