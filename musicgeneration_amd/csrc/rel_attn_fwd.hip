@@ -44,7 +44,7 @@ using namespace relattn;
 #ifndef MGX_FWD_PEEL
 #define MGX_FWD_PEEL 0      // timing experiments only (tools/peel_fwd.sh): 1 no E-fragment loads in the main loop | 2 no band round trip |
 #endif                      // 4 no exponentials | 8 K / V prefetch re-reads tile 0 | 16 no parity XOR of the band-store addresses | 32 no row-sum
-                            // adds | 64 no redo branch anywhere (main loop AND general body) | 128 no general steps after a main loop; results are then wrong
+                            // adds | 64 no redo branch anywhere (main loop AND general body) | 128 no general steps after a main loop | 256 no fma in front of the exponentials; results are then wrong
 namespace {
 constexpr int WAVES = 4;
 constexpr int OFF_K = 0;                                        // 2 x 4 KiB   image R
@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256, 3) void rel_attn_fwd_kernel(
         float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float ar = __builtin_fmaf(c[r], LOG2E, mneg);
+            // (peel 256, round 6, timing only: the exponent's argument taken as it is -- what the 16 v_fma of a tile cost, i.e. what folding
+            //  log2(e) / 8 into the q operand and -m into the chunk product's initial accumulator could win at most)
+            const float ar = (MGX_FWD_PEEL & 256) ? c[r] : __builtin_fmaf(c[r], LOG2E, mneg);
             p[r] = (MGX_FWD_PEEL & 4) ? ar * 1e-9f : __builtin_amdgcn_exp2f(ar);
         }
 #pragma unroll
