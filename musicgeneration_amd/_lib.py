@@ -124,6 +124,17 @@ def ptr(t) -> int:
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def stream_ptr() -> int:
+    """raw hipStream_t of torch's current stream on the current device.  Through torch's C entry point: the Python-level
+    ``torch.cuda.current_stream().cuda_stream`` costs ~8 us per call (device-index bookkeeping, a Stream object), i.e. 0.4 ms of
+    a training step's ~150 launches -- nothing at the bench shape, a fifth of the host's time per step where the step is a few
+    milliseconds (d_model 256, batch 2-6: round 6, profiles/r06_host_overhead.txt)."""
+    global _raw_stream
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    if _raw_stream is None:
+        raw, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        _raw_stream = (lambda: raw(dev())) if (raw is not None and dev is not None) else (lambda: torch.cuda.current_stream().cuda_stream)
+    return _raw_stream()
