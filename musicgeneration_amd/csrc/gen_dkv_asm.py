@@ -78,6 +78,8 @@ ST_PINS = [int(x) for x in os.environ.get("MGX_DKV64_STPIN", "").split(",") if x
 # experiment (round 6): the two waves of a workgroup run the same instruction stream in lock step (one barrier per iteration), so their
 # dS stores -- 1 KB each through the CU's one store path -- always collide; "a,b,c,d:e,f,g,h" gives wave 0 and wave 1 their OWN shadows
 # for the four stores (every store is emitted twice, under EXEC = (w == 0) / (w == 1); an EXEC = 0 store moves no data)
+STAMP_WAIT = os.environ.get("MGX_DKV64_STAMP_WAIT", "") == "1"      # stamp builds: time the DMA wait and the barrier at the top of a main body on their own
+STAMP_PEEL = int(os.environ.get("MGX_DKV64_STAMP_PEEL", "0"))         # stamp builds: PEEL bits applied to the stamped loop (e.g. 1: no dS stores)
 STAGGER = [[int(x) for x in part.split(",")] for part in os.environ.get("MGX_DKV64_STAGGER", "").split(":") if part]
 S_W0M, S_W1M = 18, 20   # (main bodies, STAGGER) lane masks of wave 0 / wave 1: all ones or zero -- the registers of S_FULL, which only the masked bodies use
 PEEL = 0             # timing experiments (results wrong): 1 no dS stores | 2 no E loads | 4 no DMA | 8 no skew | 16 no exp | 32 no merge | 64 no stats reads | 128 no tr reads | 256 only wave 0 stores dS | 512 control of 256 | 1024 no barrier in the loop bodies
@@ -175,9 +177,15 @@ class Step:
         g = self.g
 
         def f():
+            if STAMP and STAMP_WAIT:                       # stamp builds with MGX_DKV64_STAMP_WAIT=1: sums 5 / 6 = the counted wait / the barrier alone
+                g.stamp(None)
             g.wait_vm_tag(dma_tag)                         # this wave's pieces of tile n+1 have landed
+            if STAMP and STAMP_WAIT:
+                g.stamp(5)
             if not (PEEL & 1024):                          # PEEL 1024 (round 6, timing only): what the per-iteration barrier of the two waves costs
                 g.raw("s_barrier")
+            if STAMP and STAMP_WAIT:
+                g.stamp(6)
         return [f]
 
     def dma_addr(self):
@@ -663,7 +671,9 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     if not (ST_PINS or STAGGER or ST_CACHE != "nt"):
         for STAMP in (False, True):
+            PEEL = STAMP_PEEL if STAMP else 0
             write(here)
+        PEEL = 0
     STAMP = False
     PEEL = int(os.environ.get("MGX_DKV64_PEEL", "0"))
     if PEEL or ST_PINS or STAGGER or ST_CACHE != "nt":          # experiment builds: a loop of their own, never the tracked one
@@ -673,7 +683,7 @@ def main():
 
 def write(here):
     lines, g = generate()
-    path = os.path.join(here, "rel_attn_dkv64_loop_peel.inc" if PEEL else "rel_attn_dkv64_loop_stamp.inc" if STAMP else "rel_attn_dkv64_loop.inc")
+    path = os.path.join(here, "rel_attn_dkv64_loop_stamp.inc" if STAMP else "rel_attn_dkv64_loop_peel.inc" if PEEL else "rel_attn_dkv64_loop.inc")
     import io
     f = io.StringIO()
     if True:

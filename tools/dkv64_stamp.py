@@ -44,7 +44,8 @@ for kb in range(a.L // 128):
         per = [m[k].item() / max(it, 1) for k in range(5)]
         if w == 0:
             tot += torch.stack([m[12], m[13], m[14], torch.tensor(loop)])
+        extra = f" | DMA wait {m[5].item() / max(it, 1):6.0f}  barrier {m[6].item() / max(it, 1):6.0f} per iteration" if m[5].item() + m[6].item() > 0 else ""
         print(f"   {kb:2d} w{w} {int(m[8].item()):4d} {int(it):4d} | {m[12].item():10.0f} {m[13].item():10.0f} {m[14].item():10.0f} | {loop / max(it, 1):8.0f}   "
-              + " ".join(f"{p:7.0f}" for p in per) + f" | {m[12].item() - loop:8.0f}")
+              + " ".join(f"{p:7.0f}" for p in per) + f" | {m[12].item() - loop:8.0f}" + extra)
 print("sum over key blocks (wave 0): asm %.0f (main bodies %.0f)  epilogue %.0f  total %.0f   shares: main bodies %.3f  rest of asm %.3f  epilogue %.3f"
       % (tot[0], tot[3], tot[1], tot[2], tot[3] / tot[2], (tot[0] - tot[3]) / tot[2], tot[1] / tot[2]))
